@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE'S OWN CODE.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+What is executed from the reference, unmodified, imported from /root/reference:
+  * octree_np.encode / getDecodeFromPc / decode                      (octree_np.py)
+  * pn_kit.encode_sampled_np / decode_sampled_np / binary_array_to_byte_array /
+    byte_array_to_binary_array / farthest_point_sample_batch / index_points /
+    normalize / denormalize / pmf_to_cdf / PointNet / MLP / SetAbstraction (pn_kit.py)
+  * AE.AE / AE.ConditionalProbabilityModel                           (AE.py)
+
+pn_kit.py and AE.py import pytorch3d, pyntcloud and plyfile at module import; none
+of the three is installed in the image (no network).  Their NAMES are bound here
+to placeholders so the imports resolve: file-I/O names raise if called; the only
+third-party function the captured paths call -- pytorch3d's knn_points inside
+SetAbstraction.forward (pn_kit.py:190) -- is supplied by the oracle's definition
+(oracle/pcc_oracle.c: orc_knn).  Fixtures that depend on it are therefore pinned
+for the reference's own arithmetic (convs, centring, max-pool) but PARITY UNPINNED
+for pytorch3d's tie order; the test docstrings say so.
+
+Fixtures are data only (inputs are regenerated from seeds; expected outputs are
+stored); no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import cport, ref_model  # noqa: E402
+from tests import synth  # noqa: E402
+
+
+def _bind_absent_third_party():
+    def absent(name):
+        def f(*a, **k):
+            raise RuntimeError(f"{name} is not installed in this image")
+        return f
+
+    p3d = types.ModuleType("pytorch3d")
+    ops = types.ModuleType("pytorch3d.ops")
+    knn = types.ModuleType("pytorch3d.ops.knn")
+    loss = types.ModuleType("pytorch3d.loss")
+    knn.knn_points = ref_model.knn_points          # oracle-defined (see module docstring)
+    knn.knn_gather = absent("pytorch3d.knn_gather")
+    knn._KNN = object
+    ops.knn = knn
+    ops.knn_points = knn.knn_points
+    ops.knn_gather = knn.knn_gather
+    ops.ball_query = absent("pytorch3d.ball_query")
+    ops.sample_farthest_points = absent("pytorch3d.sample_farthest_points")
+    loss.chamfer_distance = absent("pytorch3d.chamfer_distance")
+    p3d.ops, p3d.loss = ops, loss
+    pynt = types.ModuleType("pyntcloud")
+    pynt.PyntCloud = absent("pyntcloud.PyntCloud")
+    ply = types.ModuleType("plyfile")
+    ply.PlyData = absent("plyfile.PlyData")
+    for m in (p3d, ops, knn, loss, pynt, ply):
+        sys.modules[m.__name__] = m
+
+
+def main():
+    _bind_absent_third_party()
+    sys.path.insert(0, REF)
+    import octree_np as ref_octree
+    import pn_kit as ref_pn_kit
+    import AE as ref_AE
+
+    torch.set_num_threads(1)
+
+    # ---------------------------------------------------------------- 1. octree bit streams
+    oc = {}
+    cases = synth.octree_cases()
+    bits_all, bits_off, dec_all, uniq_cnt = [], [0], [], []
+    for pc, depth in cases:
+        b = ref_octree.encode(pc, 1, depth)
+        bits_all.append(b.astype(np.uint8))
+        bits_off.append(bits_off[-1] + b.shape[0])
+        dec_all.append(ref_octree.decode(b, 1).astype(np.float32))
+        uniq_cnt.append(ref_octree.getDecodeFromPc(pc, 1, depth).shape[0])
+    oc["bits"] = np.concatenate(bits_all)
+    oc["bits_off"] = np.array(bits_off, dtype=np.int64)
+    oc["decoded_reference"] = np.stack(dec_all)
+    oc["unique_count"] = np.array(uniq_cnt, dtype=np.int32)
+    # short / degenerate streams through decode
+    short = synth.short_streams()
+    oc["short_decoded"] = np.stack([ref_octree.decode(np.array(s, dtype=np.uint8), 1) for s in short])
+    np.savez_compressed(os.path.join(HERE, "octree.npz"), **oc)
+
+    # ---------------------------------------------------------------- 2. depth search + packing
+    ds = {}
+    sb, so, nb, packed, poff, unpk = [], [0], [], [], [0], []
+    for pcs, N, K in synth.depth_search_cases():
+        codes, total = ref_pn_kit.encode_sampled_np(pcs, scale=1, N=N, min_bpp=ref_pn_kit.OCTREE_BPP_DICT[K])
+        assert len(codes) == 1
+        sb.append(codes[0].astype(np.uint8))
+        so.append(so[-1] + codes[0].shape[0])
+        nb.append(total)
+        by = ref_pn_kit.binary_array_to_byte_array(codes[0])
+        packed.append(np.frombuffer(bytes(by), dtype=np.uint8))
+        poff.append(poff[-1] + len(by))
+        unpk.append(ref_pn_kit.byte_array_to_binary_array(by).astype(np.uint8))
+    ds["bits"] = np.concatenate(sb)
+    ds["bits_off"] = np.array(so, dtype=np.int64)
+    ds["total_bits"] = np.array(nb, dtype=np.int64)
+    ds["bytes"] = np.concatenate(packed)
+    ds["bytes_off"] = np.array(poff, dtype=np.int64)
+    ds["unpacked"] = np.concatenate(unpk)
+    # tail cases len % 8 in 0..7
+    tails = synth.pack_tail_cases()
+    tb = [np.frombuffer(bytes(ref_pn_kit.binary_array_to_byte_array(t)), dtype=np.uint8) for t in tails]
+    ds["tail_bytes"] = np.concatenate(tb)
+    ds["tail_bytes_off"] = np.cumsum([0] + [len(t) for t in tb]).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "depth_search_pack.npz"), **ds)
+
+    # ---------------------------------------------------------------- 3. FPS / normalize / gather / cdf
+    fp = {}
+    idxs, starts, norms, cents, longs = [], [], [], [], []
+    for i, (pc, S) in enumerate(synth.fps_cases()):
+        x = torch.from_numpy(pc).unsqueeze(0)
+        torch.manual_seed(100 + i)
+        idx = ref_pn_kit.farthest_point_sample_batch(x, S)      # random start (pn_kit.py:321)
+        starts.append(int(idx[0, 0]))
+        idxs.append(idx[0].numpy().astype(np.int64))
+        xn, c, l = ref_pn_kit.normalize(x, margin=0.01)
+        cents.append(c.numpy()); longs.append(float(l))
+        norms.append(xn[0, ::257].numpy())                      # strided sample of the output
+        back = ref_pn_kit.denormalize(xn, c, l, margin=0.01)
+        fp[f"denorm_sample_{i}"] = back[0, ::257].numpy()
+        g = ref_pn_kit.index_points(x, idx)
+        fp[f"gather_{i}"] = g[0].numpy()
+    fp["starts"] = np.array(starts, dtype=np.int64)
+    for i, a in enumerate(idxs):
+        fp[f"fps_idx_{i}"] = a
+        fp[f"norm_sample_{i}"] = norms[i]
+    fp["centers"] = np.stack(cents).astype(np.float32)
+    fp["longest"] = np.array(longs, dtype=np.float32)
+    pmf = synth.pmf_case()
+    fp["cdf"] = ref_pn_kit.pmf_to_cdf(torch.from_numpy(pmf)).numpy()
+    np.savez_compressed(os.path.join(HERE, "pnkit_float.npz"), **fp)
+
+    # ---------------------------------------------------------------- 4. model modules
+    md = {}
+    K, k, d, L = synth.MODEL_CFG
+    ae = ref_AE.AE(K=K, k=k, d=d, L=L).eval()
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    prob = ref_AE.ConditionalProbabilityModel(L, d).eval()
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, synth.PROB_SEED, gain=synth.PROB_GAIN))
+    md["ae_keys"] = np.array(list(ae.state_dict().keys()))
+    md["ae_shapes"] = np.array([str(tuple(v.shape)) for v in ae.state_dict().values()])
+    md["prob_keys"] = np.array(list(prob.state_dict().keys()))
+    md["prob_shapes"] = np.array([str(tuple(v.shape)) for v in prob.state_dict().values()])
+    patches = torch.from_numpy(synth.patch_batch(K))               # (P,K,3)
+    with torch.no_grad():
+        xt = patches.transpose(1, 2).contiguous()                  # (P,3,K) as compress.py:107
+        _, feat = ae.sa(xt)                                        # pn_kit.py:164-211 (oracle kNN inside)
+        md["sa_feat_sample"] = feat[:, :, ::8].numpy()
+        lat = ae.pn(torch.cat((xt, feat), dim=1))                  # pn_kit.py:124-144
+        md["pn_latent_raw"] = lat.numpy()
+        rec, latent, latent_q = ae(patches)                        # AE.py:34-55
+        md["ae_latent"] = latent.numpy()
+        md["ae_latent_q"] = latent_q.numpy()
+        md["ae_recon"] = rec.numpy()
+        # decoder from a fixed integer latent (decompress.py:97-102)
+        lq = torch.from_numpy(synth.latent_case(patches.shape[0], d, L))
+        lin = ae.inv_pool(lq).view(lq.shape[0], -1, ae.k)
+        mlp_in = torch.cat((lin, lq.unsqueeze(-1).tile((1, 1, ae.k))), dim=1)
+        md["dec_lin_sample"] = lin[:, ::17, ::5].numpy()
+        md["dec_out"] = ae.inv_mlp(mlp_in).transpose(2, 1).numpy()
+        centres = torch.from_numpy(synth.centres_case())           # (1,S,3)
+        pm = prob(centres)                                         # AE.py:107-123
+        md["pmf"] = pm.numpy()
+        md["cdf"] = ref_pn_kit.pmf_to_cdf(pm).numpy()
+    np.savez_compressed(os.path.join(HERE, "model.npz"), **md)
+    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""Seeded test inputs shared by tests/golden/make_golden.py and the tests themselves.
+
+Fixtures store only expected OUTPUTS; inputs are regenerated here from fixed seeds
+(numpy Generator/PCG64 streams are stable across the numpy 2.x in this image).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "point-cloud-compression_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+from pccx import synth as cloud_synth  # noqa: E402
+
+MODEL_CFG = (256, 128, 16, 7)  # K, k, d, L: compress.py:30-34 defaults
+AE_SEED, PROB_SEED = 11, 12
+AE_LAST_GAIN = {"pn.mlp_Modules.3.0": 40.0}   # spread the quantiser's symbols over -3..3
+PROB_GAIN = 2.0                               # non-flat pmf so the range coder is exercised
+
+
+def octree_cases():
+    """[(pc (n,3) f32, depth)]: random / clustered / duplicates / boundary values."""
+    rng = np.random.default_rng(2024)
+    out = []
+    for t in range(96):
+        n = int(rng.integers(1, 100))
+        depth = int(rng.choice([1, 2, 3, 5, 7, 9, 12]))
+        kind = t % 6
+        pc = rng.random((n, 3)).astype(np.float32)
+        if kind == 1:
+            pc = (0.5 + 0.05 * rng.standard_normal((n, 3))).astype(np.float32)
+        elif kind == 2:
+            pc[int(rng.integers(0, n))] = pc[0]
+        elif kind == 3:
+            pc[0] = [1.0, 0.3, 0.2]
+            pc[-1] = [0.0, 0.0, 0.0]
+        elif kind == 4:
+            pc[0] = [-0.01, 0.5, 1.2]
+        elif kind == 5:
+            pc = np.float32(0.005) + np.float32(0.99) * pc   # the range normalize() produces
+        out.append((pc, depth))
+    # S = 64 at the depth the codec actually uses
+    for s in range(8):
+        pc = (0.005 + 0.99 * np.random.default_rng(500 + s).random((64, 3))).astype(np.float32)
+        out.append((pc, 7))
+    return out
+
+
+def short_streams():
+    return [[], [0], [1], [1, 0, 1], [1] * 8, [1, 0, 0, 0, 0, 0, 0, 0], [0] * 8, [1, 0, 1, 0, 1, 1, 0, 0, 1, 1],
+            [1, 1, 0, 0, 0, 0, 0, 1, 1, 1, 1]]
+
+
+def depth_search_cases():
+    """[(pcs (1,S,3), N, K)] for pn_kit.encode_sampled_np."""
+    out = []
+    for i, (S, N, K) in enumerate([(64, 8192, 256), (64, 8192, 256), (32, 8192, 512), (128, 8192, 128),
+                                   (16, 2048, 256), (8, 2048, 512), (64, 8192, 256), (64, 8192, 256),
+                                   (256, 8192, 64), (4, 1024, 512)]):
+        rng = np.random.default_rng(900 + i)
+        pc = (0.005 + 0.99 * rng.random((S, 3))).astype(np.float32)
+        if i == 6:   # a duplicate centre: the shape test never passes -> 16 attempts, depth-16 code kept
+            pc[5] = pc[9]
+        if i == 7:   # two centres 2^-15 apart: deep search
+            pc[1] = pc[0] + np.float32(2.0 ** -15)
+        out.append((pc[None], N, K))
+    return out
+
+
+def pack_tail_cases():
+    rng = np.random.default_rng(77)
+    return [rng.integers(0, 2, size=n).astype(np.uint8) for n in (1, 2, 3, 7, 8, 9, 15, 16, 17, 63, 64, 2385)]
+
+
+def fps_cases():
+    """[(pc (N,3) f32, S)]."""
+    return [(cloud_synth.cad_cloud(11, 8192), 64), (cloud_synth.cad_cloud(12, 8192), 64),
+            (cloud_synth.cad_cloud(13, 2048), 8), (np.random.default_rng(5).random((1000, 3)).astype(np.float32), 33),
+            (cloud_synth.cad_cloud(14, 8192), 512)]
+
+
+def pmf_case():
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((1, 64, 16, 7)).astype(np.float32) * 2
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def patch_batch(K, P=2, seed=21):
+    """(P,K,3) patches shaped as compress.py:105-108 produces them: kNN of a centre in a
+    normalised cloud, centred, scaled by (N/N0)^(1/3) = 2."""
+    pc = cloud_synth.cad_cloud(seed, 8192).astype(np.float32)
+    lo, hi = pc.min(0), pc.max(0)
+    pc = ((pc - (hi + lo) / 2) * np.float32(0.99) / (hi - lo).max() + np.float32(0.5)).astype(np.float32)
+    rng = np.random.default_rng(seed + 1)
+    out = []
+    for c in pc[rng.choice(pc.shape[0], size=P, replace=False)]:
+        d = ((pc - c) ** 2).sum(1)
+        nn = pc[np.argsort(d, kind="stable")[:K]]
+        out.append((nn - c) * np.float32(2.0))
+    return np.stack(out).astype(np.float32)
+
+
+def latent_case(P, d, L):
+    rng = np.random.default_rng(41)
+    return rng.integers(-(L // 2), L // 2 + 1, size=(P, d)).astype(np.float32)
+
+
+def centres_case(S=64):
+    rng = np.random.default_rng(51)
+    q = rng.integers(0, 128, size=(S, 3))
+    return ((q + 0.5) / 128.0).astype(np.float32)[None]
