@@ -1,0 +1,115 @@
+/*
+ * pccx.h -- C ABI of libpccx.so, the MI355X (gfx950) implementation of the
+ * patch-based compress / decompress hot path of rhmes/point-cloud-compression.
+ *
+ * The reference has no FFI of its own: its hot path is a set of Python callables
+ * (pn_kit.py, octree_np.py, AE.py) plus pytorch3d / torchac functions they import.
+ * Each entry point below replaces one of those callables (cited as file:line
+ * relative to the reference root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - tensors are dense, row-major, fp32 / int32 / int64 / uint8 as declared;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work,
+ *     they never synchronise;
+ *   - return value: 0 on success, otherwise a negative pccx_status; the text of the
+ *     last error on the calling thread is returned by pccx_last_error().
+ */
+#ifndef PCCX_H
+#define PCCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCCX_API __attribute__((visibility("default")))
+
+typedef enum {
+    PCCX_OK = 0,
+    PCCX_ERR_ARG = -1,        /* bad shape / unsupported size */
+    PCCX_ERR_HIP = -2,        /* a HIP runtime call failed */
+    PCCX_ERR_UNSUPPORTED = -3
+} pccx_status;
+
+PCCX_API const char *pccx_last_error(void);
+PCCX_API int pccx_version(void);
+
+/* ---- geometry ---------------------------------------------------------------------------- */
+
+/* pn_kit.normalize (pn_kit.py:47-60), batched: per cloud b, centre on the bounding-box
+ * middle, scale the longest side to (1-margin), shift by +0.5.
+ * pc,out: (B,N,3) f32 (may alias); center: (B,3); longest: (B). */
+PCCX_API int pccx_normalize(const float *pc, int B, int N, double margin, float *out, float *center,
+                            float *longest, void *stream);
+
+/* pn_kit.denormalize (pn_kit.py:62-66). pc,out: (B,N,3). */
+PCCX_API int pccx_denormalize(const float *pc, int B, int N, double margin, const float *center,
+                              const float *longest, float *out, void *stream);
+
+/* pn_kit.farthest_point_sample_batch (pn_kit.py:309-330) with the random start (:321) made an
+ * explicit argument; also pytorch3d sample_farthest_points (pointnet_sa_module.py:12) with
+ * start 0.  xyz: (B,N,3); start_idx: (B) int32 device, or NULL for start 0; idx_out: (B,npoint)
+ * int64.  workspace: B*N floats, required only when N > 16384 (else may be NULL). */
+PCCX_API int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_t *start_idx,
+                      int64_t *idx_out, float *workspace, void *stream);
+
+/* pn_kit.index_points (pn_kit.py:332-360) / pytorch3d knn_gather (pointnet_sa_module.py:28):
+ * out[b,m,:] = points[b, idx[b,m], :].  points: (B,N,C); idx: (B,M) int64 (negative -> row 0,
+ * the clamp of pointnet_sa_module.py:27); out: (B,M,C). */
+PCCX_API int pccx_gather(const float *points, int B, int N, int C, const int64_t *idx, int M,
+                         float *out, void *stream);
+
+/* pytorch3d knn_points(p1=q, p2=ref, K, return_nn) (compress.py:71, pn_kit.py:190, eval.py:132):
+ * squared L2, K smallest ascending, ties by lower index.  q: (B,M,3); ref: (B,N,3);
+ * dists: (B,M,K) f32; idx: (B,M,K) int64; nn: (B,M,K,3) or NULL.  K <= 1024, K <= N <= 32768.
+ * If patch_scale != 0, nn instead receives (ref[idx]-q)*patch_scale: the fused form of
+ * compress.py:72 (subtract centre) and compress.py:108 (scale by (N/N0)^(1/3)). */
+PCCX_API int pccx_knn(const float *q, int B, int M, const float *ref, int N, int K, float *dists,
+                      int64_t *idx, float *nn, float patch_scale, void *stream);
+
+/* pytorch3d ball_query(p1=q, p2=ref, K, radius) (pointnet_sa_module.py:18): first K indices in
+ * index order with d2 < radius^2, padded with -1 (dists padded with 0). */
+PCCX_API int pccx_ball_query(const float *q, int B, int M, const float *ref, int N, int K,
+                             float radius, float *dists, int64_t *idx, void *stream);
+
+/* One-directional nearest neighbour: for each x in X (B,P,3) the min over Y (B,Q,3) of |x-y|^2.
+ * d2: (B,P); nn: (B,P) int32 or NULL.  Building block of pytorch3d chamfer_distance (AE.py:67,
+ * eval.py:204) and of eval.py's D1 loop (eval.py:73-81). */
+PCCX_API int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, float *d2, int32_t *nn,
+                          void *stream);
+
+/* ---- integer path: octree of the S sampled centres ------------------------------------------- */
+
+/* Bytes needed per cloud for the bit array (one byte per bit) of pccx_octree_encode. */
+PCCX_API int pccx_octree_bits_capacity(int S);
+
+/* pn_kit.encode_sampled_np (pn_kit.py:380-401) = depth search over octree_np.encode
+ * (octree_np.py:10-45) + octree_np.getDecodeFromPc (octree_np.py:114-133), scale = 1, followed by
+ * pn_kit.binary_array_to_byte_array (pn_kit.py:463-467).
+ * centres: (B,S,3) f32, S <= 1024; N: points per cloud (bpp denominator); min_bpp as
+ * pn_kit.OCTREE_BPP_DICT[K].
+ * bits:   (B,cap) uint8, one byte per bit, cap = pccx_octree_bits_capacity(S);
+ * nbits:  (B) int32 stream length in bits;  depth: (B) int32 (DEPTH as the reference leaves it);
+ * bytes:  (B,(cap+7)/8) uint8 packed stream, last partial byte right-aligned; nbytes: (B) int32. */
+PCCX_API int pccx_octree_encode(const float *centres, int B, int S, int N, double min_bpp,
+                                uint8_t *bits, int32_t *nbits, int32_t *depth, uint8_t *bytes,
+                                int32_t *nbytes, void *stream);
+
+/* pn_kit.decode_sampled_np -> octree_np.decode (octree_np.py:47-112) from the packed stream
+ * (decompress.py:80-83 unpacks with pn_kit.byte_array_to_binary_array first).
+ * mode 0 = "reference": bug-compatible with octree_np.decode as written (only the first 8 bits are
+ *          consumed; output padded to 64 points);  S_out must be 64.
+ * mode 1 = "full": level-by-level decode (the build's extension), descending-Morton order; the
+ *          first min(count,S_out) points are written, the rest repeat the last point.
+ * bytes: (B,stride) uint8; nbytes: (B) int32; out: (B,S_out,3) f32; count: (B) int32 decoded points. */
+PCCX_API int pccx_octree_decode(const uint8_t *bytes, int stride, const int32_t *nbytes, int B,
+                                int mode, int S_out, float *out, int32_t *count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCCX_H */

@@ -1,0 +1,53 @@
+// Shared host/device helpers for libpccx (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pccx.h"
+
+#define PCCX_WAVE 64
+
+void pccx_set_error(const char *fmt, ...);
+
+#define PCCX_CHECK_ARG(cond, ...)                    \
+    do {                                             \
+        if (!(cond)) {                               \
+            pccx_set_error(__VA_ARGS__);             \
+            return PCCX_ERR_ARG;                     \
+        }                                            \
+    } while (0)
+
+#define PCCX_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            pccx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PCCX_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define PCCX_CHECK_LAUNCH() PCCX_CHECK_HIP(hipGetLastError())
+
+#ifdef __HIPCC__
+// Squared distance exactly as the oracle / torch evaluate it: three products, two adds,
+// no FMA contraction (the library is built with -ffp-contract=off; the intrinsics make the
+// intent explicit and survive flag changes).
+__device__ __forceinline__ float pccx_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    float d = __fmul_rn(dx, dx);
+    d = __fadd_rn(d, __fmul_rn(dy, dy));
+    d = __fadd_rn(d, __fmul_rn(dz, dz));
+    return d;
+}
+
+__device__ __forceinline__ int pccx_lane() { return threadIdx.x & 63; }
+
+// Inclusive-of-lower-lanes population count of a wave ballot.
+__device__ __forceinline__ int pccx_ballot_rank(unsigned long long mask)
+{
+    // number of set bits strictly below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+#endif

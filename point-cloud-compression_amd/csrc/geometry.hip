@@ -1,0 +1,314 @@
+// geometry.hip -- normalize / denormalize / gather / farthest-point sampling for gfx950.
+//
+// All four are latency- or HBM-bound integer/float32 selection work; nothing here is
+// GEMM-shaped.  One workgroup owns one cloud: a 8192x3 fp32 cloud is 96 KiB, so it lives in
+// LDS (160 KiB/CU) and in registers for the whole of FPS; throughput comes from running one
+// cloud per CU across the 256 CUs, not from splitting a cloud.
+#include <math.h>
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void pccx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *pccx_last_error(void) { return g_err; }
+extern "C" int pccx_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------------
+// normalize (pn_kit.py:47-60) / denormalize (pn_kit.py:62-66)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void normalize_kernel(const float *__restrict__ pc, int N, float one_minus_margin,
+                                                         float *__restrict__ out, float *__restrict__ center,
+                                                         float *__restrict__ longest)
+{
+    __shared__ float red[6][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *p = pc + (size_t)b * N * 3;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = p[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = wave_min(mn[a]), hi = wave_max(mx[a]);
+        if (lane == 0) { red[a][w] = lo; red[3 + a][w] = hi; }
+    }
+    __syncthreads();
+    float c[3], lg = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = red[a][0], hi = red[3 + a][0];
+        for (int k = 1; k < 16; ++k) { lo = fminf(lo, red[a][k]); hi = fmaxf(hi, red[3 + a][k]); }
+        c[a] = __fdiv_rn(__fadd_rn(hi, lo), 2.0f);   // (max+min)/2          (:53)
+        lg = fmaxf(lg, __fsub_rn(hi, lo));           // max(range)          (:54)
+    }
+    if (tid < 3) center[3 * b + tid] = c[tid];
+    if (tid == 0) longest[b] = lg;
+    float *o = out + (size_t)b * N * 3;
+    for (int i = tid; i < 3 * N; i += 1024) {
+        const int a = i % 3;
+        const float ca = a == 0 ? c[0] : (a == 1 ? c[1] : c[2]);
+        float v = __fsub_rn(p[i], ca);                             // pc - center      (:56)
+        v = __fdiv_rn(__fmul_rn(v, one_minus_margin), lg);         // *(1-m)/longest   (:57)
+        o[i] = __fadd_rn(v, 0.5f);                                 // + 0.5            (:58)
+    }
+}
+
+__global__ void denormalize_kernel(const float *__restrict__ pc, int N, float one_minus_margin,
+                                   const float *__restrict__ center, const float *__restrict__ longest,
+                                   float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const float lg = longest[b];
+    const float *p = pc + (size_t)b * N * 3;
+    float *o = out + (size_t)b * N * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * N; i += gridDim.x * blockDim.x) {
+        float v = __fsub_rn(p[i], 0.5f);
+        v = __fdiv_rn(__fmul_rn(v, lg), one_minus_margin);
+        o[i] = __fadd_rn(v, center[3 * b + i % 3]);
+    }
+}
+
+extern "C" int pccx_normalize(const float *pc, int B, int N, double margin, float *out, float *center, float *longest,
+                              void *stream)
+{
+    PCCX_CHECK_ARG(pc && out && center && longest, "pccx_normalize: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && N >= 1, "pccx_normalize: bad shape B=%d N=%d", B, N);
+    if (B == 0) return PCCX_OK;
+    hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, pc, N, (float)(1.0 - margin), out,
+                       center, longest);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_denormalize(const float *pc, int B, int N, double margin, const float *center, const float *longest,
+                                float *out, void *stream)
+{
+    PCCX_CHECK_ARG(pc && out && center && longest, "pccx_denormalize: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && N >= 1, "pccx_denormalize: bad shape B=%d N=%d", B, N);
+    if (B == 0) return PCCX_OK;
+    int gx = (3 * N + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(denormalize_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, pc, N, (float)(1.0 - margin),
+                       center, longest, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather (pn_kit.index_points, pn_kit.py:332-360; pytorch3d knn_gather)
+// ------------------------------------------------------------------------------------------
+__global__ void gather_kernel(const float *__restrict__ points, int N, int C, const int64_t *__restrict__ idx, int M,
+                              float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const size_t total = (size_t)M * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int m = (int)(e / C), c = (int)(e % C);
+        int64_t i = idx[(size_t)b * M + m];
+        if (i < 0) i = 0;            // clamp(min=0) of pointnet_sa_module.py:27
+        if (i >= N) i = N - 1;       // never fault on a bad index
+        out[(size_t)b * total + e] = points[((size_t)b * N + (size_t)i) * C + c];
+    }
+}
+
+extern "C" int pccx_gather(const float *points, int B, int N, int C, const int64_t *idx, int M, float *out, void *stream)
+{
+    PCCX_CHECK_ARG(points && idx && out, "pccx_gather: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && N >= 1 && C >= 1 && M >= 0, "pccx_gather: bad shape");
+    if (B == 0 || M == 0) return PCCX_OK;
+    size_t total = (size_t)M * C;
+    int gx = (int)((total + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(gather_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, points, N, C, idx, M, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// farthest point sampling (pn_kit.py:309-330)
+//
+// One 1024-thread workgroup per cloud.  Thread t owns points t, t+1024, ...: coordinates and the
+// running min-distance stay in registers for all npoint rounds; a copy of the cloud sits in LDS
+// so the next centroid is one LDS read.  A round is: PPT distance evaluations per thread ->
+// thread-local argmax (lowest index on ties) -> wave64 butterfly max-reduce on (value,index) ->
+// 16 wave partials through LDS (double-buffered, so ONE barrier per round) -> every wave reduces
+// the 16 partials redundantly.  Selection is bit-identical to the reference: distance is
+// (dx*dx+dy*dy)+dz*dz in fp32, update on strict '<', argmax returns the first maximum.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
+{
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
+                                                   const int32_t *__restrict__ start, int64_t *__restrict__ out,
+                                                   int use_lds)
+{
+    extern __shared__ float smem[];
+    float *part_v = smem;                 // [2][16]
+    int *part_i = (int *)(smem + 32);     // [2][16]
+    float *sx = smem + 64;                // [3N] when use_lds
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int i = tid + j * 1024;
+        if (i < N) {
+            px[j] = p[3 * i]; py[j] = p[3 * i + 1]; pz[j] = p[3 * i + 2];
+            md[j] = 1e10f;                 // distance = ones * 1e10 (:320)
+        } else {
+            px[j] = py[j] = pz[j] = 0.f;
+            md[j] = -INFINITY;             // never selected
+        }
+    }
+    if (use_lds)
+        for (int i = tid; i < 3 * N; i += 1024) sx[i] = p[i];
+    __syncthreads();
+
+    int far = start ? start[b] : 0;
+    if (far < 0 || far >= N) far = 0;
+    int par = 0;
+    for (int s = 0; s < npoint; ++s) {
+        if (tid == 0) out[(size_t)b * npoint + s] = far;             // centroids[:, i] = farthest (:324)
+        const float *cp = use_lds ? sx + 3 * far : p + 3 * far;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            float d = pccx_sqdist(px[j], py[j], pz[j], cx, cy, cz);   // (:326)
+            if (d < md[j]) md[j] = d;                                 // (:327-328)
+            if (md[j] > best) { best = md[j]; bi = tid + j * 1024; }  // ascending index, strict '>'
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            float ov = __shfl_xor(best, o);
+            int oi = __shfl_xor(bi, o);
+            argmax_merge(best, bi, ov, oi);
+        }
+        if (lane == 0) { part_v[par * 16 + w] = best; part_i[par * 16 + w] = bi; }
+        __syncthreads();
+        float v = lane < 16 ? part_v[par * 16 + lane] : -INFINITY;
+        int vi = lane < 16 ? part_i[par * 16 + lane] : 0x7fffffff;
+#pragma unroll
+        for (int o = 8; o; o >>= 1) {
+            float ov = __shfl_xor(v, o);
+            int oi = __shfl_xor(vi, o);
+            argmax_merge(v, vi, ov, oi);
+        }
+        far = __shfl(vi, 0);                                          // torch.max(distance,-1)[1] (:329)
+        par ^= 1;
+    }
+}
+
+// N > 16384: running min-distance lives in a global workspace (L2-resident), same selection rule.
+__global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int N, int npoint,
+                                                       const int32_t *__restrict__ start, int64_t *__restrict__ out,
+                                                       float *__restrict__ work)
+{
+    __shared__ float part_v[2][16];
+    __shared__ int part_i[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+    float *md = work + (size_t)b * N;
+    for (int i = tid; i < N; i += 1024) md[i] = 1e10f;
+    int far = start ? start[b] : 0;
+    if (far < 0 || far >= N) far = 0;
+    int par = 0;
+    for (int s = 0; s < npoint; ++s) {
+        if (tid == 0) out[(size_t)b * npoint + s] = far;
+        const float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < N; i += 1024) {
+            float d = pccx_sqdist(p[3 * i], p[3 * i + 1], p[3 * i + 2], cx, cy, cz);
+            float m = md[i];
+            if (d < m) { m = d; md[i] = d; }
+            if (m > best) { best = m; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            float ov = __shfl_xor(best, o);
+            int oi = __shfl_xor(bi, o);
+            argmax_merge(best, bi, ov, oi);
+        }
+        if (lane == 0) { part_v[par][w] = best; part_i[par][w] = bi; }
+        __syncthreads();
+        float v = lane < 16 ? part_v[par][lane] : -INFINITY;
+        int vi = lane < 16 ? part_i[par][lane] : 0x7fffffff;
+#pragma unroll
+        for (int o = 8; o; o >>= 1) {
+            float ov = __shfl_xor(v, o);
+            int oi = __shfl_xor(vi, o);
+            argmax_merge(v, vi, ov, oi);
+        }
+        far = __shfl(vi, 0);
+        par ^= 1;
+    }
+}
+
+template <int PPT>
+static int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int64_t *out, hipStream_t st)
+{
+    const int use_lds = (size_t)N * 12 + 256 <= 150 * 1024;
+    const size_t shmem = 256 + (use_lds ? (size_t)N * 12 : 0);
+    static bool attr_set = false;   // per template instance
+    if (!attr_set) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<PPT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fps_kernel<PPT>, dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out, use_lds);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_t *start_idx, int64_t *idx_out,
+                        float *workspace, void *stream)
+{
+    PCCX_CHECK_ARG(xyz && idx_out, "pccx_fps: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && N >= 1 && npoint >= 0, "pccx_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
+    if (B == 0 || npoint == 0) return PCCX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 1024) return launch_fps<1>(xyz, B, N, npoint, start_idx, idx_out, st);
+    if (N <= 2048) return launch_fps<2>(xyz, B, N, npoint, start_idx, idx_out, st);
+    if (N <= 4096) return launch_fps<4>(xyz, B, N, npoint, start_idx, idx_out, st);
+    if (N <= 8192) return launch_fps<8>(xyz, B, N, npoint, start_idx, idx_out, st);
+    if (N <= 16384) return launch_fps<16>(xyz, B, N, npoint, start_idx, idx_out, st);
+    PCCX_CHECK_ARG(workspace, "pccx_fps: N=%d > 16384 needs a workspace of B*N floats", N);
+    hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, npoint, start_idx, idx_out, workspace);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

@@ -1,0 +1,281 @@
+// knn.hip -- neighbour search kernels for gfx950: exact K-nearest (radix select in LDS), ball query
+// (ordered wave compaction) and one-directional nearest-neighbour distances (LDS-tiled all-pairs
+// min-reduce, the building block of Chamfer distance and D1-PSNR).
+//
+// These are HBM/LDS-bound float32 + integer selection kernels, not GEMMs.  Every distance is the
+// fp32 expression ((dx*dx)+dy*dy)+dz*dz with no FMA contraction, so selections are bit-identical
+// to the oracle (oracle/pcc_oracle.c: orc_knn / orc_ball_query / orc_nn_dist).
+#include <math.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// exact kNN: one 256-thread workgroup per query.
+//   1. N squared distances -> LDS (as uint keys; d >= 0 so uint order == float order)
+//   2. radix select (8 bits per pass, MSB first) of the K-th smallest composite key
+//      (distance bits, index): 4 passes over the distance, plus 2 over the index only when the
+//      K-th distance is tied beyond what K can take -- ties resolve to the LOWER index.
+//   3. unordered compaction of the K selected (key,index) pairs, bitonic sort in LDS
+//   4. write dists / idx / gathered (optionally centred + scaled) neighbours
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_scan_find(int h, int remaining, int *s_wsum, int *s_found, int tid)
+{
+    // inclusive scan of h over 256 threads; the thread whose bin crosses `remaining` publishes
+    // {bin, remaining - exclusive, h}.
+    const int lane = tid & 63, w = tid >> 6;
+    int incl = h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; ++k) base += s_wsum[k];
+    incl += base;
+    const int excl = incl - h;
+    if (excl < remaining && remaining <= incl) {
+        s_found[0] = tid;
+        s_found[1] = remaining - excl;
+        s_found[2] = h;
+    }
+    __syncthreads();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, int M, const float *__restrict__ ref,
+                                                  int N, int K, int Kp, float *__restrict__ dists,
+                                                  int64_t *__restrict__ idx, float *__restrict__ nn, float patch_scale)
+{
+    extern __shared__ unsigned char smem_raw[];
+    unsigned long long *sel = (unsigned long long *)smem_raw;   // [Kp]
+    unsigned *keys = (unsigned *)(sel + Kp);                    // [N]
+    int *hist = (int *)(keys + N);                              // [256]
+    int *s_wsum = hist + 256;                                   // [4]
+    int *s_found = s_wsum + 4;                                  // [3]
+    int *s_cnt = s_found + 3;                                   // [1]
+
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const float *rp = ref + (size_t)b * N * 3;
+    const float qx = q[((size_t)b * M + m) * 3], qy = q[((size_t)b * M + m) * 3 + 1], qz = q[((size_t)b * M + m) * 3 + 2];
+
+    for (int i = tid; i < N; i += 256)
+        keys[i] = __float_as_uint(pccx_sqdist(qx, qy, qz, rp[3 * i], rp[3 * i + 1], rp[3 * i + 2]));
+    if (tid == 0) *s_cnt = 0;
+
+    // ---- radix select over the distance bits
+    unsigned prefix = 0;
+    int remaining = K, ties = 0;
+    for (int p = 3; p >= 0; --p) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int sh = 8 * p;
+        for (int i = tid; i < N; i += 256) {
+            unsigned k = keys[i];
+            bool match = (p == 3) || ((k >> (sh + 8)) == (prefix >> (sh + 8)));
+            if (match) atomicAdd(&hist[(k >> sh) & 255u], 1);
+        }
+        __syncthreads();
+        block_scan_find(hist[tid], remaining, s_wsum, s_found, tid);
+        prefix |= (unsigned)s_found[0] << sh;
+        remaining = s_found[1];
+        ties = s_found[2];
+        __syncthreads();
+    }
+    // prefix == bits of the K-th smallest distance; `remaining` of the `ties` equal ones are taken.
+    int idx_thresh = 0x7fffffff;
+    if (ties != remaining) {
+        unsigned ipre = 0;
+        for (int p = 1; p >= 0; --p) {
+            hist[tid] = 0;
+            __syncthreads();
+            const int sh = 8 * p;
+            for (int i = tid; i < N; i += 256) {
+                bool match = keys[i] == prefix && (p == 1 || ((unsigned)i >> 8) == (ipre >> 8));
+                if (match) atomicAdd(&hist[((unsigned)i >> sh) & 255u], 1);
+            }
+            __syncthreads();
+            block_scan_find(hist[tid], remaining, s_wsum, s_found, tid);
+            ipre |= (unsigned)s_found[0] << sh;
+            remaining = s_found[1];
+            __syncthreads();
+        }
+        idx_thresh = (int)ipre;    // N <= 65536: two index bytes suffice
+    }
+
+    // ---- compaction (order irrelevant: sorted next)
+    for (int i = tid; i < N; i += 256) {
+        unsigned k = keys[i];
+        if (k < prefix || (k == prefix && i <= idx_thresh)) {
+            int pos = atomicAdd(s_cnt, 1);
+            if (pos < Kp) sel[pos] = ((unsigned long long)k << 32) | (unsigned)i;
+        }
+    }
+    for (int i = K + tid; i < Kp; i += 256) sel[i] = ~0ull;
+    __syncthreads();
+
+    // ---- bitonic sort of sel[0..Kp)
+    for (int size = 2; size <= Kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (Kp >> 1); t += 256) {
+                int lo = 2 * t - (t & (stride - 1));
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                unsigned long long a = sel[lo], c = sel[hi];
+                if ((a > c) == up) { sel[lo] = c; sel[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- outputs
+    const size_t ob = ((size_t)b * M + m) * K;
+    for (int k = tid; k < K; k += 256) {
+        unsigned long long e = sel[k];
+        int i = (int)(e & 0xffffffffu);
+        dists[ob + k] = __uint_as_float((unsigned)(e >> 32));
+        idx[ob + k] = i;
+        if (nn) {
+            float x = rp[3 * i], y = rp[3 * i + 1], z = rp[3 * i + 2];
+            if (patch_scale != 0.f) {
+                // grouped_xyz -= centre (compress.py:72); x_patches * (N/N0)^(1/3) (compress.py:108)
+                x = __fmul_rn(__fsub_rn(x, qx), patch_scale);
+                y = __fmul_rn(__fsub_rn(y, qy), patch_scale);
+                z = __fmul_rn(__fsub_rn(z, qz), patch_scale);
+            }
+            nn[(ob + k) * 3] = x; nn[(ob + k) * 3 + 1] = y; nn[(ob + k) * 3 + 2] = z;
+        }
+    }
+}
+
+extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, int K, float *dists, int64_t *idx,
+                        float *nn, float patch_scale, void *stream)
+{
+    PCCX_CHECK_ARG(q && ref && dists && idx, "pccx_knn: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1, "pccx_knn: bad shape B=%d M=%d N=%d", B, M, N);
+    PCCX_CHECK_ARG(K >= 1 && K <= N && K <= 1024, "pccx_knn: need 1 <= K <= min(N,1024), got K=%d N=%d", K, N);
+    PCCX_CHECK_ARG(N <= 32768, "pccx_knn: N=%d > 32768 unsupported", N);
+    PCCX_CHECK_ARG(B <= 65535, "pccx_knn: B=%d > 65535 unsupported", B);
+    if (B == 0 || M == 0) return PCCX_OK;
+    int Kp = 2;
+    while (Kp < K) Kp <<= 1;
+    size_t shmem = (size_t)Kp * 8 + (size_t)N * 4 + (256 + 4 + 3 + 1) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(knn_kernel, dim3(M, B), dim3(256), shmem, (hipStream_t)stream, q, M, ref, N, K, Kp, dists, idx, nn,
+                       patch_scale);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// ball query: one wave per query, ordered compaction of the first K in-radius indices.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ q, int M, const float *__restrict__ ref,
+                                                         int N, int K, float r2, float *__restrict__ dists,
+                                                         int64_t *__restrict__ idx)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + w, b = blockIdx.y;
+    if (m >= M) return;                         // whole wave exits together
+    const float *rp = ref + (size_t)b * N * 3;
+    const size_t qo = ((size_t)b * M + m) * 3;
+    const float qx = q[qo], qy = q[qo + 1], qz = q[qo + 2];
+    const size_t ob = ((size_t)b * M + m) * K;
+    int count = 0;
+    for (int base = 0; base < N && count < K; base += 64) {
+        int i = base + lane;
+        float d = 0.f;
+        bool in = false;
+        if (i < N) {
+            d = pccx_sqdist(qx, qy, qz, rp[3 * i], rp[3 * i + 1], rp[3 * i + 2]);
+            in = d < r2;
+        }
+        unsigned long long mask = __ballot(in);
+        int pos = count + pccx_ballot_rank(mask);
+        if (in && pos < K) { dists[ob + pos] = d; idx[ob + pos] = i; }
+        count += __popcll(mask);
+    }
+    if (count > K) count = K;
+    for (int k = count + lane; k < K; k += 64) { dists[ob + k] = 0.f; idx[ob + k] = -1; }
+}
+
+extern "C" int pccx_ball_query(const float *q, int B, int M, const float *ref, int N, int K, float radius, float *dists,
+                               int64_t *idx, void *stream)
+{
+    PCCX_CHECK_ARG(q && ref && dists && idx, "pccx_ball_query: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1 && K >= 1, "pccx_ball_query: bad shape");
+    PCCX_CHECK_ARG(B <= 65535, "pccx_ball_query: B=%d > 65535 unsupported", B);
+    if (B == 0 || M == 0) return PCCX_OK;
+    hipLaunchKernelGGL(ball_query_kernel, dim3((M + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q, M, ref, N, K,
+                       radius * radius, dists, idx);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// nn_dist: LDS-tiled all-pairs min-reduce.  A 256-thread workgroup owns 1024 query points
+// (4 per thread, registers) and streams the other cloud through LDS in tiles of 1024 points
+// (12 KiB); every lane reads the same LDS address (broadcast, conflict-free), so one 12-byte LDS
+// read feeds 4 distance evaluations.  Algorithmic HBM bytes: 12(P+Q) + 8P per cloud; the P*Q pair
+// work is VALU-bound (8 flops/pair).
+// ------------------------------------------------------------------------------------------
+#define NND_TILE 1024
+#define NND_XPT 4
+__global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, int Q,
+                                                      float *__restrict__ d2, int32_t *__restrict__ nn)
+{
+    __shared__ float ty[NND_TILE * 3];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float *xp = X + (size_t)b * P * 3;
+    const float *yp = Y + (size_t)b * Q * 3;
+    float x[NND_XPT][3], best[NND_XPT];
+    int bi[NND_XPT];
+#pragma unroll
+    for (int j = 0; j < NND_XPT; ++j) {
+        int i = blockIdx.x * (256 * NND_XPT) + j * 256 + tid;
+        int ii = i < P ? i : P - 1;
+        x[j][0] = xp[3 * ii]; x[j][1] = xp[3 * ii + 1]; x[j][2] = xp[3 * ii + 2];
+        best[j] = INFINITY; bi[j] = -1;
+    }
+    for (int base = 0; base < Q; base += NND_TILE) {
+        int cnt = Q - base < NND_TILE ? Q - base : NND_TILE;
+        __syncthreads();
+        for (int t = tid; t < cnt * 3; t += 256) ty[t] = yp[(size_t)base * 3 + t];
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            float yx = ty[3 * t], yy = ty[3 * t + 1], yz = ty[3 * t + 2];
+#pragma unroll
+            for (int j = 0; j < NND_XPT; ++j) {
+                float d = pccx_sqdist(x[j][0], x[j][1], x[j][2], yx, yy, yz);
+                if (d < best[j]) { best[j] = d; bi[j] = base + t; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NND_XPT; ++j) {
+        int i = blockIdx.x * (256 * NND_XPT) + j * 256 + tid;
+        if (i < P) {
+            d2[(size_t)b * P + i] = best[j];
+            if (nn) nn[(size_t)b * P + i] = bi[j];
+        }
+    }
+}
+
+extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, float *d2, int32_t *nn, void *stream)
+{
+    PCCX_CHECK_ARG(X && Y && d2, "pccx_nn_dist: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1, "pccx_nn_dist: bad shape");
+    PCCX_CHECK_ARG(B <= 65535, "pccx_nn_dist: B=%d > 65535 unsupported", B);
+    if (B == 0) return PCCX_OK;
+    int gx = (P + 256 * NND_XPT - 1) / (256 * NND_XPT);
+    hipLaunchKernelGGL(nn_dist_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

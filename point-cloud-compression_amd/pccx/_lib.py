@@ -1,0 +1,63 @@
+"""ctypes loader for libpccx.so (the C ABI declared in include/pccx.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpccx.so")
+
+c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+_P = C.c_void_p
+
+# name -> argtypes; every function returns int (pccx_status) unless listed in _RESTYPES
+_SIGNATURES = {
+    "pccx_version": [],
+    "pccx_normalize": [_P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P],
+    "pccx_denormalize": [_P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P],
+    "pccx_fps": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],
+    "pccx_gather": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
+    "pccx_knn": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P],
+    "pccx_ball_query": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P],
+    "pccx_nn_dist": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],
+    "pccx_octree_bits_capacity": [C.c_int],
+    "pccx_octree_encode": [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P],
+    "pccx_octree_decode": [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P],
+}
+
+_lib = None
+
+
+class PccxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpccx.so; raises PccxError when it has not been built (python -m pccx.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PccxError(
+                f"{LIB_PATH} not found: build the HIP library first (python -m pccx.build). "
+                "pccx has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.pccx_last_error.restype = C.c_char_p
+        lib.pccx_last_error.argtypes = []
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the ABI and the header disagree
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise PccxError(f"{name} failed ({rc}): {lib.pccx_last_error().decode()}")
+
+
+def declared_symbols():
+    return ["pccx_last_error"] + list(_SIGNATURES)

@@ -1,0 +1,173 @@
+"""Tensor-level operators over libpccx.so, named after the reference callables they replace.
+
+PyTorch is used for device memory and streams only; every computation is a HIP kernel behind
+the C ABI (include/pccx.h).  Inputs must live on a ROCm device: there is no CPU path.
+"""
+import collections
+
+import torch
+
+from . import _lib
+
+KNN = collections.namedtuple("KNN", ["dists", "idx", "knn"])      # pytorch3d's _KNN result shape
+OCTREE_BPP_DICT = {1024: 0.07, 512: 0.125, 256: 0.25, 128: 0.5, 64: 1.0}   # pn_kit.py:17-23
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.PccxError(f"{name}: expected a tensor on the GPU (pccx has no CPU fallback)")
+    return t
+
+
+def _f32c(t, name):
+    _dev(t, name)
+    if t.dtype != torch.float32:
+        raise _lib.PccxError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def normalize(pc, margin=0.01):
+    """pn_kit.normalize (pn_kit.py:47-60), batched over B: returns (pc, center (B,3), longest (B))."""
+    pc = _f32c(pc, "normalize")
+    B, N, _ = pc.shape
+    out = torch.empty_like(pc)
+    center = torch.empty(B, 3, device=pc.device, dtype=torch.float32)
+    longest = torch.empty(B, device=pc.device, dtype=torch.float32)
+    _lib.call("pccx_normalize", pc.data_ptr(), B, N, float(margin), out.data_ptr(), center.data_ptr(),
+              longest.data_ptr(), _stream())
+    return out, center, longest
+
+
+def denormalize(pc, center, longest, margin=0.01):
+    """pn_kit.denormalize (pn_kit.py:62-66), batched."""
+    pc = _f32c(pc, "denormalize")
+    B, N, _ = pc.shape
+    center = _f32c(center.reshape(B, 3), "denormalize.center")
+    longest = _f32c(longest.reshape(B), "denormalize.longest")
+    out = torch.empty_like(pc)
+    _lib.call("pccx_denormalize", pc.data_ptr(), B, N, float(margin), center.data_ptr(), longest.data_ptr(),
+              out.data_ptr(), _stream())
+    return out
+
+
+def farthest_point_sample_batch(xyz, npoint, start_idx=None):
+    """pn_kit.farthest_point_sample_batch (pn_kit.py:309-330).  ``start_idx`` (B,) replaces the
+    reference's torch.randint draw (:321); None draws it the same way the reference does."""
+    xyz = _f32c(xyz, "farthest_point_sample_batch")
+    B, N, _ = xyz.shape
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+    start = torch.as_tensor(start_idx).to(device=xyz.device, dtype=torch.int32).contiguous()
+    out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
+    work = torch.empty(B * N, device=xyz.device, dtype=torch.float32) if N > 16384 else None
+    _lib.call("pccx_fps", xyz.data_ptr(), B, N, int(npoint), start.data_ptr(), out.data_ptr(),
+              work.data_ptr() if work is not None else None, _stream())
+    return out
+
+
+def sample_farthest_points(xyz, K):
+    """pytorch3d.ops.sample_farthest_points as pointnet_sa_module.py:12 uses it: start index 0,
+    returns (points, idx)."""
+    idx = farthest_point_sample_batch(xyz, K, start_idx=torch.zeros(xyz.shape[0], dtype=torch.int32))
+    return index_points(xyz, idx), idx
+
+
+def index_points(points, idx):
+    """pn_kit.index_points (pn_kit.py:332-360): idx (B,S) or (B,S,K)."""
+    points = _f32c(points, "index_points")
+    B, N, Cc = points.shape
+    idx = _dev(idx, "index_points.idx").to(torch.int64).contiguous()
+    M = idx[0].numel()
+    out = torch.empty(B, M, Cc, device=points.device, dtype=torch.float32)
+    _lib.call("pccx_gather", points.data_ptr(), B, N, Cc, idx.data_ptr(), M, out.data_ptr(), _stream())
+    return out.view(*idx.shape, Cc)
+
+
+def knn_gather(x, idx):
+    """pytorch3d.ops.knn_gather(x (B,N,C), idx (B,M,K)) -> (B,M,K,C)."""
+    return index_points(x, idx)
+
+
+def knn_points(p1, p2, K, return_nn=True, patch_scale=0.0):
+    """pytorch3d.ops.knn_points (compress.py:71, pn_kit.py:190).  With patch_scale != 0 the third
+    field holds (nn - p1) * patch_scale, i.e. compress.py:72 and :108 fused."""
+    p1, p2 = _f32c(p1, "knn_points.p1"), _f32c(p2, "knn_points.p2")
+    B, M, _ = p1.shape
+    N = p2.shape[1]
+    dists = torch.empty(B, M, K, device=p1.device, dtype=torch.float32)
+    idx = torch.empty(B, M, K, device=p1.device, dtype=torch.int64)
+    nn = torch.empty(B, M, K, 3, device=p1.device, dtype=torch.float32) if return_nn else None
+    _lib.call("pccx_knn", p1.data_ptr(), B, M, p2.data_ptr(), N, int(K), dists.data_ptr(), idx.data_ptr(),
+              nn.data_ptr() if nn is not None else None, float(patch_scale), _stream())
+    return KNN(dists, idx, nn)
+
+
+def ball_query(p1, p2, K, radius):
+    """pytorch3d.ops.ball_query (pointnet_sa_module.py:18): idx padded with -1."""
+    p1, p2 = _f32c(p1, "ball_query.p1"), _f32c(p2, "ball_query.p2")
+    B, M, _ = p1.shape
+    dists = torch.empty(B, M, K, device=p1.device, dtype=torch.float32)
+    idx = torch.empty(B, M, K, device=p1.device, dtype=torch.int64)
+    _lib.call("pccx_ball_query", p1.data_ptr(), B, M, p2.data_ptr(), p2.shape[1], int(K), float(radius),
+              dists.data_ptr(), idx.data_ptr(), _stream())
+    return KNN(dists, idx, None)
+
+
+def nn_dist(x, y, return_idx=False):
+    """min_j |x_i - y_j|^2 for every i: (B,P,3),(B,Q,3) -> (B,P) [, idx (B,P) int32]."""
+    x, y = _f32c(x, "nn_dist.x"), _f32c(y, "nn_dist.y")
+    B, P, _ = x.shape
+    d2 = torch.empty(B, P, device=x.device, dtype=torch.float32)
+    nn = torch.empty(B, P, device=x.device, dtype=torch.int32) if return_idx else None
+    _lib.call("pccx_nn_dist", x.data_ptr(), B, P, y.data_ptr(), y.shape[1], d2.data_ptr(),
+              nn.data_ptr() if nn is not None else None, _stream())
+    return (d2, nn) if return_idx else d2
+
+
+def chamfer_distance(x, y, batch_reduction="mean"):
+    """pytorch3d.loss.chamfer_distance defaults (AE.py:67, eval.py:204): squared distances,
+    point mean, both directions summed; returns (value, None)."""
+    dxy, dyx = nn_dist(x, y), nn_dist(y, x)
+    per = dxy.double().mean(dim=1) + dyx.double().mean(dim=1)
+    if batch_reduction == "mean":
+        per = per.mean()
+    elif batch_reduction == "sum":
+        per = per.sum()
+    return per.float(), None
+
+
+def octree_encode(centres, N, min_bpp):
+    """pn_kit.encode_sampled_np (pn_kit.py:380-401) + binary_array_to_byte_array (:463-467),
+    batched on the GPU.  centres (B,S,3).  Returns dict of device tensors:
+    bits (B,cap) u8 one byte per bit, nbits (B), depth (B), bytes (B,stride) u8, nbytes (B)."""
+    centres = _f32c(centres, "octree_encode")
+    B, S, _ = centres.shape
+    cap = _lib.load().pccx_octree_bits_capacity(S)
+    dev = centres.device
+    r = dict(bits=torch.empty(B, cap, device=dev, dtype=torch.uint8),
+             nbits=torch.empty(B, device=dev, dtype=torch.int32),
+             depth=torch.empty(B, device=dev, dtype=torch.int32),
+             bytes=torch.empty(B, (cap + 7) // 8, device=dev, dtype=torch.uint8),
+             nbytes=torch.empty(B, device=dev, dtype=torch.int32))
+    _lib.call("pccx_octree_encode", centres.data_ptr(), B, S, int(N), float(min_bpp), r["bits"].data_ptr(),
+              r["nbits"].data_ptr(), r["depth"].data_ptr(), r["bytes"].data_ptr(), r["nbytes"].data_ptr(), _stream())
+    return r
+
+
+def octree_decode(bytes_, nbytes, mode="reference", S_out=64):
+    """pn_kit.decode_sampled_np (pn_kit.py:424-431) from packed streams.  mode 'reference' is
+    bug-compatible with octree_np.decode as written; 'full' is the level-by-level decode.
+    bytes_ (B,stride) u8, nbytes (B) i32 -> (points (B,S_out,3), count (B))."""
+    _dev(bytes_, "octree_decode")
+    bytes_ = bytes_.contiguous()
+    B, stride = bytes_.shape
+    nbytes = _dev(nbytes, "octree_decode.nbytes").to(torch.int32).contiguous()
+    out = torch.empty(B, S_out, 3, device=bytes_.device, dtype=torch.float32)
+    count = torch.empty(B, device=bytes_.device, dtype=torch.int32)
+    _lib.call("pccx_octree_decode", bytes_.data_ptr(), stride, nbytes.data_ptr(), B,
+              {"reference": 0, "full": 1}[mode], int(S_out), out.data_ptr(), count.data_ptr(), _stream())
+    return out, count

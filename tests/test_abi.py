@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pccx.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from pccx import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "pccx.h")).read()
+    return sorted(set(re.findall(r"PCCX_API\s+[\w\s\*]+?\b(pccx_\w+)\s*\(", txt)))
+
+
+def test_header_declares_symbols():
+    names = _declared()
+    assert "pccx_fps" in names and "pccx_octree_encode" in names and len(names) >= 10
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from pccx import build
+        build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"libpccx.so does not export {name}"
+
+
+def test_python_binding_covers_header():
+    assert sorted(_lib.declared_symbols()) == _declared()
+
+
+def test_ops_fail_loudly_without_gpu_tensor():
+    import torch
+    from pccx import ops
+    with pytest.raises(_lib.PccxError):
+        ops.normalize(torch.zeros(1, 8, 3))     # CPU tensor: no fallback
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert lib.pccx_version() >= 100
+    # argument validation happens on the host, before any HIP call
+    rc = lib.pccx_octree_encode(None, 1, 64, 8192, 0.25, None, None, None, None, None, None)
+    assert rc == -1 and b"null pointer" in lib.pccx_last_error()

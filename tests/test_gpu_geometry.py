@@ -1,0 +1,196 @@
+"""GPU parity: geometry / selection / integer kernels vs the oracle and the golden fixtures.
+
+Everything here goes through the C ABI (pccx.ops -> ctypes -> libpccx.so).  Bar: bit-exact for
+indices, bit streams, bytes and for the fp32 results of normalize/denormalize/kNN distances
+(same fp32 expression, no FMA contraction).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cport, ref_model
+from pccx import ops, synth as cloud_synth
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda()
+
+
+def test_normalize_denormalize_golden_and_oracle():
+    fp = np.load(os.path.join(G, "pnkit_float.npz"))
+    for i, (pc, S) in enumerate(synth.fps_cases()):
+        x = dev(pc)[None]
+        xn, c, l = ops.normalize(x)
+        assert np.array_equal(c[0].cpu().numpy(), fp["centers"][i])
+        assert float(l[0]) == fp["longest"][i]
+        assert np.array_equal(xn[0, ::257].cpu().numpy(), fp[f"norm_sample_{i}"])
+        on, oc_, ol = ref_model.normalize(torch.from_numpy(pc)[None])
+        assert np.array_equal(xn.cpu().numpy(), on.numpy())
+        back = ops.denormalize(xn, c, l)
+        assert np.array_equal(back[0, ::257].cpu().numpy(), fp[f"denorm_sample_{i}"])
+    # batched: several clouds in one launch
+    batch = cloud_synth.cad_batch(40, 5, 4096) * np.float32(3.0) - np.float32(1.0)
+    xn, c, l = ops.normalize(dev(batch))
+    for b in range(5):
+        on, oc_, ol = ref_model.normalize(torch.from_numpy(batch[b])[None])
+        assert np.array_equal(xn[b].cpu().numpy(), on[0].numpy())
+        assert np.array_equal(c[b].cpu().numpy(), oc_.numpy()) and float(l[b]) == float(ol)
+
+
+def test_fps_golden_indices():
+    fp = np.load(os.path.join(G, "pnkit_float.npz"))
+    for i, (pc, S) in enumerate(synth.fps_cases()):
+        idx = ops.farthest_point_sample_batch(dev(pc)[None], S, start_idx=[int(fp["starts"][i])])
+        assert np.array_equal(idx[0].cpu().numpy(), fp[f"fps_idx_{i}"]), f"case {i}"
+        g = ops.index_points(dev(pc)[None], idx)
+        assert np.array_equal(g[0].cpu().numpy(), fp[f"gather_{i}"])
+
+
+@pytest.mark.parametrize("N,S", [(1, 1), (7, 7), (64, 10), (1000, 33), (1024, 64), (1025, 5), (3000, 100),
+                                 (8192, 64), (10000, 17), (16384, 8), (20000, 9)])
+def test_fps_ragged_sizes_vs_oracle(N, S):
+    rng = np.random.default_rng(N * 31 + S)
+    B = 3
+    pcs = rng.random((B, N, 3)).astype(np.float32)
+    if N >= 64:
+        pcs[1, 5] = pcs[1, 50]                      # duplicate points: argmax ties -> first index
+        pcs[2] = np.round(pcs[2] * 8) / 8           # heavy ties on a lattice
+    starts = rng.integers(0, N, size=B)
+    got = ops.farthest_point_sample_batch(dev(pcs), S, start_idx=starts).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], cport.fps(pcs[b], S, int(starts[b]))), f"cloud {b}"
+
+
+@pytest.mark.parametrize("N,M,K", [(8192, 64, 256), (300, 5, 300), (256, 256, 16), (1000, 3, 1), (5000, 7, 1000),
+                                   (32768, 2, 64), (2, 2, 2)])
+def test_knn_vs_oracle(N, M, K):
+    rng = np.random.default_rng(N + M + K)
+    ref = rng.random((2, N, 3)).astype(np.float32)
+    ref[1] = np.round(ref[1] * 16) / 16             # lattice: massive distance ties -> index order
+    q = ref[:, rng.choice(N, size=M, replace=M > N)] if M <= N else rng.random((2, M, 3)).astype(np.float32)
+    q = np.ascontiguousarray(q)
+    r = ops.knn_points(dev(q), dev(ref), K)
+    for b in range(2):
+        d, i = cport.knn(q[b], ref[b], K)
+        assert np.array_equal(r.idx[b].cpu().numpy(), i)
+        assert np.array_equal(r.dists[b].cpu().numpy(), d)
+        assert np.array_equal(r.knn[b].cpu().numpy(), ref[b][i])
+
+
+def test_knn_patches_fused_centre_and_scale():
+    pc = cloud_synth.cad_cloud(3, 8192)
+    c = pc[:64] + np.float32(0.001)
+    scale = float((8192 / 1024) ** (1 / 3))
+    r = ops.knn_points(dev(c)[None], dev(pc)[None], 256, patch_scale=scale)
+    d, i = cport.knn(c, pc, 256)
+    want = (pc[i] - c[:, None, :]) * np.float32(scale)
+    assert np.array_equal(r.knn[0].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("N,M,K,r", [(512, 128, 32, 0.2), (2048, 100, 64, 0.4), (100, 7, 128, 0.8), (777, 3, 5, 0.05)])
+def test_ball_query_vs_oracle(N, M, K, r):
+    rng = np.random.default_rng(N + K)
+    ref = rng.random((2, N, 3)).astype(np.float32)
+    q = rng.random((2, M, 3)).astype(np.float32)
+    got = ops.ball_query(dev(q), dev(ref), K, r)
+    for b in range(2):
+        d, i = cport.ball_query(q[b], ref[b], K, r)
+        assert np.array_equal(got.idx[b].cpu().numpy(), i)
+        assert np.array_equal(got.dists[b].cpu().numpy(), d)
+
+
+@pytest.mark.parametrize("P,Q", [(8192, 8192), (1000, 3000), (1, 5), (5000, 1), (4097, 1025)])
+def test_nn_dist_and_chamfer_vs_oracle(P, Q):
+    rng = np.random.default_rng(P + Q)
+    x = rng.random((2, P, 3)).astype(np.float32)
+    y = rng.random((2, Q, 3)).astype(np.float32)
+    y[1] = np.round(y[1] * 4) / 4
+    d2, nn = ops.nn_dist(dev(x), dev(y), return_idx=True)
+    for b in range(2):
+        d, i = cport.nn_dist(x[b], y[b])
+        assert np.array_equal(d2[b].cpu().numpy(), d)
+        assert np.array_equal(nn[b].cpu().numpy(), i)
+    got, _ = ops.chamfer_distance(dev(x), dev(y))
+    want, _ = ref_model.chamfer_distance(torch.from_numpy(x), torch.from_numpy(y))
+    assert abs(float(got) - want) <= 1e-6 * abs(want)      # fp64 means of identical fp32 terms
+
+
+def _check_octree(pcs, N, min_bpp):
+    r = ops.octree_encode(dev(pcs), N, min_bpp)
+    nbits, depth = r["nbits"].cpu().numpy(), r["depth"].cpu().numpy()
+    bits, bytes_, nbytes = r["bits"].cpu().numpy(), r["bytes"].cpu().numpy(), r["nbytes"].cpu().numpy()
+    for b in range(pcs.shape[0]):
+        want, wd = cport.encode_sampled(pcs[b], 1, N, min_bpp)
+        assert nbits[b] == want.shape[0] and depth[b] == wd, f"cloud {b}: {nbits[b]} vs {want.shape[0]}, {depth[b]} vs {wd}"
+        assert np.array_equal(bits[b, :nbits[b]], want), f"cloud {b}"
+        assert bytes(bytes_[b, :nbytes[b]]) == bytes(cport.pack_bits(want))
+    return r
+
+
+def test_octree_depth_search_golden():
+    ds = np.load(os.path.join(G, "depth_search_pack.npz"))
+    bo, yo = ds["bits_off"], ds["bytes_off"]
+    for i, (pcs, N, K) in enumerate(synth.depth_search_cases()):
+        r = ops.octree_encode(dev(pcs), N, ops.OCTREE_BPP_DICT[K])
+        nb = int(r["nbits"][0])
+        assert nb == ds["total_bits"][i]
+        assert np.array_equal(r["bits"][0, :nb].cpu().numpy(), ds["bits"][bo[i]:bo[i + 1]]), f"case {i}"
+        ny = int(r["nbytes"][0])
+        assert r["bytes"][0, :ny].cpu().numpy().tobytes() == ds["bytes"][yo[i]:yo[i + 1]].tobytes()
+
+
+def test_octree_encode_batched_vs_oracle_incl_edge_cases():
+    rng = np.random.default_rng(8)
+    pcs = (0.005 + 0.99 * rng.random((40, 64, 3))).astype(np.float32)
+    pcs[1, 3] = pcs[1, 60]                                    # duplicate centre -> depth 17, code of depth 16
+    pcs[2, 1] = pcs[2, 0] + np.float32(2.0 ** -15)            # deep search
+    pcs[3, 0] = [1.0, 0.3, 0.2]; pcs[3, 63] = [0.0, 0.0, 0.0]  # boundary values
+    pcs[4, 0] = [-0.01, 0.5, 1.2]                             # outside the cube
+    pcs[5] = 1.5 + pcs[5]                                     # nothing inside: stream is the single bit 0
+    pcs[6] = (0.5 + 0.01 * rng.standard_normal((64, 3))).astype(np.float32)   # clustered
+    _check_octree(pcs, 8192, 0.25)
+    for S, N, K in [(32, 8192, 512), (128, 8192, 128), (256, 8192, 64), (7, 2048, 512), (1, 1024, 1024), (700, 8192, 64)]:
+        p = (0.005 + 0.99 * rng.random((6, S, 3))).astype(np.float32)
+        _check_octree(p, N, ops.OCTREE_BPP_DICT[K])
+
+
+def test_octree_decode_reference_mode_golden_and_round_trip():
+    oc = np.load(os.path.join(G, "octree.npz"))
+    cases = synth.octree_cases()
+    off = oc["bits_off"]
+    for i in range(len(cases)):
+        bits = oc["bits"][off[i]:off[i + 1]]
+        by = np.frombuffer(bytes(cport.pack_bits(bits)), dtype=np.uint8)
+        if bits.shape[0] < 8:
+            continue        # sub-byte streams unpack differently in the reference itself (tail quirk)
+        out, cnt = ops.octree_decode(dev(by)[None], dev(np.array([by.shape[0]], dtype=np.int32)), "reference")
+        assert np.array_equal(out[0].cpu().numpy(), oc["decoded_reference"][i]), f"case {i}"
+    # what decompress.py sees: bytes -> unpack -> decode, for every golden case incl. sub-byte ones
+    for i in range(len(cases)):
+        bits = oc["bits"][off[i]:off[i + 1]]
+        by = cport.pack_bits(bits)
+        want, _ = cport.octree_decode_reference(cport.unpack_bits(by).astype(np.uint8), 1)
+        arr = np.frombuffer(bytes(by), dtype=np.uint8)
+        out, _ = ops.octree_decode(dev(arr)[None], dev(np.array([arr.shape[0]], dtype=np.int32)), "reference")
+        assert np.array_equal(out[0].cpu().numpy(), want)
+
+
+def test_octree_full_mode_round_trip_on_device():
+    rng = np.random.default_rng(9)
+    for S in (64, 32, 128, 500):
+        pcs = (0.005 + 0.99 * rng.random((16, S, 3))).astype(np.float32)
+        r = ops.octree_encode(dev(pcs), 8192, 0.25 if S == 64 else 0.1)
+        out, cnt = ops.octree_decode(r["bytes"], r["nbytes"], "full", S_out=S)
+        depth = r["depth"].cpu().numpy()
+        for b in range(16):
+            want, d = cport.octree_decode_full(r["bits"][b, :int(r["nbits"][b])].cpu().numpy(), 1)
+            assert d == depth[b] and int(cnt[b]) == want.shape[0] == S
+            assert np.array_equal(out[b].cpu().numpy(), want)
+            cells = cport.get_decode_from_pc(pcs[b], 1, int(depth[b]))
+            assert np.array_equal(np.unique(out[b].cpu().numpy(), axis=0), cells)   # decode inverts encode
