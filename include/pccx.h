@@ -109,6 +109,72 @@ PCCX_API int pccx_octree_encode(const float *centres, int B, int S, int N, doubl
 PCCX_API int pccx_octree_decode(const uint8_t *bytes, int stride, const int32_t *nbytes, int B,
                                 int mode, int S_out, float *out, int32_t *count, void *stream);
 
+/* ---- neural transforms (fp32 on the matrix cores) --------------------------------------------- */
+
+/* Packed weight blobs.  pccx_pack_* run on the HOST, once per model load: every pointer they take
+ * is a HOST pointer to a dense row-major fp32 tensor with the shape of the reference's state_dict
+ * entry named in the comment; the caller uploads the resulting blob.
+ * Limits: bottleneck d <= 16, d*L <= 128; layer widths are those of AE.py. */
+PCCX_API size_t pccx_ae_encoder_blob_floats(void);
+/* AE.AE.sa / AE.AE.pn (AE.py:16-17): sa.conv0 (32,3) sa.conv1 (64,32) sa.conv2 (128,64)
+ * pn.mlp_Modules.{0,1,2,3}.0 (128,131) (256,128) (512,256) (d,512), each with its bias. */
+PCCX_API int pccx_pack_ae_encoder(const float *sa_w0, const float *sa_b0, const float *sa_w1,
+                                  const float *sa_b1, const float *sa_w2, const float *sa_b2,
+                                  const float *pn_w0, const float *pn_b0, const float *pn_w1,
+                                  const float *pn_b1, const float *pn_w2, const float *pn_b2,
+                                  const float *pn_w3, const float *pn_b3, int d, float *blob_host);
+PCCX_API size_t pccx_ae_decoder_blob_floats(int k);
+/* AE.AE.inv_pool / inv_mlp (AE.py:19-27): inv_pool.{0,2,4} (256,d) (1024,256) (k*128,1024);
+ * inv_mlp.mlp_Modules.{0,1,2,3}.0 (128,128+d) (64,128) (32,64) (3,32). */
+PCCX_API int pccx_pack_ae_decoder(const float *ip_w0, const float *ip_b0, const float *ip_w1,
+                                  const float *ip_b1, const float *ip_w2, const float *ip_b2,
+                                  const float *m_w0, const float *m_b0, const float *m_w1,
+                                  const float *m_b1, const float *m_w2, const float *m_b2,
+                                  const float *m_w3, const float *m_b3, int k, int d, float *blob_host);
+PCCX_API size_t pccx_prob_blob_floats(void);
+/* AE.ConditionalProbabilityModel (AE.py:96-105): model_pn.mlp_Modules.{0,1,2}.0 (64,3) (128,64)
+ * (256,128); model_mlp.{0,2,4} (512,259) (512,512) (d*L,512). */
+PCCX_API int pccx_pack_prob(const float *p_w0, const float *p_b0, const float *p_w1, const float *p_b1,
+                            const float *p_w2, const float *p_b2, const float *m_w0, const float *m_b0,
+                            const float *m_w1, const float *m_b1, const float *m_w2, const float *m_b2,
+                            int d, int L, float *blob_host);
+
+/* Analysis transform of AE.AE.forward (AE.py:37-45) = the two per-patch loops of
+ * compress.py:113-127: ae.sa (pn_kit.py:164-211), ae.pn (pn_kit.py:124-144), sigmoid spread, round.
+ * patches: (P,K,3) f32, already centred and scaled (compress.py:105-108); K % 16 == 0, K <= 1024.
+ * feat_ws: workspace of P*K*128 floats.  Outputs (P,d) f32: latent_raw (PointNet output),
+ * latent (after sigmoid spread), latent_q (rounded).  Spread is L - 0.2. */
+PCCX_API int pccx_ae_encode(const float *patches, int P, int K, const float *enc_blob, int d, int L,
+                            float *feat_ws, float *latent_raw, float *latent, float *latent_q,
+                            void *stream);
+
+PCCX_API size_t pccx_ae_decode_workspace_floats(int P);
+/* Synthesis transform (AE.py:48-53 = decompress.py:97-102) and, optionally, the reassembly of
+ * decompress.py:104-116.  latent_q: (P,d) f32; workspace: pccx_ae_decode_workspace_floats(P).
+ * patches_out (P,k,3) or NULL: raw decoder output (new_xyz.transpose(2,1)).
+ * pc_out (P*k,3) or NULL: ((patch / scale) + centres[patch] - 0.5) * longest[b] / (1-margin) +
+ * center[b] with b = patch / S; needs centres (P,3), nrm_center (B,3), nrm_longest (B). */
+PCCX_API int pccx_ae_decode(const float *latent_q, int P, int d, int k, const float *dec_blob,
+                            float *workspace, float *patches_out, float scale, const float *centres,
+                            const float *nrm_center, const float *nrm_longest, int S, double margin,
+                            float *pc_out, void *stream);
+
+/* AE.ConditionalProbabilityModel.forward (AE.py:107-123) + pn_kit.pmf_to_cdf (pn_kit.py:452-461)
+ * + torchac's float-CDF -> 16-bit conversion.  centres: (B,S,3), S % 16 == 0.  Any of the outputs
+ * may be NULL: pmf (B,S,d,L) f32; cdf (B,S,d,L+1) f32; cdf_int (B,S,d,L+1) int32 holding uint16. */
+PCCX_API int pccx_prob_forward(const float *centres, int B, int S, int d, int L, const float *prob_blob,
+                               float *pmf, float *cdf, int32_t *cdf_int, void *stream);
+
+/* torchac.encode_float_cdf (compress.py:134-136) / decode_float_cdf (decompress.py:92-93) on the
+ * integer CDFs of pccx_prob_forward.  One independent stream per cloud of nsym = S*d symbols.
+ * latent_q: (B,nsym) f32 integer-valued in [-(L/2), L/2]; out: (B,cap) bytes; nbytes: (B) int32
+ * (negative = capacity exceeded, |value| bytes were needed). */
+PCCX_API int pccx_range_encode(const int32_t *cdf_int, const float *latent_q, int B, int nsym, int L,
+                               uint8_t *out, int cap, int32_t *nbytes, void *stream);
+PCCX_API int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int stride,
+                               const int32_t *nbytes, int B, int nsym, int L, float *latent_q,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,59 @@
+// blobs.h -- layout of the packed weight blobs (device float arrays) the NN kernels read.
+//
+// A blob is built once at model-load time on the host by pccx_pack_* (pack.hip) from the
+// reference's state_dict tensors (SURVEY Appendix C key names) and uploaded by the caller.
+// Dense layers are stored as MFMA A-operand fragments (see mfma_chain.h):
+//     frag(kt, mt)[lane][r] = W[16*mt + (lane&15)][chan(16*kt + 4*(lane>>4) + r)]
+// kt-major ([kt][mt][64 lanes][4]); `chan` is a per-layer input-channel permutation chosen so
+// that producer and consumer kernels agree without any data movement.  All offsets are in
+// floats and multiples of 4 (16-byte aligned).
+#pragma once
+
+// ---- AE encoder: SetAbstraction 3->32->64->128 (AE.py:16) + PointNet 131->128->256->512->d (AE.py:17)
+#define ENC_SA_W0B0 0                         // [32][4]: w(3), bias
+#define ENC_SA_B1 (ENC_SA_W0B0 + 32 * 4)       // [64]
+#define ENC_SA_B2 (ENC_SA_B1 + 64)             // [128]
+#define ENC_SA_W1 (ENC_SA_B2 + 128)            // KT=2,  MT=4
+#define ENC_SA_W2 (ENC_SA_W1 + 2 * 4 * 256)    // KT=4,  MT=8
+#define ENC_PN_B0 (ENC_SA_W2 + 4 * 8 * 256)    // [128]
+#define ENC_PN_B1 (ENC_PN_B0 + 128)            // [256]
+#define ENC_PN_B2 (ENC_PN_B1 + 256)            // [512]
+#define ENC_PN_B3 (ENC_PN_B2 + 512)            // [16]  (d <= 16, zero padded)
+#define ENC_PN_W0 (ENC_PN_B3 + 16)             // KT=9 (128 SA features, then xyz), MT=8
+#define ENC_PN_W1 (ENC_PN_W0 + 9 * 8 * 256)    // KT=8,  MT=16
+#define ENC_PN_W2 (ENC_PN_W1 + 8 * 16 * 256)   // KT=16, MT=32
+#define ENC_PN_W3 (ENC_PN_W2 + 16 * 32 * 256)  // KT=32, MT=1
+#define ENC_BLOB_FLOATS (ENC_PN_W3 + 32 * 1 * 256)
+
+// ---- AE decoder: inv_pool 16->256->1024->k*128 (AE.py:19-26) + inv_mlp 144->128->64->32->3 (AE.py:27)
+#define DEC_H_B1 0                             // [256]
+#define DEC_H_B2 (DEC_H_B1 + 256)              // [1024]
+#define DEC_H_W1 (DEC_H_B2 + 1024)             // KT=1,  MT=16
+#define DEC_H_W2 (DEC_H_W1 + 1 * 16 * 256)     // KT=16, MT=64
+#define DEC_M_B0 (DEC_H_W2 + 16 * 64 * 256)    // [128]
+#define DEC_M_B1 (DEC_M_B0 + 128)              // [64]
+#define DEC_M_B2 (DEC_M_B1 + 64)               // [32]
+#define DEC_M_B3 (DEC_M_B2 + 32)               // [16] (3 used)
+#define DEC_M_W0 (DEC_M_B3 + 16)               // KT=9 (128 inv_pool channels, then the 16 latents), MT=8
+#define DEC_M_W1 (DEC_M_W0 + 9 * 8 * 256)      // KT=8, MT=4
+#define DEC_M_W2 (DEC_M_W1 + 8 * 4 * 256)      // KT=4, MT=2
+#define DEC_M_W3 (DEC_M_W2 + 4 * 2 * 256)      // KT=2, MT=1
+#define DEC_G_B (DEC_M_W3 + 2 * 1 * 256)       // [k*128] bias of inv_pool.4, rows permuted to p*128+c
+// followed by the inv_pool.4 fragments: KT=64, MT=k*8, rows permuted to o' = p*128 + c
+#define DEC_G_W(k) (DEC_G_B + (k) * 128)
+#define DEC_BLOB_FLOATS(k) (DEC_G_W(k) + 64 * ((k) * 8) * 256)
+
+// ---- ConditionalProbabilityModel (AE.py:87-123): PointNet 3->64->128->256, MLP 259->512->512->d*L
+#define PRB_P_B0 0                             // [64]
+#define PRB_P_B1 (PRB_P_B0 + 64)               // [128]
+#define PRB_P_B2 (PRB_P_B1 + 128)              // [256]
+#define PRB_M_B0 (PRB_P_B2 + 256)              // [512]
+#define PRB_M_B1 (PRB_M_B0 + 512)              // [512]
+#define PRB_M_B2 (PRB_M_B1 + 512)              // [128] (d*L = 112 used)
+#define PRB_P_W0 (PRB_M_B2 + 128)              // KT=1,  MT=4
+#define PRB_P_W1 (PRB_P_W0 + 1 * 4 * 256)      // KT=4,  MT=8
+#define PRB_P_W2 (PRB_P_W1 + 4 * 8 * 256)      // KT=8,  MT=16
+#define PRB_M_W0 (PRB_P_W2 + 8 * 16 * 256)     // KT=17 (256 features, then xyz), MT=32
+#define PRB_M_W1 (PRB_M_W0 + 17 * 32 * 256)    // KT=32, MT=32
+#define PRB_M_W2 (PRB_M_W1 + 32 * 32 * 256)    // KT=32, MT=8
+#define PRB_BLOB_FLOATS (PRB_M_W2 + 32 * 8 * 256)

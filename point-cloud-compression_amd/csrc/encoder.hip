@@ -1,0 +1,249 @@
+// encoder.hip -- the analysis transform of AE.AE (AE.py:34-45) for a batch of patches:
+//   SetAbstraction (pn_kit.py:146-211; AE.py:16: kNN-16 inside the patch, centre, Conv 3->32->64->128
+//   + ReLU, max over the 16 neighbours)  ->  PointNet (pn_kit.py:98-144; AE.py:17: Conv
+//   131->128->256->512->d, max over the K points)  ->  sigmoid spread + round (AE.py:43-45).
+//
+// The reference calls ae.sa / ae.pn once per patch from Python (compress.py:113-121: 128 tiny
+// launches per cloud); here one launch covers every patch of every cloud in the batch, one
+// workgroup per patch.  The GEMM-shaped layers run on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact fp32) as register-resident chains (mfma_chain.h).
+// MFMA-bound: 5.42 GFLOP (SA) + 6.19 GFLOP (PointNet) per 8192-point cloud.
+#include <math.h>
+
+#include "blobs.h"
+#include "common.h"
+#include "mfma_chain.h"
+
+// ------------------------------------------------------------------------------------------
+// SetAbstraction.  Workgroup = one patch (K points), 4 waves.
+//   phase 1: thread t finds the 16 nearest points of point t inside the patch (sorted insertion
+//            over an LDS broadcast of the patch; (dist, index) order as the oracle's orc_knn).
+//   phase 2: wave w walks its K/4 points; the 16 lanes of a DPP row are the 16 neighbours
+//            (n index of the MFMA tile), so max-pool over neighbours is a 4-step row reduction.
+// Output layout feat[P][8][K][16]: 16-channel groups are contiguous per point, which is what the
+// PointNet kernel loads as its B operand (one 16-byte load per lane, 1 KiB per wave).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restrict__ x, int K, const float *__restrict__ blob,
+                                                         float *__restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4 *sw1 = (f32x4 *)smem;                          // [2*4*64]   8 KiB
+    f32x4 *sw2 = sw1 + 2 * 4 * 64;                       // [4*8*64]  32 KiB
+    float *sb1 = (float *)(sw2 + 4 * 8 * 64);            // [64]
+    float *sb2 = sb1 + 64;                               // [128]
+    float *sx = sb2 + 128;                               // [3K]
+    unsigned char *nbr = (unsigned char *)(sx + 3 * K);  // [K][16] (index < K <= 1024 needs 10 bits)
+    unsigned short *nbr16 = (unsigned short *)nbr;       // stored as u16
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const size_t P = blockIdx.x;
+    const float *xp = x + P * (size_t)K * 3;
+
+    {   // stage weights + patch
+        const f32x4 *gw1 = (const f32x4 *)(blob + ENC_SA_W1);
+        const f32x4 *gw2 = (const f32x4 *)(blob + ENC_SA_W2);
+        for (int i = tid; i < 2 * 4 * 64; i += 256) sw1[i] = gw1[i];
+        for (int i = tid; i < 4 * 8 * 64; i += 256) sw2[i] = gw2[i];
+        if (tid < 64) sb1[tid] = blob[ENC_SA_B1 + tid];
+        if (tid < 128) sb2[tid] = blob[ENC_SA_B2 + tid];
+        for (int i = tid; i < 3 * K; i += 256) sx[i] = xp[i];
+    }
+    __syncthreads();
+
+    // ---- phase 1: kNN-16 inside the patch (pn_kit.py:190, K=16)
+    for (int i = tid; i < K; i += 256) {
+        const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
+        float td[16];
+        int ti[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { td[s] = INFINITY; ti[s] = 0; }
+        for (int j = 0; j < K; ++j) {
+            const float d = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
+            if (d < td[15]) {
+                // sorted insert AFTER any equal keys: candidates arrive in index order, so the list
+                // stays ordered by (distance, index), the oracle's orc_knn order.
+#pragma unroll
+                for (int s = 15; s >= 1; --s) {
+                    const bool shift = d < td[s - 1];
+                    const bool here = d < td[s];
+                    td[s] = shift ? td[s - 1] : (here ? d : td[s]);
+                    ti[s] = shift ? ti[s - 1] : (here ? j : ti[s]);
+                }
+                if (d < td[0]) { td[0] = d; ti[0] = j; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)ti[s];
+    }
+    __syncthreads();
+
+    // per-lane first-layer weights: channels c = 16*kt + 4*g + r, kt in {0,1}
+    f32x4 w0[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w0[kt][r] = *(const f32x4 *)(blob + ENC_SA_W0B0 + 4 * (16 * kt + 4 * g + r));
+
+    const int per_wave = (K + 3) / 4;
+    for (int i = w * per_wave; i < (w + 1) * per_wave && i < K; ++i) {
+        const int j = nbr16[i * 16 + n];
+        const float rx = __fsub_rn(sx[3 * j], sx[3 * i]);          // grouped_xyz -= new_xyz (pn_kit.py:191)
+        const float ry = __fsub_rn(sx[3 * j + 1], sx[3 * i + 1]);
+        const float rz = __fsub_rn(sx[3 * j + 2], sx[3 * i + 2]);
+        f32x4 h0[1][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 wv = w0[kt][r];
+                h0[0][kt][r] = fmaxf(fmaf(wv[2], rz, fmaf(wv[1], ry, fmaf(wv[0], rx, wv[3]))), 0.f);   // relu(conv0)
+            }
+        f32x4 a1[1][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a1[0][mt] = *(const f32x4 *)(sb1 + 16 * mt + 4 * g);
+        dense_acc<2, 4, 1, 4>(sw1, lane, h0, a1);                                   // conv1
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a1[0][mt] = relu4(a1[0][mt]);
+        f32x4 a2[1][8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a2[0][mt] = *(const f32x4 *)(sb2 + 16 * mt + 4 * g);
+        dense_acc<4, 8, 1, 8>(sw2, lane, a1, a2);                                   // conv2
+        // relu then max over the 16 neighbours (pn_kit.py:204-207) == max then relu
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(row16_max(a2[0][mt][r]), 0.f);
+            if (n == 0) *(f32x4 *)(feat + ((P * 8 + mt) * (size_t)K + i) * 16 + 4 * g) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PointNet + quantiser.  Workgroup = one patch, 4 waves; a wave walks point tiles of 16 (NT at a
+// time), keeps a running per-channel max, and the 4 waves combine through LDS.  Layers 2 and 3
+// are interleaved two output tiles at a time so the 512-channel activation never materialises.
+// Weights stream from L2 as packed fragments (1 KiB contiguous per wave-load).
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restrict__ x, const float *__restrict__ feat, int K,
+                                                         const float *__restrict__ blob, int d, float spread,
+                                                         float half_spread, float *__restrict__ latent_raw,
+                                                         float *__restrict__ latent, float *__restrict__ latent_q)
+{
+    __shared__ float smax[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const size_t P = blockIdx.x;
+    const float *xp = x + P * (size_t)K * 3;
+    const int ntiles = K >> 4;
+
+    f32x4 run;                                            // running max, channel 4g+r
+    run[0] = run[1] = run[2] = run[3] = -INFINITY;
+    for (int t0 = w * NT; t0 < ntiles; t0 += 4 * NT) {
+        blob = opaque_uniform(blob);
+        const f32x4 *w0 = (const f32x4 *)(blob + ENC_PN_W0);
+        const f32x4 *w1 = (const f32x4 *)(blob + ENC_PN_W1);
+        const f32x4 *w2 = (const f32x4 *)(blob + ENC_PN_W2);
+        const f32x4 *w3 = (const f32x4 *)(blob + ENC_PN_W3);
+        f32x4 in[NT][9];
+        bool valid[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int tile = t0 + nt;
+            valid[nt] = tile < ntiles;
+            const int p = (valid[nt] ? tile : 0) * 16 + n;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) in[nt][kt] = *(const f32x4 *)(feat + ((P * 8 + kt) * (size_t)K + p) * 16 + 4 * g);
+            f32x4 xyz;
+            xyz[0] = g == 0 ? xp[3 * p] : 0.f;            // channels 128,129,130 = x,y,z (g == 0, r = 0..2)
+            xyz[1] = g == 0 ? xp[3 * p + 1] : 0.f;
+            xyz[2] = g == 0 ? xp[3 * p + 2] : 0.f;
+            xyz[3] = 0.f;
+            in[nt][8] = xyz;
+        }
+        f32x4 a0[NT][8];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) a0[nt][mt] = *(const f32x4 *)(blob + ENC_PN_B0 + 16 * mt + 4 * g);
+        dense_acc<9, 8, NT, 8>(w0, lane, in, a0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) a0[nt][mt] = relu4(a0[nt][mt]);
+
+        f32x4 a1[NT][16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a1[nt][mt] = *(const f32x4 *)(blob + ENC_PN_B1 + 16 * mt + 4 * g);
+        dense_acc<8, 16, NT, 16>(w1, lane, a0, a1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a1[nt][mt] = relu4(a1[nt][mt]);
+
+        f32x4 a3[NT][1];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a3[nt][0] = *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
+#pragma unroll
+        for (int mp = 0; mp < 16; ++mp) {                 // pairs of layer-2 output tiles
+            f32x4 a2[NT][2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a2[nt][m] = *(const f32x4 *)(blob + ENC_PN_B2 + 16 * (2 * mp + m) + 4 * g);
+            dense_acc<16, 2, NT, 32>(w2, lane, a1, a2, 0, 2 * mp);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a2[nt][m] = relu4(a2[nt][m]);
+            dense_acc<2, 1, NT, 1>(w3, lane, a2, a3, 2 * mp, 0);  // last layer has no ReLU (AE.py:17 relu=[T,T,T,F])
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (valid[nt])
+#pragma unroll
+                for (int r = 0; r < 4; ++r) run[r] = fmaxf(run[r], row16_max(a3[nt][0][r]));
+    }
+    if (n == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smax[w][4 * g + r] = run[r];
+    __syncthreads();
+    if (tid < 16 && tid < d) {
+        const float m = fmaxf(fmaxf(smax[0][tid], smax[1][tid]), fmaxf(smax[2][tid], smax[3][tid]));   // torch.max(points, 2)
+        // latent = sigmoid(latent) * spread - spread / 2 ; round  (AE.py:43-45, compress.py:125-127)
+        const float s = 1.0f / (1.0f + expf(-m));
+        const float y = __fsub_rn(__fmul_rn(s, spread), half_spread);
+        latent_raw[P * d + tid] = m;
+        latent[P * d + tid] = y;
+        latent_q[P * d + tid] = rintf(y);
+    }
+}
+
+extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *enc_blob, int d, int L, float *feat_ws,
+                              float *latent_raw, float *latent, float *latent_q, void *stream)
+{
+    PCCX_CHECK_ARG(patches && enc_blob && feat_ws && latent_raw && latent && latent_q, "pccx_ae_encode: null pointer");
+    PCCX_CHECK_ARG(P >= 0 && K >= 16 && K <= 1024 && K % 16 == 0, "pccx_ae_encode: need K %% 16 == 0, 16 <= K <= 1024 (K=%d)", K);
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode: unsupported d=%d L=%d", d, L);
+    if (P == 0) return PCCX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sa_lds = (size_t)(2 * 4 * 64 + 4 * 8 * 64) * 16 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sa_forward_kernel, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, feat_ws);
+    PCCX_CHECK_LAUNCH();
+    const float spread = (float)((double)L - 0.2);
+    const float half = (float)(((double)L - 0.2) / 2);
+    hipLaunchKernelGGL(pn_forward_kernel<1>, dim3(P), dim3(256), 0, st, patches, feat_ws, K, enc_blob, d, spread, half,
+                       latent_raw, latent, latent_q);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

@@ -1,0 +1,153 @@
+// prob.hip -- AE.ConditionalProbabilityModel (AE.py:87-123) + pn_kit.pmf_to_cdf (pn_kit.py:452-461)
+// + torchac's float->16-bit CDF conversion, for a batch of clouds.
+//
+// Workgroup = one cloud (S decoded patch centres, S % 16 == 0), 4 waves.
+//   pass 1: PointNet 3->64->128->256 on every centre tile, max over all S centres -> LDS feature
+//   pass 2: per tile, Conv 259->512->512->d*L (feature broadcast + xyz), logits -> LDS,
+//           softmax over L per (centre, latent dim), cumsum, clamp, integer CDF.
+// Runs on both sides of the codec from bit-identical centres with a fixed summation order, so the
+// encoder's and the decoder's integer CDFs are identical (a range-coder requirement).
+#include <math.h>
+
+#include "blobs.h"
+#include "common.h"
+#include "mfma_chain.h"
+
+__global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__restrict__ centres, int S, int d, int L,
+                                                              const float *__restrict__ blob, float *__restrict__ pmf,
+                                                              float *__restrict__ cdf, int32_t *__restrict__ cdf_int)
+{
+    __shared__ __attribute__((aligned(16))) float sfeat[256];
+    __shared__ float smax[4][256];
+    __shared__ __attribute__((aligned(16))) float slog[4][16][128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const size_t b = blockIdx.x;
+    const float *cp = centres + b * (size_t)S * 3;
+    const int ntiles = S >> 4;
+
+    // ---- pass 1: model_pn (AE.py:96,112)
+    f32x4 run[16];
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) run[mt][0] = run[mt][1] = run[mt][2] = run[mt][3] = -INFINITY;
+    for (int tile = w; tile < ntiles; tile += 4) {
+        const float *bl = opaque_uniform(blob);
+        const int c = tile * 16 + n;
+        f32x4 in[1][1];
+        in[0][0][0] = g == 0 ? cp[3 * c] : 0.f;
+        in[0][0][1] = g == 0 ? cp[3 * c + 1] : 0.f;
+        in[0][0][2] = g == 0 ? cp[3 * c + 2] : 0.f;
+        in[0][0][3] = 0.f;
+        f32x4 a0[1][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a0[0][mt] = *(const f32x4 *)(bl + PRB_P_B0 + 16 * mt + 4 * g);
+        dense_acc<1, 4, 1, 4>((const f32x4 *)(bl + PRB_P_W0), lane, in, a0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a0[0][mt] = relu4(a0[0][mt]);
+        f32x4 a1[1][8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a1[0][mt] = *(const f32x4 *)(bl + PRB_P_B1 + 16 * mt + 4 * g);
+        dense_acc<4, 8, 1, 8>((const f32x4 *)(bl + PRB_P_W1), lane, a0, a1);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a1[0][mt] = relu4(a1[0][mt]);
+        f32x4 a2[1][16];
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) a2[0][mt] = *(const f32x4 *)(bl + PRB_P_B2 + 16 * mt + 4 * g);
+        dense_acc<8, 16, 1, 16>((const f32x4 *)(bl + PRB_P_W2), lane, a1, a2);
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) run[mt][r] = fmaxf(run[mt][r], fmaxf(row16_max(a2[0][mt][r]), 0.f));
+    }
+    if (n == 0)
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) smax[w][16 * mt + 4 * g + r] = run[mt][r];
+    __syncthreads();
+    sfeat[tid] = fmaxf(fmaxf(smax[0][tid], smax[1][tid]), fmaxf(smax[2][tid], smax[3][tid]));
+    __syncthreads();
+
+    // ---- pass 2: model_mlp (AE.py:97-105,115-118) + softmax (AE.py:120) + cdf
+    const int Lp = L + 1;
+    for (int tile0 = 0; tile0 < ntiles; tile0 += 4) {
+        const int tile = tile0 + w;
+        if (tile < ntiles) {
+            const float *bl = opaque_uniform(blob);
+            const int c = tile * 16 + n;
+            f32x4 a0[1][32];
+#pragma unroll
+            for (int mt = 0; mt < 32; ++mt) a0[0][mt] = *(const f32x4 *)(bl + PRB_M_B0 + 16 * mt + 4 * g);
+#pragma unroll 1
+            for (int kt = 0; kt < 17; ++kt) {
+                f32x4 in[1][1];
+                if (kt < 16) {
+                    in[0][0] = *(const f32x4 *)(sfeat + 16 * kt + 4 * g);      // feature, same for every centre
+                } else {
+                    in[0][0][0] = g == 0 ? cp[3 * c] : 0.f;
+                    in[0][0][1] = g == 0 ? cp[3 * c + 1] : 0.f;
+                    in[0][0][2] = g == 0 ? cp[3 * c + 2] : 0.f;
+                    in[0][0][3] = 0.f;
+                }
+                dense_acc<1, 32, 1, 32>(opaque_uniform((const f32x4 *)(bl + PRB_M_W0)) + (size_t)kt * 32 * 64, lane, in, a0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 32; ++mt) a0[0][mt] = relu4(a0[0][mt]);
+            f32x4 a2[1][8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) a2[0][mt] = *(const f32x4 *)(bl + PRB_M_B2 + 16 * mt + 4 * g);
+#pragma unroll
+            for (int mp = 0; mp < 16; ++mp) {
+                f32x4 a1[1][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a1[0][m] = *(const f32x4 *)(bl + PRB_M_B1 + 16 * (2 * mp + m) + 4 * g);
+                dense_acc<32, 2, 1, 32>((const f32x4 *)(bl + PRB_M_W1), lane, a0, a1, 0, 2 * mp);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a1[0][m] = relu4(a1[0][m]);
+                dense_acc<2, 8, 1, 8>((const f32x4 *)(bl + PRB_M_W2), lane, a1, a2, 2 * mp, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) *(f32x4 *)(&slog[w][n][16 * mt + 4 * g]) = a2[0][mt];
+        }
+        __syncthreads();
+        // one thread per (centre, latent dim): the wave's own tile, 16 centres x 16 dims
+        if (tile < ntiles) {
+            for (int e = lane; e < 16 * d; e += 64) {
+                const int cn = e / d, i = e % d;
+                const float *lg = &slog[w][cn][i * L];          // output.view(B,S,d,L): channel i*L + l
+                float mx = -INFINITY;
+                for (int l = 0; l < L; ++l) mx = fmaxf(mx, lg[l]);
+                float sum = 0.f;
+                for (int l = 0; l < L; ++l) sum += expf(lg[l] - mx);
+                const size_t row = (b * S + (size_t)tile * 16 + cn) * d + i;
+                float run_c = 0.f;
+                if (cdf) cdf[row * Lp] = 0.f;
+                if (cdf_int) cdf_int[row * Lp] = 0;
+                for (int l = 0; l < L; ++l) {
+                    const float pv = expf(lg[l] - mx) / sum;
+                    if (pmf) pmf[row * L + l] = pv;
+                    run_c = run_c + pv;                                        // cumsum (pn_kit.py:453)
+                    const float cv = fminf(run_c, 1.0f);                       // clamp(max=1) (pn_kit.py:460)
+                    if (cdf) cdf[row * Lp + l + 1] = cv;
+                    // torchac: round(cdf * (2^16 - (Lp-1))) + arange(Lp), kept to 16 bits
+                    if (cdf_int) cdf_int[row * Lp + l + 1] = ((int)rintf(cv * (float)(65536 - (Lp - 1))) + (l + 1)) & 0xFFFF;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int pccx_prob_forward(const float *centres, int B, int S, int d, int L, const float *prob_blob, float *pmf,
+                                 float *cdf, int32_t *cdf_int, void *stream)
+{
+    PCCX_CHECK_ARG(centres && prob_blob, "pccx_prob_forward: null pointer");
+    PCCX_CHECK_ARG(pmf || cdf || cdf_int, "pccx_prob_forward: no output requested");
+    PCCX_CHECK_ARG(B >= 0 && S >= 16 && S % 16 == 0, "pccx_prob_forward: need S %% 16 == 0 (S=%d)", S);
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1 && L <= 15 && d * L <= 128, "pccx_prob_forward: unsupported d=%d L=%d", d, L);
+    if (B == 0) return PCCX_OK;
+    hipLaunchKernelGGL(prob_forward_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, centres, S, d, L, prob_blob, pmf, cdf,
+                       cdf_int);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

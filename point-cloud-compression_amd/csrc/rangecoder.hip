@@ -1,0 +1,155 @@
+// rangecoder.hip -- torchac-style range coder (compress.py:136 encode_float_cdf, decompress.py:93
+// decode_float_cdf) on the GPU: 32-bit low/high, 16-bit CDFs, E1/E2/E3 renormalisation with pending
+// bits, MSB-first bit packing, zero-padded last byte.  Byte layout PARITY UNPINNED (torchac is not in
+// the image); the oracle (orc_range_encode / orc_range_decode) restates the same published algorithm
+// and must agree byte-for-byte.
+//
+// The coder is inherently serial per stream (S*d = 1024 symbols per cloud), so parallelism is one
+// lane per cloud; at ~0.5 KiB per cloud this is integer/byte work that never shows in the profile.
+#include "common.h"
+
+struct BitWriter {
+    uint8_t *buf;
+    int cap, n;
+    unsigned cache;
+    int count;
+    __device__ void bit(int b)
+    {
+        cache = (cache << 1) | (unsigned)(b & 1);
+        if (++count == 8) {
+            if (n < cap) buf[n] = (uint8_t)cache;
+            ++n;
+            count = 0; cache = 0;
+        }
+    }
+    __device__ void bit_pending(int b, unsigned long long &pending)
+    {
+        bit(b);
+        while (pending > 0) { bit(!b); --pending; }
+    }
+    __device__ void flush()
+    {
+        if (count > 0) {
+            cache <<= (8 - count);
+            if (n < cap) buf[n] = (uint8_t)cache;
+            ++n;
+            count = 0; cache = 0;
+        }
+    }
+};
+
+__global__ void range_encode_kernel(const int32_t *__restrict__ cdf_int, const float *__restrict__ latent_q, int B, int nsym,
+                                    int Lp, int sym_offset, uint8_t *__restrict__ out, int cap, int32_t *__restrict__ nbytes)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    BitWriter w{out + (size_t)b * cap, cap, 0, 0u, 0};
+    unsigned low = 0u, high = 0xFFFFFFFFu;
+    unsigned long long pending = 0;
+    const int max_symbol = Lp - 2;
+    const int32_t *c = cdf_int + (size_t)b * nsym * Lp;
+    const float *q = latent_q + (size_t)b * nsym;
+    for (int i = 0; i < nsym; ++i, c += Lp) {
+        int s = (int)q[i] + sym_offset;                       // latent_quantized.to(int16) + L//2 (compress.py:135)
+        s = s < 0 ? 0 : (s > max_symbol ? max_symbol : s);
+        const unsigned long long span = (unsigned long long)high - (unsigned long long)low + 1ull;
+        const unsigned c_low = (unsigned)c[s] & 0xFFFFu;
+        const unsigned c_high = s == max_symbol ? 0x10000u : ((unsigned)c[s + 1] & 0xFFFFu);
+        high = (unsigned)((low - 1u) + (unsigned)((span * c_high) >> 16));
+        low = (unsigned)(low + (unsigned)((span * c_low) >> 16));
+        for (;;) {
+            if (high < 0x80000000u) {
+                w.bit_pending(0, pending);
+                low <<= 1; high <<= 1; high |= 1u;
+            } else if (low >= 0x80000000u) {
+                w.bit_pending(1, pending);
+                low <<= 1; high <<= 1; high |= 1u;
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                ++pending;
+                low <<= 1; low &= 0x7FFFFFFFu;
+                high <<= 1; high |= 0x80000001u;
+            } else
+                break;
+        }
+    }
+    ++pending;
+    if (low < 0x40000000u) w.bit_pending(0, pending);
+    else w.bit_pending(1, pending);
+    w.flush();
+    nbytes[b] = w.n <= cap ? w.n : -w.n;                      // negative: capacity exceeded
+}
+
+__global__ void range_decode_kernel(const int32_t *__restrict__ cdf_int, const uint8_t *__restrict__ in, int stride,
+                                    const int32_t *__restrict__ nbytes, int B, int nsym, int Lp, int sym_offset,
+                                    float *__restrict__ latent_q)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint8_t *buf = in + (size_t)b * stride;
+    const int nb = nbytes[b] < 0 ? 0 : (nbytes[b] > stride ? stride : nbytes[b]);
+    int pos = 0, cached = 0;
+    unsigned cache = 0;
+    unsigned low = 0u, high = 0xFFFFFFFFu, value = 0u;
+    auto get = [&]() {
+        if (cached == 0) {
+            if (pos >= nb) { value <<= 1; return; }
+            cache = buf[pos++]; cached = 8;
+        }
+        value = (value << 1) | ((cache >> (cached - 1)) & 1u);
+        --cached;
+    };
+    for (int i = 0; i < 32; ++i) get();
+    const int max_symbol = Lp - 2;
+    const int32_t *c = cdf_int + (size_t)b * nsym * Lp;
+    for (int i = 0; i < nsym; ++i, c += Lp) {
+        const unsigned long long span = (unsigned long long)high - (unsigned long long)low + 1ull;
+        const unsigned count =
+            (unsigned)((((unsigned long long)value - (unsigned long long)low + 1ull) * 0x10000ull - 1ull) / span) & 0xFFFFu;
+        int left = 0, right = max_symbol + 1;
+        while (left + 1 < right) {
+            const int mid = (left + right) >> 1;
+            if (((unsigned)c[mid] & 0xFFFFu) <= count) left = mid; else right = mid;
+        }
+        const int s = left;
+        latent_q[(size_t)b * nsym + i] = (float)(s - sym_offset);            // decode - L//2 (decompress.py:93)
+        const unsigned c_low = (unsigned)c[s] & 0xFFFFu;
+        const unsigned c_high = s == max_symbol ? 0x10000u : ((unsigned)c[s + 1] & 0xFFFFu);
+        high = (unsigned)((low - 1u) + (unsigned)((span * c_high) >> 16));
+        low = (unsigned)(low + (unsigned)((span * c_low) >> 16));
+        for (;;) {
+            if (low >= 0x80000000u || high < 0x80000000u) {
+                low <<= 1; high <<= 1; high |= 1u; get();
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                low <<= 1; low &= 0x7FFFFFFFu;
+                high <<= 1; high |= 0x80000001u;
+                value -= 0x40000000u;
+                get();
+            } else
+                break;
+        }
+    }
+}
+
+extern "C" int pccx_range_encode(const int32_t *cdf_int, const float *latent_q, int B, int nsym, int L, uint8_t *out, int cap,
+                                 int32_t *nbytes, void *stream)
+{
+    PCCX_CHECK_ARG(cdf_int && latent_q && out && nbytes, "pccx_range_encode: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && cap >= 8, "pccx_range_encode: bad shape");
+    if (B == 0) return PCCX_OK;
+    hipLaunchKernelGGL(range_encode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cdf_int, latent_q, B, nsym,
+                       L + 1, L / 2, out, cap, nbytes);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int stride, const int32_t *nbytes, int B, int nsym,
+                                 int L, float *latent_q, void *stream)
+{
+    PCCX_CHECK_ARG(cdf_int && in && nbytes && latent_q, "pccx_range_decode: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && stride >= 1, "pccx_range_decode: bad shape");
+    if (B == 0) return PCCX_OK;
+    hipLaunchKernelGGL(range_decode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cdf_int, in, stride, nbytes,
+                       B, nsym, L + 1, L / 2, latent_q);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

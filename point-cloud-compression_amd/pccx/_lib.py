@@ -24,7 +24,21 @@ _SIGNATURES = {
     "pccx_octree_bits_capacity": [C.c_int],
     "pccx_octree_encode": [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P],
     "pccx_octree_decode": [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "pccx_ae_encoder_blob_floats": [],
+    "pccx_pack_ae_encoder": [_P] * 14 + [C.c_int, _P],
+    "pccx_ae_decoder_blob_floats": [C.c_int],
+    "pccx_pack_ae_decoder": [_P] * 14 + [C.c_int, C.c_int, _P],
+    "pccx_prob_blob_floats": [],
+    "pccx_pack_prob": [_P] * 12 + [C.c_int, C.c_int, _P],
+    "pccx_ae_encode": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "pccx_ae_decode_workspace_floats": [C.c_int],
+    "pccx_ae_decode": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_double, _P, _P],
+    "pccx_prob_forward": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "pccx_range_encode": [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
+    "pccx_range_decode": [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P],
 }
+_RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
+             "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t}
 
 _lib = None
 
@@ -47,7 +61,7 @@ def load():
         for name, args in _SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError if the ABI and the header disagree
             fn.argtypes = args
-            fn.restype = C.c_int
+            fn.restype = _RESTYPES.get(name, C.c_int)
         _lib = lib
     return _lib
 

@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's model classes (AE.py, pn_kit.py) over libpccx.so.
+
+The classes keep the reference's constructor arguments and ``state_dict`` key names (SURVEY
+Appendix C) so reference checkpoints load with ``load_state_dict``; torch modules are used as
+parameter containers only.  Every forward computation is a HIP kernel behind the C ABI; there
+is no torch / CPU compute path (inference only, as compress.py / decompress.py use the models).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import _stream, _f32c
+
+
+def _conv_stack(chans, relu):
+    mods = nn.ModuleList()
+    for i in range(len(chans) - 1):
+        layers = [nn.Conv2d(chans[i], chans[i + 1], 1)]
+        if relu[i]:
+            layers.append(nn.ReLU())
+        mods.append(nn.Sequential(*layers))
+    return mods
+
+
+class _Params(nn.Module):
+    def forward(self, *a, **k):
+        raise _lib.PccxError(f"{type(self).__name__} is a parameter container; use the owning model's HIP entry points")
+
+
+class SetAbstraction(_Params):      # pn_kit.SetAbstraction (pn_kit.py:146-161), bn=False
+    def __init__(self, npoint, K, in_channel, mlp):
+        super().__init__()
+        self.npoint, self.K = npoint, K
+        self.conv0 = nn.Conv2d(in_channel + 3, mlp[0], 1)
+        self.conv1 = nn.Conv2d(mlp[0], mlp[1], 1)
+        self.conv2 = nn.Conv2d(mlp[1], mlp[2], 1)
+
+
+class PointNet(_Params):            # pn_kit.PointNet (pn_kit.py:98-121), bn=False
+    def __init__(self, in_channel, mlps, relu):
+        super().__init__()
+        self.mlp_Modules = _conv_stack([in_channel] + list(mlps), relu)
+
+
+class MLP(_Params):                 # pn_kit.MLP (pn_kit.py:263-286), bn=False
+    def __init__(self, in_channel, mlps, relu):
+        super().__init__()
+        self.mlp_Modules = _conv_stack([in_channel] + list(mlps), relu)
+
+
+def _host(t):
+    return t.detach().to("cpu", torch.float32).contiguous()
+
+
+def _pack(fn_name, size, tensors, ints):
+    keep = [_host(t) for t in tensors]
+    blob = torch.zeros(size, dtype=torch.float32)
+    _lib.call(fn_name, *[t.data_ptr() for t in keep], *ints, blob.data_ptr())
+    return blob
+
+
+class AE(nn.Module):
+    """AE.AE (AE.py:12-55): SetAbstraction + PointNet encoder, Linear + MLP decoder."""
+
+    def __init__(self, K, k, d, L):
+        super().__init__()
+        if d > 16:
+            raise _lib.PccxError("pccx.AE supports bottleneck d <= 16")
+        self.sa = SetAbstraction(npoint=K, K=16, in_channel=0, mlp=[32, 64, 128])
+        self.pn = PointNet(3 + 128, [128, 256, 512, d], [True, True, True, False])
+        self.inv_pool = nn.Sequential(nn.Linear(d, 256), nn.ReLU(), nn.Linear(256, 1024), nn.ReLU(),
+                                      nn.Linear(1024, k * 128), nn.ReLU())
+        self.inv_mlp = MLP(d + 128, [128, 64, 32, 3], [True, True, True, False])
+        self.K, self.k, self.d, self.L = K, k, d, L
+        self._enc_blob = self._dec_blob = None
+
+    def quantize(self, x):          # AE.STEQuantize.forward (AE.py:79-81)
+        return x.round()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._enc_blob = self._dec_blob = None
+        return r
+
+    def pack(self, device="cuda"):
+        """Build the MFMA fragment blobs (C ABI pccx_pack_*) and upload them."""
+        sd = self.state_dict()
+        w = lambda key: sd[key].reshape(sd[key].shape[0], -1)
+        lib = _lib.load()
+        enc = _pack("pccx_pack_ae_encoder", lib.pccx_ae_encoder_blob_floats(),
+                    [w("sa.conv0.weight"), sd["sa.conv0.bias"], w("sa.conv1.weight"), sd["sa.conv1.bias"],
+                     w("sa.conv2.weight"), sd["sa.conv2.bias"],
+                     w("pn.mlp_Modules.0.0.weight"), sd["pn.mlp_Modules.0.0.bias"],
+                     w("pn.mlp_Modules.1.0.weight"), sd["pn.mlp_Modules.1.0.bias"],
+                     w("pn.mlp_Modules.2.0.weight"), sd["pn.mlp_Modules.2.0.bias"],
+                     w("pn.mlp_Modules.3.0.weight"), sd["pn.mlp_Modules.3.0.bias"]], [self.d])
+        dec = _pack("pccx_pack_ae_decoder", lib.pccx_ae_decoder_blob_floats(self.k),
+                    [sd["inv_pool.0.weight"], sd["inv_pool.0.bias"], sd["inv_pool.2.weight"], sd["inv_pool.2.bias"],
+                     sd["inv_pool.4.weight"], sd["inv_pool.4.bias"],
+                     w("inv_mlp.mlp_Modules.0.0.weight"), sd["inv_mlp.mlp_Modules.0.0.bias"],
+                     w("inv_mlp.mlp_Modules.1.0.weight"), sd["inv_mlp.mlp_Modules.1.0.bias"],
+                     w("inv_mlp.mlp_Modules.2.0.weight"), sd["inv_mlp.mlp_Modules.2.0.bias"],
+                     w("inv_mlp.mlp_Modules.3.0.weight"), sd["inv_mlp.mlp_Modules.3.0.bias"]], [self.k, self.d])
+        self._enc_blob, self._dec_blob = enc.to(device), dec.to(device)
+        return self
+
+    def _blobs(self, device):
+        if self._enc_blob is None or self._enc_blob.device != torch.device(device):
+            self.pack(device)
+        return self._enc_blob, self._dec_blob
+
+    def encode(self, patches):
+        """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
+        = ae.sa + ae.pn + sigmoid spread + round (compress.py:113-127, AE.py:37-45)."""
+        x = _f32c(patches, "AE.encode")
+        P, K, _ = x.shape
+        enc, _ = self._blobs(x.device)
+        ws = torch.empty(P * K * 128, device=x.device, dtype=torch.float32)
+        outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
+        _lib.call("pccx_ae_encode", x.data_ptr(), P, K, enc.data_ptr(), self.d, self.L, ws.data_ptr(),
+                  outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+        return tuple(outs)
+
+    def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01):
+        """latent_q (BS,d) -> decoded patches (BS,k,3) (AE.py:48-53).  With centres/center/longest/S/scale
+        it returns instead the reassembled, denormalised cloud (B,S*k,3) of decompress.py:104-116."""
+        q = _f32c(latent_q, "AE.decode")
+        P = q.shape[0]
+        _, dec = self._blobs(q.device)
+        ws = torch.empty(_lib.load().pccx_ae_decode_workspace_floats(P), device=q.device, dtype=torch.float32)
+        if centres is None:
+            out = torch.empty(P, self.k, 3, device=q.device, dtype=torch.float32)
+            _lib.call("pccx_ae_decode", q.data_ptr(), P, self.d, self.k, dec.data_ptr(), ws.data_ptr(), out.data_ptr(),
+                      0.0, None, None, None, 1, float(margin), None, _stream())
+            return out
+        B = P // S
+        centres = _f32c(centres.reshape(P, 3), "AE.decode.centres")
+        center = _f32c(center.reshape(B, 3), "AE.decode.center")
+        longest = _f32c(longest.reshape(B), "AE.decode.longest")
+        pc = torch.empty(B, S * self.k, 3, device=q.device, dtype=torch.float32)
+        _lib.call("pccx_ae_decode", q.data_ptr(), P, self.d, self.k, dec.data_ptr(), ws.data_ptr(), None, float(scale),
+                  centres.data_ptr(), center.data_ptr(), longest.data_ptr(), int(S), float(margin), pc.data_ptr(), _stream())
+        return pc
+
+    def forward(self, xyz):
+        """AE.AE.forward (AE.py:34-55), inference: xyz (BS,K,3) -> (new_xyz (BS,k,3), latent, latent_quantized)."""
+        _, latent, q = self.encode(xyz)
+        return self.decode(q), latent, q
+
+
+class ConditionalProbabilityModel(nn.Module):
+    """AE.ConditionalProbabilityModel (AE.py:87-123)."""
+
+    def __init__(self, L, d):
+        super().__init__()
+        self.L, self.d = L, d
+        self.model_pn = PointNet(3, [64, 128, 256], [True, True, True])
+        self.model_mlp = nn.Sequential(nn.Conv2d(3 + 256, 512, 1), nn.ReLU(), nn.Conv2d(512, 512, 1), nn.ReLU(),
+                                       nn.Conv2d(512, d * L, 1))
+        self._blob = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._blob = None
+        return r
+
+    def pack(self, device="cuda"):
+        sd = self.state_dict()
+        w = lambda key: sd[key].reshape(sd[key].shape[0], -1)
+        blob = _pack("pccx_pack_prob", _lib.load().pccx_prob_blob_floats(),
+                     [w("model_pn.mlp_Modules.0.0.weight"), sd["model_pn.mlp_Modules.0.0.bias"],
+                      w("model_pn.mlp_Modules.1.0.weight"), sd["model_pn.mlp_Modules.1.0.bias"],
+                      w("model_pn.mlp_Modules.2.0.weight"), sd["model_pn.mlp_Modules.2.0.bias"],
+                      w("model_mlp.0.weight"), sd["model_mlp.0.bias"], w("model_mlp.2.weight"), sd["model_mlp.2.bias"],
+                      w("model_mlp.4.weight"), sd["model_mlp.4.bias"]], [self.d, self.L])
+        self._blob = blob.to(device)
+        return self
+
+    def run(self, sampled_xyz, want=("pmf",)):
+        """sampled_xyz (B,S,3) -> dict with any of pmf (B,S,d,L), cdf (B,S,d,L+1), cdf_int (int32)."""
+        x = _f32c(sampled_xyz, "ConditionalProbabilityModel")
+        B, S, _ = x.shape
+        if self._blob is None or self._blob.device != x.device:
+            self.pack(x.device)
+        r = {}
+        if "pmf" in want:
+            r["pmf"] = torch.empty(B, S, self.d, self.L, device=x.device, dtype=torch.float32)
+        if "cdf" in want:
+            r["cdf"] = torch.empty(B, S, self.d, self.L + 1, device=x.device, dtype=torch.float32)
+        if "cdf_int" in want:
+            r["cdf_int"] = torch.empty(B, S, self.d, self.L + 1, device=x.device, dtype=torch.int32)
+        p = lambda k: r[k].data_ptr() if k in r else None
+        _lib.call("pccx_prob_forward", x.data_ptr(), B, S, self.d, self.L, self._blob.data_ptr(), p("pmf"), p("cdf"),
+                  p("cdf_int"), _stream())
+        return r
+
+    def forward(self, sampled_xyz):
+        return self.run(sampled_xyz, ("pmf",))["pmf"]
+
+
+def range_encode(cdf_int, latent_q, L, cap=None):
+    """torchac.encode_float_cdf on device: cdf_int (B,nsym,L+1) int32, latent_q (B,nsym) -> (bytes (B,cap) u8, nbytes (B))."""
+    B = cdf_int.shape[0]
+    nsym = cdf_int[0].numel() // (L + 1)
+    cap = cap or (nsym * 2 + 16)
+    q = _f32c(latent_q.reshape(B, nsym), "range_encode")
+    out = torch.empty(B, cap, device=q.device, dtype=torch.uint8)
+    nb = torch.empty(B, device=q.device, dtype=torch.int32)
+    _lib.call("pccx_range_encode", cdf_int.contiguous().data_ptr(), q.data_ptr(), B, nsym, int(L), out.data_ptr(), cap,
+              nb.data_ptr(), _stream())
+    return out, nb
+
+
+def range_decode(cdf_int, bytes_, nbytes, L):
+    """torchac.decode_float_cdf on device -> latent_q (B,nsym) f32 (already minus L//2)."""
+    B = cdf_int.shape[0]
+    nsym = cdf_int[0].numel() // (L + 1)
+    bytes_ = bytes_.contiguous()
+    q = torch.empty(B, nsym, device=bytes_.device, dtype=torch.float32)
+    _lib.call("pccx_range_decode", cdf_int.contiguous().data_ptr(), bytes_.data_ptr(), bytes_.shape[1],
+              nbytes.to(torch.int32).contiguous().data_ptr(), B, nsym, int(L), q.data_ptr(), _stream())
+    return q

@@ -1,0 +1,159 @@
+"""GPU parity: the neural transforms (fp32 MFMA chains) vs golden fixtures and the torch oracle.
+
+Tolerances (floating point, stated per assert): the HIP path accumulates each dot product as a
+k-ordered fp32 fmaf chain on the matrix cores, torch CPU uses oneDNN/MKL blocked sums, so results
+agree to ~1e-6 relative, not bit-for-bit.  Quantised symbols must be identical except where the
+pre-rounding value sits within 1e-4 of a rounding boundary.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cport, ref_model
+from pccx import models, ops
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+K, k, d, L = synth.MODEL_CFG
+
+
+@pytest.fixture(scope="module")
+def nets():
+    ae = models.AE(K, k, d, L)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    prob = models.ConditionalProbabilityModel(L, d)
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, synth.PROB_SEED, gain=synth.PROB_GAIN))
+    oae = ref_model.AE(K, k, d, L).eval()
+    oae.load_state_dict(ae.state_dict())
+    oprob = ref_model.ConditionalProbabilityModel(L, d).eval()
+    oprob.load_state_dict(prob.state_dict())
+    return ae.pack("cuda"), prob.pack("cuda"), oae, oprob
+
+
+def _symbols_agree(q_gpu, latent_ref, q_ref):
+    bad = q_gpu != q_ref
+    if bad.any():
+        frac = np.abs(latent_ref[bad] - np.floor(latent_ref[bad]) - 0.5)
+        assert (frac < 1e-4).all(), f"{bad.sum()} symbol flips away from a rounding boundary"
+    return int(bad.sum())
+
+
+def test_state_dict_keys_match_reference(nets):
+    md = np.load(os.path.join(G, "model.npz"))
+    ae, prob = nets[0], nets[1]
+    assert list(ae.state_dict().keys()) == list(md["ae_keys"])
+    assert [str(tuple(v.shape)) for v in ae.state_dict().values()] == list(md["ae_shapes"])
+    assert list(prob.state_dict().keys()) == list(md["prob_keys"])
+
+
+def test_encoder_matches_golden(nets):
+    md = np.load(os.path.join(G, "model.npz"))
+    ae = nets[0]
+    patches = torch.from_numpy(synth.patch_batch(K)).cuda()
+    raw, latent, q = ae.encode(patches)
+    np.testing.assert_allclose(raw.cpu().numpy(), md["pn_latent_raw"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(latent.cpu().numpy(), md["ae_latent"], rtol=0, atol=5e-5)
+    _symbols_agree(q.cpu().numpy(), md["ae_latent"], md["ae_latent_q"])
+
+
+def test_decoder_matches_golden(nets):
+    md = np.load(os.path.join(G, "model.npz"))
+    ae = nets[0]
+    lq = torch.from_numpy(synth.latent_case(2, d, L)).cuda()
+    out = ae.decode(lq)
+    np.testing.assert_allclose(out.cpu().numpy(), md["dec_out"], rtol=1e-4, atol=2e-5)
+    rec, latent, q = ae(torch.from_numpy(synth.patch_batch(K)).cuda())
+    if np.array_equal(q.cpu().numpy(), md["ae_latent_q"]):
+        np.testing.assert_allclose(rec.cpu().numpy(), md["ae_recon"], rtol=1e-4, atol=2e-5)
+
+
+def test_prob_model_matches_golden(nets):
+    md = np.load(os.path.join(G, "model.npz"))
+    prob = nets[1]
+    r = prob.run(torch.from_numpy(synth.centres_case()).cuda(), ("pmf", "cdf", "cdf_int"))
+    np.testing.assert_allclose(r["pmf"].cpu().numpy(), md["pmf"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["cdf"].cpu().numpy(), md["cdf"], rtol=0, atol=4e-6)
+    want = ref_model.cdf_float_to_int(torch.from_numpy(md["cdf"]))
+    got = r["cdf_int"].cpu().numpy()
+    diff = ((got.astype(np.int64) - want.astype(np.int64) + 32768) % 65536) - 32768
+    assert np.abs(diff).max() <= 1          # +-1 count where the float cdf differs in its last bits
+
+
+@pytest.mark.parametrize("P", [1, 5, 37])
+def test_encoder_decoder_vs_oracle_ragged_batches(nets, P):
+    ae, _, oae, _ = nets
+    rng = np.random.default_rng(P)
+    base = synth.patch_batch(K, P=min(P, 6), seed=70 + P)
+    patches = np.concatenate([base] * ((P + base.shape[0] - 1) // base.shape[0]))[:P].copy()
+    patches += rng.normal(0, 1e-3, patches.shape).astype(np.float32)
+    x = torch.from_numpy(patches)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        olat = oae.encode(x)
+        oq = olat.round()
+        odec = oae.decode(oq)
+    raw, latent, q = ae.encode(x.cuda())
+    np.testing.assert_allclose(latent.cpu().numpy(), olat.numpy(), rtol=0, atol=5e-5)
+    flips = _symbols_agree(q.cpu().numpy(), olat.numpy(), oq.numpy())
+    dec = ae.decode(oq.cuda())
+    np.testing.assert_allclose(dec.cpu().numpy(), odec.numpy(), rtol=1e-4, atol=2e-5)
+    assert flips <= max(1, P * d // 200)
+
+
+def test_sa_knn_ties_on_lattice_patch(nets):
+    """Lattice patch: many equal in-patch distances; the kNN-16 tie rule (lower index) must match."""
+    ae, _, oae, _ = nets
+    rng = np.random.default_rng(0)
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(4), indexing="ij"), -1).reshape(-1, 3)
+    patches = ((g[rng.permutation(256)] - 3.5) * 0.05).astype(np.float32)[None]
+    with torch.no_grad():
+        olat = oae.encode(torch.from_numpy(patches))
+    _, latent, _ = ae.encode(torch.from_numpy(patches).cuda())
+    np.testing.assert_allclose(latent.cpu().numpy(), olat.numpy(), rtol=0, atol=5e-5)
+
+
+def test_decode_reassembly_matches_decompress_ops(nets):
+    """pc_out path = decompress.py:104-116: / scale, + centres, denormalize."""
+    ae, _, oae, _ = nets
+    S, B = 64, 2
+    rng = np.random.default_rng(4)
+    lq = rng.integers(-3, 4, size=(B * S, d)).astype(np.float32)
+    centres = ((rng.integers(0, 128, size=(B, S, 3)) + 0.5) / 128).astype(np.float32)
+    center = rng.normal(size=(B, 3)).astype(np.float32)
+    longest = (1 + rng.random(B)).astype(np.float32)
+    scale = float((S * k / 1024) ** (1 / 3))
+    pc = ae.decode(torch.from_numpy(lq).cuda(), torch.from_numpy(centres).cuda(), torch.from_numpy(center).cuda(),
+                   torch.from_numpy(longest).cuda(), S=S, scale=scale)
+    raw = ae.decode(torch.from_numpy(lq).cuda()).cpu()
+    patches = raw / scale
+    want = (patches.view(B, S, -1, 3) + torch.from_numpy(centres).view(B, S, 1, 3)).reshape(B, -1, 3)
+    for b in range(B):
+        w = ref_model.denormalize(want[b:b + 1], torch.from_numpy(center[b]).reshape(1, 3), torch.from_numpy(longest[b:b + 1]))
+        assert np.array_equal(pc[b].cpu().numpy(), w[0].numpy())      # same fp32 op sequence: bit-exact
+
+
+def test_range_coder_device_matches_oracle_bytes_and_round_trips(nets):
+    prob = nets[1]
+    rng = np.random.default_rng(6)
+    B, S = 9, 64
+    centres = ((rng.integers(0, 128, size=(B, S, 3)) + 0.5) / 128).astype(np.float32)
+    r = prob.run(torch.from_numpy(centres).cuda(), ("pmf", "cdf_int"))
+    pmf = r["pmf"].cpu().numpy().reshape(B, S * d, L).astype(np.float64)
+    sym = np.stack([[rng.choice(L, p=row / row.sum()) for row in pmf[b]] for b in range(B)])
+    sym[0] = 0; sym[1] = L - 1                                   # degenerate streams
+    q = (sym - L // 2).astype(np.float32)
+    by, nb = models.range_encode(r["cdf_int"], torch.from_numpy(q).cuda(), L)
+    back = models.range_decode(r["cdf_int"], by, nb, L)
+    assert np.array_equal(back.cpu().numpy(), q)                 # lossless on device
+    ci = r["cdf_int"].cpu().numpy().reshape(B, S * d, L + 1)
+    tot_ideal = 0.0
+    for b in range(B):
+        want = cport.range_encode(ci[b], sym[b].astype(np.int16))
+        got = bytes(by[b, :int(nb[b])].cpu().numpy())
+        assert got == want                                       # byte-identical to the oracle coder
+        assert np.array_equal(cport.range_decode(ci[b], got), sym[b])
+        tot_ideal += -np.log2(pmf[b][np.arange(S * d), sym[b]]).sum() / 8
+    assert abs(int(nb.sum()) - tot_ideal) <= 0.01 * tot_ideal + 2 * B
