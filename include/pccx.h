@@ -148,6 +148,15 @@ PCCX_API int pccx_ae_encode(const float *patches, int P, int K, const float *enc
                             float *feat_ws, float *latent_raw, float *latent, float *latent_q,
                             void *stream);
 
+/* The two halves of pccx_ae_encode, as the reference calls them (compress.py:114 ae.sa,
+ * compress.py:121 ae.pn).  feat: (P,8,K,16) f32 = the (P,128,K) SetAbstraction feature map with
+ * channels grouped by 16 (feat[p][c/16][i][c%16]), the layout pccx_pn_forward consumes. */
+PCCX_API int pccx_sa_forward(const float *patches, int P, int K, const float *enc_blob, float *feat,
+                             void *stream);
+PCCX_API int pccx_pn_forward(const float *patches, const float *feat, int P, int K,
+                             const float *enc_blob, int d, int L, float *latent_raw, float *latent,
+                             float *latent_q, void *stream);
+
 PCCX_API size_t pccx_ae_decode_workspace_floats(int P);
 /* Synthesis transform (AE.py:48-53 = decompress.py:97-102) and, optionally, the reassembly of
  * decompress.py:104-116.  latent_q: (P,d) f32; workspace: pccx_ae_decode_workspace_floats(P).

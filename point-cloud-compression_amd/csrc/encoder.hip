@@ -223,14 +223,8 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
     }
 }
 
-extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *enc_blob, int d, int L, float *feat_ws,
-                              float *latent_raw, float *latent, float *latent_q, void *stream)
+static int launch_sa(const float *patches, int P, int K, const float *enc_blob, float *feat, hipStream_t st)
 {
-    PCCX_CHECK_ARG(patches && enc_blob && feat_ws && latent_raw && latent && latent_q, "pccx_ae_encode: null pointer");
-    PCCX_CHECK_ARG(P >= 0 && K >= 16 && K <= 1024 && K % 16 == 0, "pccx_ae_encode: need K %% 16 == 0, 16 <= K <= 1024 (K=%d)", K);
-    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode: unsupported d=%d L=%d", d, L);
-    if (P == 0) return PCCX_OK;
-    hipStream_t st = (hipStream_t)stream;
     const size_t sa_lds = (size_t)(2 * 4 * 64 + 4 * 8 * 64) * 16 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32;
     static bool attr_set = false;
     if (!attr_set) {
@@ -238,12 +232,51 @@ extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *e
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(sa_forward_kernel, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, feat_ws);
+    hipLaunchKernelGGL(sa_forward_kernel, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, feat);
     PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+static int launch_pn(const float *patches, const float *feat, int P, int K, const float *enc_blob, int d, int L,
+                     float *latent_raw, float *latent, float *latent_q, hipStream_t st)
+{
     const float spread = (float)((double)L - 0.2);
     const float half = (float)(((double)L - 0.2) / 2);
-    hipLaunchKernelGGL(pn_forward_kernel<1>, dim3(P), dim3(256), 0, st, patches, feat_ws, K, enc_blob, d, spread, half,
+    hipLaunchKernelGGL(pn_forward_kernel<1>, dim3(P), dim3(256), 0, st, patches, feat, K, enc_blob, d, spread, half,
                        latent_raw, latent, latent_q);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
+}
+
+#define CHECK_PK(fn)                                                                                              \
+    PCCX_CHECK_ARG(P >= 0 && K >= 16 && K <= 1024 && K % 16 == 0, fn ": need K %% 16 == 0, 16 <= K <= 1024 (K=%d)", K)
+
+extern "C" int pccx_sa_forward(const float *patches, int P, int K, const float *enc_blob, float *feat, void *stream)
+{
+    PCCX_CHECK_ARG(patches && enc_blob && feat, "pccx_sa_forward: null pointer");
+    CHECK_PK("pccx_sa_forward");
+    if (P == 0) return PCCX_OK;
+    return launch_sa(patches, P, K, enc_blob, feat, (hipStream_t)stream);
+}
+
+extern "C" int pccx_pn_forward(const float *patches, const float *feat, int P, int K, const float *enc_blob, int d, int L,
+                               float *latent_raw, float *latent, float *latent_q, void *stream)
+{
+    PCCX_CHECK_ARG(patches && feat && enc_blob && latent_raw && latent && latent_q, "pccx_pn_forward: null pointer");
+    CHECK_PK("pccx_pn_forward");
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_pn_forward: unsupported d=%d L=%d", d, L);
+    if (P == 0) return PCCX_OK;
+    return launch_pn(patches, feat, P, K, enc_blob, d, L, latent_raw, latent, latent_q, (hipStream_t)stream);
+}
+
+extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *enc_blob, int d, int L, float *feat_ws,
+                              float *latent_raw, float *latent, float *latent_q, void *stream)
+{
+    PCCX_CHECK_ARG(patches && enc_blob && feat_ws && latent_raw && latent && latent_q, "pccx_ae_encode: null pointer");
+    CHECK_PK("pccx_ae_encode");
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode: unsupported d=%d L=%d", d, L);
+    if (P == 0) return PCCX_OK;
+    int rc = launch_sa(patches, P, K, enc_blob, feat_ws, (hipStream_t)stream);
+    if (rc != PCCX_OK) return rc;
+    return launch_pn(patches, feat_ws, P, K, enc_blob, d, L, latent_raw, latent, latent_q, (hipStream_t)stream);
 }

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "pccx_prob_blob_floats": [],
     "pccx_pack_prob": [_P] * 12 + [C.c_int, C.c_int, _P],
     "pccx_ae_encode": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "pccx_sa_forward": [_P, C.c_int, C.c_int, _P, _P, _P],
+    "pccx_pn_forward": [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P],
     "pccx_ae_decode_workspace_floats": [C.c_int],
     "pccx_ae_decode": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_double, _P, _P],
     "pccx_prob_forward": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
@@ -55,6 +57,9 @@ def load():
             raise PccxError(
                 f"{LIB_PATH} not found: build the HIP library first (python -m pccx.build). "
                 "pccx has no CPU fallback.")
+        # torch first: its bundled HIP runtime must be the one (and only) libamdhip64 in the process,
+        # so that libpccx's kernels and torch's allocator / streams share devices and contexts.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.pccx_last_error.restype = C.c_char_p
         lib.pccx_last_error.argtypes = []

@@ -1,0 +1,125 @@
+"""Batched compress / decompress pipeline: the loop bodies of compress.py:90-152 and
+decompress.py:80-116 for B clouds per launch sequence, everything resident in HBM.
+
+The reference processes one cloud at a time (B = 1, compress.py:48) with 128 per-patch module
+calls and several host round trips per cloud; here each stage is one kernel launch over the whole
+batch and nothing returns to the host until the caller asks for the byte streams.
+
+Stream formats are the reference's: ``.s.bin`` = packed octree bits (tail byte
+right-aligned), ``.p.bin`` = range-coder bytes of the S*d latent symbols, ``.c.bin`` = 4 x fp32
+[cx, cy, cz, longest].
+"""
+import dataclasses
+
+import numpy as np
+import torch
+
+from . import models, ops
+from .ops import stage
+
+
+@dataclasses.dataclass
+class Compressed:
+    s_bytes: torch.Tensor     # (B, stride) u8  packed octree streams
+    s_nbytes: torch.Tensor    # (B) i32
+    p_bytes: torch.Tensor     # (B, cap) u8     range-coded latents
+    p_nbytes: torch.Tensor    # (B) i32
+    c: torch.Tensor           # (B, 4) f32      centre xyz + longest side
+    n_points: int
+    extras: dict = None       # intermediates for tests / diagnostics
+
+    def bits(self):
+        """Total bits per cloud of the three files (eval.py:189 numerator)."""
+        return 8 * (self.s_nbytes.long() + self.p_nbytes.long() + 16)
+
+    def bpp(self):
+        return self.bits().double() / self.n_points
+
+    def files(self, b):
+        """The three byte strings compress.py:139-152 writes for cloud b."""
+        s = bytes(self.s_bytes[b, :int(self.s_nbytes[b])].cpu().numpy())
+        p = bytes(self.p_bytes[b, :int(self.p_nbytes[b])].cpu().numpy())
+        c = self.c[b].cpu().numpy().astype(np.float32).tobytes()
+        return s, p, c
+
+
+class Codec:
+    def __init__(self, ae, prob, K=256, ALPHA=2, N0=1024, octree_mode="reference", margin=0.01):
+        self.ae, self.prob = ae, prob
+        self.K, self.ALPHA, self.N0 = K, ALPHA, N0
+        self.k = K // ALPHA                                  # compress.py:46
+        self.octree_mode = octree_mode
+        self.margin = margin
+        if ae.K != K or ae.k != self.k:
+            raise ValueError("AE was built for a different K / k")
+
+    def compress(self, pc, start_idx, keep_extras=False):
+        """pc (B,N,3) f32 on the GPU; start_idx (B,) FPS start per cloud (the reference draws it
+        from torch.randint, pn_kit.py:321)."""
+        B, N, _ = pc.shape
+        d, L = self.ae.d, self.ae.L
+        with stage("normalize"):
+            pcn, center, longest = ops.normalize(pc, self.margin)                    # compress.py:90
+        S = int(N * self.ALPHA // self.K)                                            # compress.py:93
+        if self.octree_mode == "reference" and S != 64:
+            raise ValueError(f"octree_mode='reference' reproduces octree_np.decode's hard-coded S=64 "
+                             f"(octree_np.py:100; compress.py:102 asserts); got S={S}. Use octree_mode='full'.")
+        with stage("fps"):
+            fps_idx = ops.farthest_point_sample_batch(pcn, S, start_idx)             # compress.py:96
+        with stage("gather"):
+            sampled = ops.index_points(pcn, fps_idx)
+        with stage("octree_encode"):
+            oc = ops.octree_encode(sampled, N, ops.OCTREE_BPP_DICT[self.K])          # compress.py:98
+        with stage("octree_decode"):
+            rec, _ = ops.octree_decode(oc["bytes"], oc["nbytes"], self.octree_mode, S)   # compress.py:100
+        scale = float((N / self.N0) ** (1 / 3))
+        with stage("knn_patches"):
+            nn = ops.knn_points(rec, pcn, self.K, patch_scale=scale)                 # compress.py:105-108
+        patches = nn.knn.view(B * S, self.K, 3)
+        raw, latent, q = self.ae.encode(patches)                                     # compress.py:113-127
+        with stage("prob"):
+            cdf_int = self.prob.run(rec, ("cdf_int",))["cdf_int"]                    # compress.py:131-134
+        with stage("range_encode"):
+            p_bytes, p_nbytes = models.range_encode(cdf_int, q.view(B, S * d), L)    # compress.py:135-136
+        c = torch.cat([center, longest[:, None]], dim=1)                             # compress.py:149-152
+        extras = None
+        if keep_extras:
+            extras = dict(pcn=pcn, fps_idx=fps_idx, sampled=sampled, octree=oc, rec_sampled=rec, patches=patches,
+                          latent_raw=raw, latent=latent, latent_q=q, cdf_int=cdf_int, knn_idx=nn.idx)
+        return Compressed(oc["bytes"], oc["nbytes"], p_bytes, p_nbytes, c, N, extras)
+
+    def decompress(self, comp, S=64):
+        """Inverse pipeline (decompress.py:80-116) -> (B, S*k, 3) f32."""
+        B = comp.s_bytes.shape[0]
+        d, L = self.ae.d, self.ae.L
+        with stage("octree_decode"):
+            rec, cnt = ops.octree_decode(comp.s_bytes, comp.s_nbytes, self.octree_mode, S)    # decompress.py:80-85
+        with stage("prob"):
+            cdf_int = self.prob.run(rec, ("cdf_int",))["cdf_int"]                         # decompress.py:88-92
+        with stage("range_decode"):
+            q = models.range_decode(cdf_int, comp.p_bytes, comp.p_nbytes, L)              # decompress.py:93
+        N = S * self.k                                                                    # decompress.py:106
+        scale = float((N / self.N0) ** (1 / 3))
+        with stage("ae_decode"):
+            return self.ae.decode(q.view(B * S, d), rec.view(B * S, 3), comp.c[:, :3].contiguous(),
+                                  comp.c[:, 3].contiguous(), S=S, scale=scale, margin=self.margin)
+
+
+def d1_psnr(orig, recon):
+    """eval.py:43-98 D1 (point-to-point) PSNR, batched: 10*log10(diag^2 / mean_recon min_orig |.|^2),
+    diag = bounding-box diagonal of the original.  (B,N,3),(B,M,3) -> (B,) f64."""
+    d2 = ops.nn_dist(recon, orig).double()
+    mse = d2.mean(dim=1)
+    rng = orig.amax(dim=1).double() - orig.amin(dim=1).double()
+    diag2 = (rng * rng).sum(dim=1)
+    return 10 * torch.log10(diag2 / mse)
+
+
+def normalized_chamfer(orig, recon):
+    """eval.py:198-205: both clouds min-max normalised by the ORIGINAL's global min/max, then
+    pytorch3d chamfer_distance.  Returns (B,) f64."""
+    lo = orig.amin(dim=(1, 2), keepdim=True)
+    hi = orig.amax(dim=(1, 2), keepdim=True)
+    a = ((orig - lo) / (hi - lo)).contiguous()
+    b = ((recon - lo) / (hi - lo)).contiguous()
+    return ops.nn_dist(b, a).double().mean(dim=1) + ops.nn_dist(a, b).double().mean(dim=1)

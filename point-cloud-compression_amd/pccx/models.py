@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import _stream, _f32c
+from .ops import _stream, _f32c, stage
 
 
 def _conv_stack(chans, relu):
@@ -117,8 +117,11 @@ class AE(nn.Module):
         enc, _ = self._blobs(x.device)
         ws = torch.empty(P * K * 128, device=x.device, dtype=torch.float32)
         outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
-        _lib.call("pccx_ae_encode", x.data_ptr(), P, K, enc.data_ptr(), self.d, self.L, ws.data_ptr(),
-                  outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+        with stage("sa_forward"):
+            _lib.call("pccx_sa_forward", x.data_ptr(), P, K, enc.data_ptr(), ws.data_ptr(), _stream())
+        with stage("pn_forward"):
+            _lib.call("pccx_pn_forward", x.data_ptr(), ws.data_ptr(), P, K, enc.data_ptr(), self.d, self.L,
+                      outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
         return tuple(outs)
 
     def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01):

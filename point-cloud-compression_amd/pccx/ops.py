@@ -17,6 +17,47 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class StageTimer:
+    """Optional per-stage HIP-event timing (bench.py).  Events are recorded on torch's current
+    stream, the stream every pccx kernel is launched on."""
+
+    def __init__(self):
+        self.records = []
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.records:
+            t, n = out.get(name, (0.0, 0))
+            out[name] = (t + a.elapsed_time(b), n + 1)
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class stage:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timer is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _timer.records.append((self.name, self.a, b))
+        return False
+
+
 def _dev(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.PccxError(f"{name}: expected a tensor on the GPU (pccx has no CPU fallback)")

@@ -1,0 +1,110 @@
+"""GPU parity, end to end: Codec.compress / decompress (batched HIP path through the C ABI) against
+the reference-structured CPU oracle (oracle/ref_pipeline.py) on the same seeded clouds and weights.
+
+Bars: FPS indices, octree bits / .s.bin bytes, decoded centres, kNN indices and patches are
+bit-identical; latents within 5e-5 with symbol flips only at rounding boundaries; reconstructed
+XYZ within 2e-5 (absolute, unit-cube scale) when fed the same symbols; D1-PSNR within 0.01 dB.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cport, ref_model, ref_pipeline
+from pccx import codec, models, synth as cloud_synth
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+K, k, d, L = synth.MODEL_CFG
+
+
+@pytest.fixture(scope="module")
+def nets():
+    ae = models.AE(K, k, d, L)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    prob = models.ConditionalProbabilityModel(L, d)
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, synth.PROB_SEED, gain=synth.PROB_GAIN))
+    oae = ref_model.AE(K, k, d, L).eval()
+    oae.load_state_dict(ae.state_dict())
+    oprob = ref_model.ConditionalProbabilityModel(L, d).eval()
+    oprob.load_state_dict(prob.state_dict())
+    return ae.pack("cuda"), prob.pack("cuda"), oae, oprob
+
+
+@pytest.mark.parametrize("mode", ["reference", "full"])
+def test_compress_decompress_vs_oracle(nets, mode):
+    ae, prob, oae, oprob = nets
+    B = 3
+    clouds = cloud_synth.cad_batch(11, B, 8192) * np.float32(2.5) - np.float32(0.7)   # not pre-normalised
+    starts = np.array([5, 4000, 8191])
+    cd = codec.Codec(ae, prob, K=K, octree_mode=mode)
+    comp = cd.compress(torch.from_numpy(clouds).cuda(), starts, keep_extras=True)
+    out = cd.decompress(comp)
+    ex = comp.extras
+    torch.set_num_threads(8)
+    for b in range(B):
+        o, _ = ref_pipeline.compress_one(clouds[b], oae, oprob, int(starts[b]), K=K, octree_mode=mode)
+        s, p, c = comp.files(b)
+        assert np.array_equal(ex["pcn"][b].cpu().numpy(), o["pcn"])
+        assert np.array_equal(ex["fps_idx"][b].cpu().numpy(), o["fps_idx"])
+        assert s == o["s"] and c == o["c"]                                    # .s.bin / .c.bin bit-identical
+        nb = int(ex["octree"]["nbits"][b])
+        assert np.array_equal(ex["octree"]["bits"][b, :nb].cpu().numpy(), o["bits"])
+        assert np.array_equal(ex["rec_sampled"][b].cpu().numpy(), o["rec_sampled"])
+        assert np.array_equal(ex["knn_idx"][b].cpu().numpy(), o["knn_idx"])
+        assert np.array_equal(ex["patches"].view(B, 64, K, 3)[b].cpu().numpy(), o["patches"])
+        lat = ex["latent"].view(B, 64, d)[b].cpu().numpy()
+        q = ex["latent_q"].view(B, 64, d)[b].cpu().numpy()
+        np.testing.assert_allclose(lat, o["latent"], rtol=0, atol=5e-5)
+        bad = q != o["latent_q"]
+        assert (np.abs(o["latent"][bad] - np.floor(o["latent"][bad]) - 0.5) < 1e-4).all()
+        # integer CDFs: +-1 count at most; the GPU stream decodes losslessly with the GPU CDF by the oracle coder
+        ci = ex["cdf_int"][b].cpu().numpy().reshape(-1, L + 1)
+        diff = ((ci.astype(np.int64) - o["cdf_int"].astype(np.int64) + 32768) % 65536) - 32768
+        assert np.abs(diff).max() <= 1
+        sym = cport.range_decode(ci, p)
+        assert np.array_equal(sym.astype(np.float32) - L // 2, q.reshape(-1))
+        if not bad.any() and np.array_equal(ci, o["cdf_int"]):
+            assert p == o["p"]                                                # .p.bin byte-identical
+        # decompress: same symbols in -> same cloud out
+        want, _ = ref_pipeline.decompress_one(s, p, c, oae, oprob, octree_mode=mode, latent_q_override=q.copy())
+        got = out[b].cpu().numpy()
+        assert got.shape == want.shape == (64 * k, 3)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * float(comp.c[b, 3]))
+        psnr_gpu = float(codec.d1_psnr(torch.from_numpy(clouds[b:b + 1]).cuda(), out[b:b + 1])[0])
+        assert abs(psnr_gpu - ref_pipeline.d1_psnr(clouds[b], want)) < 0.01
+
+
+def test_round_trip_properties_at_batch_scale(nets):
+    """Size-independent properties at a batch the oracle could not finish in seconds."""
+    ae, prob, _, _ = nets
+    B = 48
+    clouds = torch.from_numpy(cloud_synth.cad_batch(100, B, 8192)).cuda()
+    starts = np.arange(B) * 97 % 8192
+    for mode in ("reference", "full"):
+        cd = codec.Codec(ae, prob, K=K, octree_mode=mode)
+        comp = cd.compress(clouds, starts, keep_extras=True)
+        # the decoder recovers exactly the symbols the encoder produced (range coder + identical CDFs)
+        rec, _ = codec.ops.octree_decode(comp.s_bytes, comp.s_nbytes, mode, 64)
+        assert torch.equal(rec, comp.extras["rec_sampled"])
+        cdf_int = prob.run(rec, ("cdf_int",))["cdf_int"]
+        assert torch.equal(cdf_int, comp.extras["cdf_int"])
+        q = models.range_decode(cdf_int, comp.p_bytes, comp.p_nbytes, L)
+        assert torch.equal(q.view(-1, d), comp.extras["latent_q"])
+        out = cd.decompress(comp)
+        assert out.shape == (B, 64 * k, 3) and torch.isfinite(out).all()
+        # compress is a pure function of (cloud, start): batch composition must not matter
+        comp1 = cd.compress(clouds[7:8], starts[7:8])
+        assert comp.files(7) == comp1.files(0)
+        bpp = comp.bpp().cpu().numpy()
+        assert (bpp > 0.3).all() and (bpp < 1.5).all()
+        if mode == "full":
+            # 64 distinct centres: the patches cover the cloud, D1-PSNR is finite and sane
+            psnr = codec.d1_psnr(clouds, out).cpu().numpy()
+            assert np.isfinite(psnr).all()
+
+
+def test_reference_mode_rejects_other_S(nets):
+    ae, prob, _, _ = nets
+    cd = codec.Codec(ae, prob, K=K, octree_mode="reference")
+    with pytest.raises(ValueError):
+        cd.compress(torch.zeros(1, 4096, 3).cuda(), [0])
