@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the file-sharded runner (pccx/dist.py).
+The per-file work is replaced by a deterministic function of the file index (no GPU here); what is
+tested is the partition, the sharding-independent FPS start and the summary exchange."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pccx import dist as pdist
+
+
+def _fake_file_result(i):
+    """(bits, points, psnr, chamfer) of file i."""
+    start = pdist.fps_start_index(11, i, 8192)
+    return 5000 + 7 * i + start % 13, 8192, 30.0 + 0.1 * i, 1e-4 * (i + 1)
+
+
+def _local_summary(idx, seconds):
+    r = np.array([_fake_file_result(i) for i in idx], dtype=np.float64).reshape(-1, 4)
+    return [r[:, 0].sum(), r[:, 1].sum(), r[:, 2].sum(), r[:, 3].sum(), float(len(idx)), seconds]
+
+
+def _worker(rank, world, port, n_files, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = pdist.shard_indices(n_files, rank, world)
+    g = pdist.gather_summaries(_local_summary(idx, 1.0 + rank))
+    tmax = pdist.max_over_ranks(1.0 + rank)
+    q.put((rank, idx, pdist.reduce_summaries(g), tmax))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    n_files, world = 37, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_files, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owned = sorted(i for _, idx, _, _ in res for i in idx)
+    assert owned == list(range(n_files))                       # every file exactly once
+    single = pdist.reduce_summaries(torch.tensor([_local_summary(list(range(n_files)), 2.0)], dtype=torch.float64))
+    for _, _, s, tmax in res:
+        assert tmax == 2.0                                     # MAX over ranks
+        assert s["files"] == n_files
+        for k in ("bpp", "d1_psnr_db", "chamfer", "points_per_s"):
+            assert abs(s[k] - single[k]) <= 1e-12 * abs(single[k])
+
+
+def test_fps_start_is_sharding_independent():
+    a = [pdist.fps_start_index(11, i, 8192) for i in range(10)]
+    assert a == [pdist.fps_start_index(11, i, 8192) for i in range(10)]
+    assert len(set(a)) > 5 and all(0 <= v < 8192 for v in a)
+
+
+def test_single_process_fallback_needs_no_process_group():
+    g = pdist.gather_summaries([1, 2, 3, 4, 5, 6])
+    assert g.shape == (1, 6) and pdist.max_over_ranks(3.5) == 3.5
