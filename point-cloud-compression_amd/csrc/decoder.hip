@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     const int g = lane >> 4, n = lane & 15;
     const int p = blockIdx.y;
     const int tile0 = blockIdx.x * 8 + 2 * w;
-    const int MTOT = k * 8;
-    const f32x4 *gw = (const f32x4 *)(blob + DEC_G_W(k));
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * WS_CHUNK * 64];      // 32 KiB ring: 2 k-tiles x 8 m-tiles per chunk
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const WStream ws{blob + DEC_G_W(k) + (size_t)p * DEC_STREAM_CHUNKS * 16 * 256, swt, DEC_STREAM_CHUNKS, lane, wu, false};
+    ws.prologue();
 
     f32x4 acc[2][8];
 #pragma unroll
@@ -68,30 +70,36 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
         acc[0][mt] = b; acc[1][mt] = b;
     }
     const int t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
-    // ---- GEMM over K = 1024 (64 k-tiles), fragments prefetched one k-tile ahead
-    f32x4 a_cur[8], b_cur[2], a_nxt[8], b_nxt[2];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) a_cur[mt] = gw[((size_t)0 * MTOT + 8 * p + mt) * 64 + lane];
+    // ---- GEMM over K = 1024 (64 k-tiles).  A (weights of point p, shared by the 4 waves) comes through
+    // the LDS ring one chunk (2 k-tiles) ahead; B (this wave's 2 patch tiles) is prefetched one k-tile
+    // ahead from global.
+    f32x4 b_cur[2], b_nxt[2];
     b_cur[0] = h2p[((size_t)0 * ntiles + t0) * 64 + lane];
     b_cur[1] = h2p[((size_t)0 * ntiles + t1) * 64 + lane];
 #pragma unroll 1
-    for (int kt = 0; kt < 64; ++kt) {
-        const int kn = kt + 1 < 64 ? kt + 1 : 63;
+    for (int c = 0; c < 32; ++c) {
+        ws.boundary(c);
+        const f32x4 *buf = swt + (c & 1) * WS_CHUNK * 64 + lane;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) a_nxt[mt] = gw[((size_t)kn * MTOT + 8 * p + mt) * 64 + lane];
-        b_nxt[0] = h2p[((size_t)kn * ntiles + t0) * 64 + lane];
-        b_nxt[1] = h2p[((size_t)kn * ntiles + t1) * 64 + lane];
+        for (int h = 0; h < 2; ++h) {
+            const int kt = 2 * c + h;
+            const int kn = kt + 1 < 64 ? kt + 1 : 63;
+            b_nxt[0] = h2p[((size_t)kn * ntiles + t0) * 64 + lane];
+            b_nxt[1] = h2p[((size_t)kn * ntiles + t1) * 64 + lane];
+            f32x4 a[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int mt = 0; mt < 8; ++mt) a[mt] = buf[(h * 8 + mt) * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                acc[0][mt] = mfma16(a_cur[mt][r], b_cur[0][r], acc[0][mt]);
-                acc[1][mt] = mfma16(a_cur[mt][r], b_cur[1][r], acc[1][mt]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) a_cur[mt] = a_nxt[mt];
-        b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+                for (int mt = 0; mt < 8; ++mt) {
+                    acc[0][mt] = mfma16(a[mt][r], b_cur[0][r], acc[0][mt]);
+                    acc[1][mt] = mfma16(a[mt][r], b_cur[1][r], acc[1][mt]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+        }
     }
     // ---- inv_mlp on registers: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent
     f32x4 in[2][9];
@@ -109,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(blob + DEC_M_B0 + 16 * mt + 4 * g);
-    dense_acc<9, 8, 2, 8>((const f32x4 *)(blob + DEC_M_W0), lane, in, m0);
+    int f = DEC_STREAM_GEMM_FRAGS;                    // the inv_mlp fragments follow in the same LDS ring
+    dense_acc_stream<9, 8, 2>(ws, f, in, m0);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(blob + DEC_M_B1 + 16 * mt + 4 * g);
-    dense_acc<8, 4, 2, 4>((const f32x4 *)(blob + DEC_M_W1), lane, m0, m1);
+    dense_acc_stream<8, 4, 2>(ws, f, m0, m1);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(blob + DEC_M_B2 + 16 * mt + 4 * g);
-    dense_acc<4, 2, 2, 2>((const f32x4 *)(blob + DEC_M_W2), lane, m1, m2);
+    dense_acc_stream<4, 2, 2>(ws, f, m1, m2);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -137,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     f32x4 m3[2][1];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(blob + DEC_M_B3 + 4 * g);
-    dense_acc<2, 1, 2, 1>((const f32x4 *)(blob + DEC_M_W3), lane, m2, m3);   // last layer: no ReLU (AE.py:27)
+    dense_acc_stream<2, 1, 2>(ws, f, m2, m3);          // last layer: no ReLU (AE.py:27)
+    ws.drain();
 
     // ---- epilogue: rows 0..2 of the last tile (g == 0, r = 0..2) are x,y,z of (patch, point p)
     if (g == 0) {

@@ -51,102 +51,118 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
     }
     __syncthreads();
 
-    // ---- phase 1: kNN-16 inside the patch (pn_kit.py:190, K=16)
+    // ---- phase 1: kNN-16 inside the patch (pn_kit.py:190, K=16).  Only the SET matters (max-pool),
+    // so pass 1 keeps just the 16 smallest distances sorted (one v_med3 per slot per candidate) and
+    // pass 2 collects the indices below the 16th distance, plus ties at it in index order -- the
+    // same set as the oracle's (distance, index) sort.
     for (int i = tid; i < K; i += 256) {
         const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
         float td[16];
-        int ti[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { td[s] = INFINITY; ti[s] = 0; }
+        for (int s = 0; s < 16; ++s) td[s] = INFINITY;
         for (int j = 0; j < K; ++j) {
             const float d = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
-            if (d < td[15]) {
-                // sorted insert AFTER any equal keys: candidates arrive in index order, so the list
-                // stays ordered by (distance, index), the oracle's orc_knn order.
 #pragma unroll
-                for (int s = 15; s >= 1; --s) {
-                    const bool shift = d < td[s - 1];
-                    const bool here = d < td[s];
-                    td[s] = shift ? td[s - 1] : (here ? d : td[s]);
-                    ti[s] = shift ? ti[s - 1] : (here ? j : ti[s]);
-                }
-                if (d < td[0]) { td[0] = d; ti[0] = j; }
-            }
+            for (int s = 15; s >= 1; --s) td[s] = __builtin_amdgcn_fmed3f(td[s - 1], d, td[s]);
+            td[0] = fminf(td[0], d);
         }
+        const float T = td[15];
+        int need = 16;                                   // ties at T to take = 16 - #(d < T)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)ti[s];
+        for (int s = 0; s < 16; ++s) need -= td[s] < T ? 1 : 0;
+        int c = 0, ties = 0;
+        for (int j = 0; j < K; ++j) {
+            const float d = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
+            const bool tie = d == T;
+            if (d < T || (tie && ties < need)) {
+                if (c < 16) nbr16[i * 16 + c] = (unsigned short)j;
+                ++c;
+            }
+            ties += tie ? 1 : 0;
+        }
     }
     __syncthreads();
 
-    // per-lane first-layer weights: channels c = 16*kt + 4*g + r, kt in {0,1}
-    f32x4 w0[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w0[kt][r] = *(const f32x4 *)(blob + ENC_SA_W0B0 + 4 * (16 * kt + 4 * g + r));
+    // conv0 (3 -> 32) also runs on the matrix core: one K=4 MFMA per 16 output channels with the bias
+    // folded in as a fourth input of 1.0.  A = [w0 w1 w2 b] of channel 16*kt + (lane&15) at k = lane>>4;
+    // B = coordinate (lane>>4) of neighbour (lane&15).
+    const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    const int per_wave = (K + 3) / 4;
-    for (int i = w * per_wave; i < (w + 1) * per_wave && i < K; ++i) {
-        const int j = nbr16[i * 16 + n];
-        const float rx = __fsub_rn(sx[3 * j], sx[3 * i]);          // grouped_xyz -= new_xyz (pn_kit.py:191)
-        const float ry = __fsub_rn(sx[3 * j + 1], sx[3 * i + 1]);
-        const float rz = __fsub_rn(sx[3 * j + 2], sx[3 * i + 2]);
-        f32x4 h0[1][2];
+    // Two points per iteration (K % 16 == 0, so every wave owns an even count): the weight fragments read
+    // from LDS feed both points' MFMA tiles and the two dependency chains interleave.
+    const int per_wave = K / 4;
+    for (int i0 = w * per_wave; i0 < (w + 1) * per_wave; i0 += 2) {
+        f32x4 h0[2][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int i = i0 + nt;
+            const int j = nbr16[i * 16 + n];
+            // grouped_xyz -= new_xyz (pn_kit.py:191): this lane's coordinate g of neighbour n, or the bias input
+            const float rel = g < 3 ? __fsub_rn(sx[3 * j + g], sx[3 * i + g]) : 1.0f;
+            h0[nt][0] = relu4(mfma16(w0a, rel, zero4));                              // relu(conv0)
+            h0[nt][1] = relu4(mfma16(w0b, rel, zero4));
+        }
+        f32x4 a1[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x4 wv = w0[kt][r];
-                h0[0][kt][r] = fmaxf(fmaf(wv[2], rz, fmaf(wv[1], ry, fmaf(wv[0], rx, wv[3]))), 0.f);   // relu(conv0)
-            }
-        f32x4 a1[1][4];
+        for (int mt = 0; mt < 4; ++mt) a1[0][mt] = a1[1][mt] = *(const f32x4 *)(sb1 + 16 * mt + 4 * g);
+        dense_acc<2, 4, 2, 4>(sw1, lane, h0, a1);                                    // conv1
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a1[0][mt] = *(const f32x4 *)(sb1 + 16 * mt + 4 * g);
-        dense_acc<2, 4, 1, 4>(sw1, lane, h0, a1);                                   // conv1
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a1[0][mt] = relu4(a1[0][mt]);
-        f32x4 a2[1][8];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) a2[0][mt] = *(const f32x4 *)(sb2 + 16 * mt + 4 * g);
-        dense_acc<4, 8, 1, 8>(sw2, lane, a1, a2);                                   // conv2
-        // relu then max over the 16 neighbours (pn_kit.py:204-207) == max then relu
+            for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = relu4(a1[nt][mt]);
+        // conv2 transposed (points x channels): bias of channel 16*mt + n in every register
+        f32x4 a2[2][8];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
-            f32x4 v;
+            const float bv = sb2[16 * mt + n];
+            f32x4 b4 = {bv, bv, bv, bv};
+            a2[0][mt] = b4; a2[1][mt] = b4;
+        }
+        dense_acc<4, 8, 2, 8, true>(sw2, lane, a1, a2);                              // conv2
+        // relu then max over the 16 neighbours (pn_kit.py:204-207) == max then relu
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(row16_max(a2[0][mt][r]), 0.f);
-            if (n == 0) *(f32x4 *)(feat + ((P * 8 + mt) * (size_t)K + i) * 16 + 4 * g) = v;
+        for (int nt = 0; nt < 2; ++nt) {
+            float mx[2];
+            max16_of_8_transposed_tiles(a2[nt], mx);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)   // lane (row g, j = n) holds channel 16*(2g + s2) + n
+                feat[((P * 8 + (2 * g + s2)) * (size_t)K + i0 + nt) * 16 + n] = fmaxf(mx[s2], 0.f);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// PointNet + quantiser.  Workgroup = one patch, 4 waves; a wave walks point tiles of 16 (NT at a
-// time), keeps a running per-channel max, and the 4 waves combine through LDS.  Layers 2 and 3
-// are interleaved two output tiles at a time so the 512-channel activation never materialises.
-// Weights stream from L2 as packed fragments (1 KiB contiguous per wave-load).
+// PointNet + quantiser.  Workgroup = one patch, 4 waves; a wave walks point tiles of 16, keeps a
+// running per-channel max, and the 4 waves combine through LDS.  Layers 2 and 3 are interleaved
+// two output tiles at a time so the 512-channel activation never materialises.  All four waves
+// consume the same 744-fragment weight sequence per tile, so it is streamed L2 -> LDS once per
+// workgroup by LDS-DMA one chunk ahead of the MFMAs (WStream, mfma_chain.h).
 // ------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restrict__ x, const float *__restrict__ feat, int K,
-                                                         const float *__restrict__ blob, int d, float spread,
-                                                         float half_spread, float *__restrict__ latent_raw,
-                                                         float *__restrict__ latent, float *__restrict__ latent_q)
+                                                            const float *__restrict__ blob, int d, float spread,
+                                                            float half_spread, float *__restrict__ latent_raw,
+                                                            float *__restrict__ latent, float *__restrict__ latent_q)
 {
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * WS_CHUNK * 64];      // 32 KiB weight ring
     __shared__ float smax[4][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     const size_t P = blockIdx.x;
     const float *xp = x + P * (size_t)K * 3;
     const int ntiles = K >> 4;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    WStream ws{blob + ENC_PN_STREAM, swt, ENC_PN_STREAM_CHUNKS, lane, wu, true};
+    ws.prologue();
 
     f32x4 run;                                            // running max, channel 4g+r
     run[0] = run[1] = run[2] = run[3] = -INFINITY;
-    for (int t0 = w * NT; t0 < ntiles; t0 += 4 * NT) {
-        blob = opaque_uniform(blob);
-        const f32x4 *w0 = (const f32x4 *)(blob + ENC_PN_W0);
-        const f32x4 *w1 = (const f32x4 *)(blob + ENC_PN_W1);
-        const f32x4 *w2 = (const f32x4 *)(blob + ENC_PN_W2);
-        const f32x4 *w3 = (const f32x4 *)(blob + ENC_PN_W3);
+    const int passes = (ntiles + 4 * NT - 1) / (4 * NT);  // identical for all waves: barriers inside
+    for (int it = 0; it < passes; ++it) {
+        const int t0 = (it * 4 + w) * NT;
+        blob = opaque_uniform(blob);                      // keep weight / bias addressing inside the pass (no LICM)
+        ws.g = blob + ENC_PN_STREAM;
         f32x4 in[NT][9];
         bool valid[NT];
 #pragma unroll
@@ -163,12 +179,13 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
             xyz[3] = 0.f;
             in[nt][8] = xyz;
         }
+        int f = 0;                                        // fragment cursor of this pass (constant-folds)
         f32x4 a0[NT][8];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) a0[nt][mt] = *(const f32x4 *)(blob + ENC_PN_B0 + 16 * mt + 4 * g);
-        dense_acc<9, 8, NT, 8>(w0, lane, in, a0);
+        dense_acc_stream<9, 8, NT>(ws, f, in, a0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) a1[nt][mt] = *(const f32x4 *)(blob + ENC_PN_B1 + 16 * mt + 4 * g);
-        dense_acc<8, 16, NT, 16>(w1, lane, a0, a1);
+        dense_acc_stream<8, 16, NT>(ws, f, a0, a1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -188,26 +205,28 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
         f32x4 a3[NT][1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) a3[nt][0] = *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int mp = 0; mp < 16; ++mp) {                 // pairs of layer-2 output tiles
             f32x4 a2[NT][2];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) a2[nt][m] = *(const f32x4 *)(blob + ENC_PN_B2 + 16 * (2 * mp + m) + 4 * g);
-            dense_acc<16, 2, NT, 32>(w2, lane, a1, a2, 0, 2 * mp);
+            dense_acc_stream<16, 2, NT>(ws, f, a1, a2);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) a2[nt][m] = relu4(a2[nt][m]);
-            dense_acc<2, 1, NT, 1>(w3, lane, a2, a3, 2 * mp, 0);  // last layer has no ReLU (AE.py:17 relu=[T,T,T,F])
+            dense_acc_stream<2, 1, NT>(ws, f, a2, a3);     // last layer has no ReLU (AE.py:17 relu=[T,T,T,F])
         }
+        ws.boundary(ENC_PN_STREAM_CHUNKS - 1);             // padding chunk: keeps the ring parity; prefetches chunk 0
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             if (valid[nt])
 #pragma unroll
                 for (int r = 0; r < 4; ++r) run[r] = fmaxf(run[r], row16_max(a3[nt][0][r]));
     }
+    ws.drain();                                            // no DMA may land after the workgroup retires
     if (n == 0)
 #pragma unroll
         for (int r = 0; r < 4; ++r) smax[w][4 * g + r] = run[r];
@@ -242,8 +261,14 @@ static int launch_pn(const float *patches, const float *feat, int P, int K, cons
 {
     const float spread = (float)((double)L - 0.2);
     const float half = (float)(((double)L - 0.2) / 2);
-    hipLaunchKernelGGL(pn_forward_kernel<1>, dim3(P), dim3(256), 0, st, patches, feat, K, enc_blob, d, spread, half,
-                       latent_raw, latent, latent_q);
+    // two point tiles per wave per pass (shared weight fragments, 140 vs 123 TFLOP/s) when the tile count
+    // divides evenly over 4 waves x 2; otherwise one.
+    if ((K >> 4) % 8 == 0)
+        hipLaunchKernelGGL(pn_forward_kernel<2>, dim3(P), dim3(256), 0, st, patches, feat, K, enc_blob, d, spread, half,
+                           latent_raw, latent, latent_q);
+    else
+        hipLaunchKernelGGL(pn_forward_kernel<1>, dim3(P), dim3(256), 0, st, patches, feat, K, enc_blob, d, spread, half,
+                           latent_raw, latent, latent_q);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

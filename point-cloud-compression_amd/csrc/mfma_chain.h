@@ -16,6 +16,7 @@
 // so one 16-byte load per lane feeds 4 MFMAs and a wave's load is 1 KiB contiguous.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v)
 // acc[nt][mt] += W[kt0..kt0+KT)[mt0..mt0+MT) * in[nt][kt]   for NT point tiles sharing the A fragments.
 // `w` (wave-uniform, so loads use the scalar-base + lane-offset form) points at fragment (kt=0, mt=0); WMT = number of m-tiles in the
 // packed layer (row stride of the fragment table).
-template <int KT, int MT, int NT, int WMT>
+template <int KT, int MT, int NT, int WMT, bool SWAP = false>
 __device__ __forceinline__ void dense_acc(const f32x4 *__restrict__ w, int lane, const f32x4 (&in)[NT][KT],
                                           f32x4 (&acc)[NT][MT], int kt0 = 0, int mt0 = 0)
 {
@@ -43,31 +44,153 @@ __device__ __forceinline__ void dense_acc(const f32x4 *__restrict__ w, int lane,
     // 32-cycle issue).  The loads of group i+1 are issued ahead of group i's MFMAs and pinned there
     // with sched_barrier: left alone, hipcc hoists every fragment load of the unrolled chain to the
     // top and spills thousands of registers.
+    //
+    // SWAP exchanges the MFMA operands (the A and B lane maps of 16x16x4 are mirror images, so the
+    // same registers serve either way): the tile comes out transposed, D[point][channel], i.e.
+    // lane (g, j) register r holds channel 16*mt + j of point 4*g + r.  Used for a chain's LAST layer
+    // when a max over the 16 points follows: it becomes an in-lane max over 4 registers plus two
+    // cross-row steps instead of a 16-lane reduction per register.
     constexpr int MG = MT >= 4 ? 4 : MT;
     static_assert(MT % MG == 0, "MT must be a multiple of the m-group");
     constexpr int GPK = MT / MG;          // groups per k-tile
     constexpr int NG = KT * GPK;
+    const char *wb = (const char *)w;     // wave-uniform base: loads take the scalar-base + lane-offset form
+    const unsigned voff = (unsigned)lane * 16u;
     f32x4 cur[MG], nxt[MG];
 #pragma unroll
-    for (int m = 0; m < MG; ++m) cur[m] = w[(kt0 * WMT + mt0 + m) * 64 + lane];
+    for (int m = 0; m < MG; ++m) cur[m] = *(const f32x4 *)(wb + (size_t)(kt0 * WMT + mt0 + m) * 1024 + voff);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
         const int kt = gi / GPK, m0 = (gi % GPK) * MG;
         if (gi + 1 < NG) {
             const int kt_n = (gi + 1) / GPK, m0_n = ((gi + 1) % GPK) * MG;
 #pragma unroll
-            for (int m = 0; m < MG; ++m) nxt[m] = w[((kt0 + kt_n) * WMT + mt0 + m0_n + m) * 64 + lane];
+            for (int m = 0; m < MG; ++m)
+                nxt[m] = *(const f32x4 *)(wb + (size_t)((kt0 + kt_n) * WMT + mt0 + m0_n + m) * 1024 + voff);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int m = 0; m < MG; ++m)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][m0 + m] = mfma16(cur[m][r], in[nt][kt][r], acc[nt][m0 + m]);
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? mfma16(in[nt][kt][r], cur[m][r], acc[nt][m0 + m])
+                                           : mfma16(cur[m][r], in[nt][kt][r], acc[nt][m0 + m]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MG; ++m) cur[m] = nxt[m];
     }
+}
+
+// Max over the 16 points of EIGHT transposed tiles (dense_acc<..., SWAP=true> outputs, lane (g, j)
+// register r = channel 16*t + j of point 4*g + r), as a transpose-reduce: in-lane max over the 4
+// registers, then v_permlane32_swap / v_permlane16_swap pair the lane groups so that each swap+max
+// finishes two tiles at once.  Result: out[s] (s = 0,1) in lane (row, j) is the max of channel
+// 16*(2*row + s) + j.  ~30 VALU instead of ~400 for the 16-lane DPP reduction per register.
+__device__ __forceinline__ void max16_of_8_transposed_tiles(const f32x4 (&t)[8], float (&out)[2])
+{
+    float p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = fmaxf(fmaxf(t[i][0], t[i][1]), fmaxf(t[i][2], t[i][3]));
+    float u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // lanes 0-31 finish tile i over rows {0,2},{1,3}; lanes 32-63 tile i+4
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[i]), __float_as_uint(p[i + 4]), false, false);
+        u[i] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {       // row0: tile s, row1: tile s+2, row2: tile s+4, row3: tile s+6
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[s]), __float_as_uint(u[s + 2]), false, false);
+        out[s] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight stream through LDS.  When every wave of a workgroup consumes the SAME fragment sequence
+// (PointNet: each wave runs the whole layer stack on its own 16 points), the sequence is packed on
+// the host in consumption order and streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4, one
+// 1 KiB fragment per wave-instruction, no VGPRs), one 16-fragment chunk ahead of the MFMAs:
+//   * L2 -> CU traffic drops by the number of waves sharing the stream,
+//   * MFMAs read fragments with short, uniform LDS latency instead of exposed L2 latency.
+// Protocol per chunk c (all waves in lock step, ONE barrier per chunk):
+//   s_waitcnt vmcnt(0)   own DMA of chunk c has landed
+//   __syncthreads()      everyone's has, and everyone finished reading chunk c-1's buffer
+//   issue DMA of chunk c+1 into that buffer; run the 64 MFMAs of chunk c.
+// The fragment counter is a plain int that constant-folds after full unrolling, so the chunk hook
+// costs nothing between boundaries.
+// ------------------------------------------------------------------------------------------
+#define WS_CHUNK 16                       // fragments (KiB) per chunk
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+
+struct WStream {
+    const float *g;                       // global stream, NCH * WS_CHUNK fragments, wave-uniform
+    f32x4 *lds;                           // [2][WS_CHUNK][64]
+    int nch;                              // chunks per pass (even)
+    int lane, wave;
+    bool wrap;                            // several passes over the same stream
+
+    __device__ __forceinline__ void issue(int c, int buf) const
+    {
+        // 4 waves x 4 fragments: wave w moves fragments 4w .. 4w+3 of the chunk.  Source address =
+        // wave-uniform fragment base (scalar registers) + lane*16 (one VGPR shared by every DMA).
+        const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int q = 0; q < WS_CHUNK / 4; ++q) {
+            const int fr = wave * (WS_CHUNK / 4) + q;                // wave is scalar (readfirstlane)
+            const char *src = (const char *)g + ((size_t)c * WS_CHUNK + fr) * 1024;
+            f32x4 *dst = lds + (buf * WS_CHUNK + fr) * 64;          // wave-uniform; hardware adds lane*16
+            __builtin_amdgcn_global_load_lds((const void *)(src + voff), (lds_u32 *)(uintptr_t)dst, 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void prologue() const { issue(0, 0); }
+    __device__ __forceinline__ void boundary(int c) const     // before the first read of chunk c
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nch) issue(c + 1, (c + 1) & 1);
+        else if (wrap) issue(0, (c + 1) & 1);       // next pass starts over (nch is even)
+    }
+    __device__ __forceinline__ f32x4 get(int f) const         // fragment f of the current pass
+    {
+        if ((f % WS_CHUNK) == 0) boundary(f / WS_CHUNK);
+        return lds[(((f / WS_CHUNK) & 1) * WS_CHUNK + (f % WS_CHUNK)) * 64 + lane];
+    }
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// dense_acc fed from a WStream: fragments are taken in stream order (kt-major, m inner), `f` is the
+// running fragment index of the pass.
+template <int KT, int MT, int NT, bool SWAP = false>
+__device__ __forceinline__ void dense_acc_stream(const WStream &ws, int &f, const f32x4 (&in)[NT][KT], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 4 ? 4 : MT;
+    static_assert(MT % MG == 0, "MT must be a multiple of the m-group");
+    constexpr int GPK = MT / MG;
+    constexpr int NG = KT * GPK;
+    f32x4 cur[MG], nxt[MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) cur[m] = ws.get(f + m);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / GPK, m0 = (gi % GPK) * MG;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) nxt[m] = ws.get(f + (gi + 1) * MG + m);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? mfma16(in[nt][kt][r], cur[m][r], acc[nt][m0 + m])
+                                           : mfma16(cur[m][r], in[nt][kt][r], acc[nt][m0 + m]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m) cur[m] = nxt[m];
+    }
+    f += NG * MG;
 }
 
 // Launders a wave-uniform pointer through an empty asm so loads through it are not treated as

@@ -8,8 +8,13 @@
 namespace {
 
 // frag(kt,mt)[lane][r] = W[row_of(16mt + (lane&15))][col_of(16kt + 4(lane>>4) + r)], zero where either is < 0.
-template <class RowOf, class ColOf>
-void pack_dense(const float *W, int ldw, int KT, int MT, float *dst, RowOf row_of, ColOf col_of)
+struct KtMajor {
+    int MT;
+    size_t operator()(int kt, int mt) const { return (size_t)kt * MT + mt; }
+};
+
+template <class RowOf, class ColOf, class FragAt>
+void pack_dense(const float *W, int ldw, int KT, int MT, float *dst, RowOf row_of, ColOf col_of, FragAt frag_at)
 {
     for (int kt = 0; kt < KT; ++kt)
         for (int mt = 0; mt < MT; ++mt)
@@ -17,9 +22,14 @@ void pack_dense(const float *W, int ldw, int KT, int MT, float *dst, RowOf row_o
                 for (int r = 0; r < 4; ++r) {
                     const long orow = row_of(16 * mt + (lane & 15));
                     const long ocol = col_of(16 * kt + 4 * (lane >> 4) + r);
-                    dst[(((size_t)kt * MT + mt) * 64 + lane) * 4 + r] =
-                        (orow >= 0 && ocol >= 0) ? W[(size_t)orow * ldw + ocol] : 0.f;
+                    dst[(frag_at(kt, mt) * 64 + lane) * 4 + r] = (orow >= 0 && ocol >= 0) ? W[(size_t)orow * ldw + ocol] : 0.f;
                 }
+}
+
+template <class RowOf, class ColOf>
+void pack_dense(const float *W, int ldw, int KT, int MT, float *dst, RowOf row_of, ColOf col_of)
+{
+    pack_dense(W, ldw, KT, MT, dst, row_of, col_of, KtMajor{MT});
 }
 
 struct Ident {
@@ -70,6 +80,22 @@ extern "C" int pccx_pack_ae_encoder(const float *sa_w0, const float *sa_b0, cons
     pack_dense(pn_w1, 128, 8, 16, blob + ENC_PN_W1, Ident{256}, Ident{128});
     pack_dense(pn_w2, 256, 16, 32, blob + ENC_PN_W2, Ident{512}, Ident{256});
     pack_dense(pn_w3, 512, 32, 1, blob + ENC_PN_W3, Ident{d}, Ident{512});
+    // consumption-order stream for the LDS-staged PointNet kernel
+    {
+        float *st = blob + ENC_PN_STREAM;
+        int f = 0;
+        auto put = [&](int base, int MT, int kt, int mt) {
+            memcpy(st + (size_t)f * 256, blob + base + ((size_t)kt * MT + mt) * 256, 256 * sizeof(float));
+            ++f;
+        };
+        for (int kt = 0; kt < 9; ++kt) for (int mt = 0; mt < 8; ++mt) put(ENC_PN_W0, 8, kt, mt);
+        for (int kt = 0; kt < 8; ++kt) for (int mt = 0; mt < 16; ++mt) put(ENC_PN_W1, 16, kt, mt);
+        for (int mp = 0; mp < 16; ++mp) {
+            for (int kt = 0; kt < 16; ++kt) for (int m = 0; m < 2; ++m) put(ENC_PN_W2, 32, kt, 2 * mp + m);
+            for (int k3 = 0; k3 < 2; ++k3) put(ENC_PN_W3, 1, 2 * mp + k3, 0);
+        }
+        if (f != ENC_PN_STREAM_FRAGS) { pccx_set_error("pccx_pack_ae_encoder: stream has %d fragments", f); return PCCX_ERR_ARG; }
+    }
     return PCCX_OK;
 }
 
@@ -101,8 +127,15 @@ extern "C" int pccx_pack_ae_decoder(const float *ip_w0, const float *ip_b0, cons
     // are then directly the B operand of inv_mlp's first layer.
     for (int p = 0; p < k; ++p)
         for (int c = 0; c < 128; ++c) blob[DEC_G_B + p * 128 + c] = ip_b2[(size_t)c * k + p];
+    // Per-point weight stream (blobs.h): [p][ 64 kt x 8 m-tiles | inv_mlp fragments | pad ].
+    const size_t stride = (size_t)DEC_STREAM_CHUNKS * 16;          // fragments per point
     pack_dense(ip_w2, 1024, 64, k * 8, blob + DEC_G_W(k),
-               [k](int row) -> long { return (long)(row & 127) * k + (row >> 7); }, Ident{1024});
+               [k](int row) -> long { return (long)(row & 127) * k + (row >> 7); }, Ident{1024},
+               [=](int kt, int mt) -> size_t { return (size_t)(mt >> 3) * stride + (size_t)kt * 8 + (mt & 7); });
+    for (int p = 0; p < k; ++p) {
+        float *st = blob + DEC_G_W(k) + ((size_t)p * stride + DEC_STREAM_GEMM_FRAGS) * 256;
+        memcpy(st, blob + DEC_M_W0, sizeof(float) * 114 * 256);   // DEC_M_W0..W3 are contiguous, kt-major each
+    }
     return PCCX_OK;
 }
 

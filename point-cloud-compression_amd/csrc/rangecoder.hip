@@ -4,8 +4,11 @@
 // the image); the oracle (orc_range_encode / orc_range_decode) restates the same published algorithm
 // and must agree byte-for-byte.
 //
-// The coder is inherently serial per stream (S*d = 1024 symbols per cloud), so parallelism is one
-// lane per cloud; at ~0.5 KiB per cloud this is integer/byte work that never shows in the profile.
+// The coder is inherently serial per stream (S*d = 1024 symbols per cloud).  One wave per cloud:
+// the 64 lanes stage the cloud's CDF table (as uint16), symbols and output bytes through LDS with
+// coalesced transfers, and lane 0 runs the serial recurrence against LDS (~64-cycle reads instead of
+// dependent ~1 us global loads).  Streams larger than the LDS budget fall back to one lane per cloud
+// working from global memory.
 #include "common.h"
 
 struct BitWriter {
@@ -130,12 +133,140 @@ __global__ void range_decode_kernel(const int32_t *__restrict__ cdf_int, const u
     }
 }
 
+#define RC_MAX_LDS_BYTES (60 * 1024)
+
+__global__ __launch_bounds__(64) void range_encode_lds_kernel(const int32_t *__restrict__ cdf_int, const float *__restrict__ latent_q,
+                                                              int nsym, int Lp, int sym_offset, uint8_t *__restrict__ out, int cap,
+                                                              int32_t *__restrict__ nbytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+    unsigned short *scdf = (unsigned short *)rc_smem;                 // [nsym*Lp]
+    unsigned char *ssym = (unsigned char *)(scdf + (size_t)nsym * Lp); // [nsym]
+    uint8_t *sout = ssym + ((nsym + 15) & ~15);                        // [cap]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int32_t *c = cdf_int + (size_t)b * nsym * Lp;
+    const int max_symbol = Lp - 2;
+    for (int i = lane; i < nsym * Lp; i += 64) scdf[i] = (unsigned short)c[i];
+    for (int i = lane; i < nsym; i += 64) {
+        int s = (int)latent_q[(size_t)b * nsym + i] + sym_offset;
+        ssym[i] = (unsigned char)(s < 0 ? 0 : (s > max_symbol ? max_symbol : s));
+    }
+    __syncthreads();
+    int n_out = 0;
+    if (lane == 0) {
+        BitWriter w{sout, cap, 0, 0u, 0};
+        unsigned low = 0u, high = 0xFFFFFFFFu;
+        unsigned long long pending = 0;
+        for (int i = 0; i < nsym; ++i) {
+            const int s = ssym[i];
+            const unsigned short *ci = scdf + (size_t)i * Lp;
+            const unsigned long long span = (unsigned long long)high - (unsigned long long)low + 1ull;
+            const unsigned c_low = ci[s];
+            const unsigned c_high = s == max_symbol ? 0x10000u : (unsigned)ci[s + 1];
+            high = (unsigned)((low - 1u) + (unsigned)((span * c_high) >> 16));
+            low = (unsigned)(low + (unsigned)((span * c_low) >> 16));
+            for (;;) {
+                if (high < 0x80000000u) {
+                    w.bit_pending(0, pending);
+                    low <<= 1; high <<= 1; high |= 1u;
+                } else if (low >= 0x80000000u) {
+                    w.bit_pending(1, pending);
+                    low <<= 1; high <<= 1; high |= 1u;
+                } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                    ++pending;
+                    low <<= 1; low &= 0x7FFFFFFFu;
+                    high <<= 1; high |= 0x80000001u;
+                } else
+                    break;
+            }
+        }
+        ++pending;
+        if (low < 0x40000000u) w.bit_pending(0, pending);
+        else w.bit_pending(1, pending);
+        w.flush();
+        n_out = w.n;
+        nbytes[b] = w.n <= cap ? w.n : -w.n;
+    }
+    n_out = __shfl(n_out, 0);
+    __syncthreads();
+    if (n_out > cap) n_out = cap;
+    for (int i = lane; i < n_out; i += 64) out[(size_t)b * cap + i] = sout[i];
+}
+
+__global__ __launch_bounds__(64) void range_decode_lds_kernel(const int32_t *__restrict__ cdf_int, const uint8_t *__restrict__ in,
+                                                              int stride, const int32_t *__restrict__ nbytes, int nsym, int Lp,
+                                                              int sym_offset, float *__restrict__ latent_q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+    unsigned short *scdf = (unsigned short *)rc_smem;                 // [nsym*Lp]
+    unsigned char *ssym = (unsigned char *)(scdf + (size_t)nsym * Lp); // [nsym]
+    uint8_t *sin = ssym + ((nsym + 15) & ~15);                         // [nb]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int32_t *c = cdf_int + (size_t)b * nsym * Lp;
+    const int nb = nbytes[b] < 0 ? 0 : (nbytes[b] > stride ? stride : nbytes[b]);
+    for (int i = lane; i < nsym * Lp; i += 64) scdf[i] = (unsigned short)c[i];
+    for (int i = lane; i < nb; i += 64) sin[i] = in[(size_t)b * stride + i];
+    __syncthreads();
+    if (lane == 0) {
+        int pos = 0, cached = 0;
+        unsigned cache = 0;
+        unsigned low = 0u, high = 0xFFFFFFFFu, value = 0u;
+        auto get = [&]() {
+            if (cached == 0) {
+                if (pos >= nb) { value <<= 1; return; }
+                cache = sin[pos++]; cached = 8;
+            }
+            value = (value << 1) | ((cache >> (cached - 1)) & 1u);
+            --cached;
+        };
+        for (int i = 0; i < 32; ++i) get();
+        const int max_symbol = Lp - 2;
+        for (int i = 0; i < nsym; ++i) {
+            const unsigned short *ci = scdf + (size_t)i * Lp;
+            const unsigned long long span = (unsigned long long)high - (unsigned long long)low + 1ull;
+            const unsigned count =
+                (unsigned)((((unsigned long long)value - (unsigned long long)low + 1ull) * 0x10000ull - 1ull) / span) & 0xFFFFu;
+            int left = 0, right = max_symbol + 1;
+            while (left + 1 < right) {
+                const int mid = (left + right) >> 1;
+                if ((unsigned)ci[mid] <= count) left = mid; else right = mid;
+            }
+            const int s = left;
+            ssym[i] = (unsigned char)s;
+            const unsigned c_low = ci[s];
+            const unsigned c_high = s == max_symbol ? 0x10000u : (unsigned)ci[s + 1];
+            high = (unsigned)((low - 1u) + (unsigned)((span * c_high) >> 16));
+            low = (unsigned)(low + (unsigned)((span * c_low) >> 16));
+            for (;;) {
+                if (low >= 0x80000000u || high < 0x80000000u) {
+                    low <<= 1; high <<= 1; high |= 1u; get();
+                } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                    low <<= 1; low &= 0x7FFFFFFFu;
+                    high <<= 1; high |= 0x80000001u;
+                    value -= 0x40000000u;
+                    get();
+                } else
+                    break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < nsym; i += 64) latent_q[(size_t)b * nsym + i] = (float)((int)ssym[i] - sym_offset);
+}
+
 extern "C" int pccx_range_encode(const int32_t *cdf_int, const float *latent_q, int B, int nsym, int L, uint8_t *out, int cap,
                                  int32_t *nbytes, void *stream)
 {
     PCCX_CHECK_ARG(cdf_int && latent_q && out && nbytes, "pccx_range_encode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && cap >= 8, "pccx_range_encode: bad shape");
     if (B == 0) return PCCX_OK;
+    const size_t lds = (size_t)nsym * (L + 1) * 2 + ((nsym + 15) & ~15) + (size_t)cap;
+    if (lds <= RC_MAX_LDS_BYTES && L + 1 <= 256) {
+        hipLaunchKernelGGL(range_encode_lds_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cdf_int, latent_q, nsym, L + 1,
+                           L / 2, out, cap, nbytes);
+        PCCX_CHECK_LAUNCH();
+        return PCCX_OK;
+    }
     hipLaunchKernelGGL(range_encode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cdf_int, latent_q, B, nsym,
                        L + 1, L / 2, out, cap, nbytes);
     PCCX_CHECK_LAUNCH();
@@ -148,6 +279,13 @@ extern "C" int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int 
     PCCX_CHECK_ARG(cdf_int && in && nbytes && latent_q, "pccx_range_decode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && stride >= 1, "pccx_range_decode: bad shape");
     if (B == 0) return PCCX_OK;
+    const size_t lds = (size_t)nsym * (L + 1) * 2 + ((nsym + 15) & ~15) + (size_t)stride;
+    if (lds <= RC_MAX_LDS_BYTES && L + 1 <= 256) {
+        hipLaunchKernelGGL(range_decode_lds_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cdf_int, in, stride, nbytes, nsym,
+                           L + 1, L / 2, latent_q);
+        PCCX_CHECK_LAUNCH();
+        return PCCX_OK;
+    }
     hipLaunchKernelGGL(range_decode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, cdf_int, in, stride, nbytes,
                        B, nsym, L + 1, L / 2, latent_q);
     PCCX_CHECK_LAUNCH();

@@ -20,7 +20,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function", "-I", INCLUDE]
+         "-Wall", "-Wno-unused-function", "-I", INCLUDE] + os.environ.get("PCCX_EXTRA_FLAGS", "").split()
 
 
 def _newer(a, b):
