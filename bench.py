@@ -49,6 +49,9 @@ def seeded_state_dict(module, seed, gain=1.0, last_gain=None):
     cur = module.state_dict()
     for k, v in cur.items():
         shape = tuple(v.shape)
+        if len(shape) == 0:
+            sd[k] = v.clone()
+            continue
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
         if k.endswith("bias"):
             fan_in = int(np.prod(tuple(cur[k[:-4] + "weight"].shape)[1:]))

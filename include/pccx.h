@@ -184,6 +184,32 @@ PCCX_API int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int st
                                const int32_t *nbytes, int B, int nsym, int L, float *latent_q,
                                void *stream);
 
+/* ---- generic layers for the other model families (PPPF_AE.py, pointnet_sa_module.py,
+ *      pppe_pcd_ae.py:556-917): correctness-first building blocks ------------------------------- */
+
+/* 1x1 Conv2d / Conv1d / Linear (pointnet_sa_module.py:51, PPPF_AE.py:65-80,122-123,
+ * pppe_pcd_ae.py:556-568,697-707) on row-major "channels last" activations, with eval-mode
+ * BatchNorm folded into W and b by the caller: out[M][N] = act(x[M][K] . W^T + b).
+ * pccx_pack_linear (HOST pointers): W (N,K) row-major -> pccx_packed_linear_floats(N,K) floats.
+ * pccx_linear: x (M, ldx>=K), wp packed (device), bias (N) or NULL, relu 0/1, out (M, ldo>=N). */
+PCCX_API size_t pccx_packed_linear_floats(int N, int K);
+PCCX_API int pccx_pack_linear(const float *W_host, int N, int K, float *wp_host);
+PCCX_API int pccx_linear(const float *x, int M, int K, int ldx, const float *wp, const float *bias,
+                         int N, int relu, float *out, int ldo, void *stream);
+
+/* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
+ * x (G,Kn,C) -> out (G,C). */
+PCCX_API int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream);
+
+/* y = sigmoid(x)*(L-0.2) - (L-0.2)/2 (PPPF_AE.py:136-137, AE.py:43-44), optionally rounded;
+ * y = round(x) (AE.STEQuantize, AE.py:79-81). */
+PCCX_API int pccx_sigmoid_spread(const float *x, int64_t n, int L, int do_round, float *y, void *stream);
+PCCX_API int pccx_round(const float *x, int64_t n, float *y, void *stream);
+
+/* quantize_st forward value and its dequantisation (pppe_pcd_ae.py:719-735, :873). y_deq may be NULL. */
+PCCX_API int pccx_quantize_st(const float *x, int64_t n, float qmin, float qmax, int levels, float *y_q,
+                              float *y_deq, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

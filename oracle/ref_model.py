@@ -235,6 +235,9 @@ def seeded_state_dict(module, seed, gain=1.0, last_gain=None):
     sd = {}
     for k, v in module.state_dict().items():
         shape = tuple(v.shape)
+        if len(shape) == 0:                     # e.g. BatchNorm.num_batches_tracked
+            sd[k] = v.clone()
+            continue
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
         if k.endswith("bias"):
             w = module.state_dict()[k[:-4] + "weight"]

@@ -1,0 +1,218 @@
+// linear.hip -- generic building blocks for the reference's other model families (PPPF_AE.py,
+// pointnet_sa_module.py, pppe_pcd_ae.py:556-917): a runtime-shaped fp32 MFMA linear layer
+// (1x1 Conv / Linear with eval-mode BatchNorm folded into weight and bias on the host, optional ReLU)
+// and a max over the neighbour axis.  Activations are row-major "channels last" ((rows, C) with rows =
+// batch x points x neighbours), which is exactly the lane map of the 16x16x4 B operand (one 16-byte
+// load per lane) and of its C/D tile (one 16-byte store per lane), so no staging is needed.
+// These rows are correctness-first (unfused, activations round-trip through HBM); the fused chains
+// in encoder.hip / decoder.hip are the tuned path for the IPDAE configuration.
+#include <math.h>
+
+#include "common.h"
+#include "mfma_chain.h"
+
+extern "C" size_t pccx_packed_linear_floats(int N, int K)
+{
+    if (N < 1 || K < 1) return 0;
+    return (size_t)((K + 15) / 16) * (size_t)((N + 15) / 16) * 256;
+}
+
+// HOST: W (N,K) row-major -> fragments [kt][mt][lane][4] (mfma_chain.h), zero padded.
+extern "C" int pccx_pack_linear(const float *W_host, int N, int K, float *wp_host)
+{
+    PCCX_CHECK_ARG(W_host && wp_host && N >= 1 && K >= 1, "pccx_pack_linear: bad arguments");
+    const int KT = (K + 15) / 16, MT = (N + 15) / 16;
+    for (int kt = 0; kt < KT; ++kt)
+        for (int mt = 0; mt < MT; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + (lane & 15), col = 16 * kt + 4 * (lane >> 4) + r;
+                    wp_host[(((size_t)kt * MT + mt) * 64 + lane) * 4 + r] = (row < N && col < K) ? W_host[(size_t)row * K + col] : 0.f;
+                }
+    return PCCX_OK;
+}
+
+// out[M][N] = act(x[M][K] . W^T + b).  Block = 4 waves; wave = 32 rows (2 point tiles) x MTB*16 columns.
+template <int MTB, bool VEC>
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int M, int K, int ldx,
+                                                     const f32x4 *__restrict__ wp, int KT, int MT,
+                                                     const float *__restrict__ bias, int N, int relu,
+                                                     float *__restrict__ out, int ldo)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int row0 = (blockIdx.x * 4 + w) * 32;
+    if (row0 >= M) return;                                        // whole wave
+    const int mt0 = blockIdx.y * MTB;
+    f32x4 acc[2][MTB];
+#pragma unroll
+    for (int m = 0; m < MTB; ++m) {
+        f32x4 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (mt0 + m) + 4 * g + r;
+            b[r] = (bias && c < N) ? bias[c] : 0.f;
+        }
+        acc[0][m] = b; acc[1][m] = b;
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+        f32x4 bx[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int row = row0 + nt * 16 + n;
+            const int k = 16 * kt + 4 * g;
+            const float *px = x + (size_t)(row < M ? row : M - 1) * ldx + k;
+            if (VEC && k + 3 < K) {
+                bx[nt] = *(const f32x4 *)px;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bx[nt][r] = k + r < K ? px[r] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) {
+            if (mt0 + m < MT) {                                   // uniform
+                const f32x4 a = wp[((size_t)kt * MT + mt0 + m) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[0][m] = mfma16(a[r], bx[0][r], acc[0][m]);
+                    acc[1][m] = mfma16(a[r], bx[1][r], acc[1][m]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int row = row0 + nt * 16 + n;
+        if (row >= M) continue;
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) {
+            const int c = 16 * (mt0 + m) + 4 * g;
+            f32x4 v = acc[nt][m];
+            if (relu) v = relu4(v);
+            float *po = out + (size_t)row * ldo + c;
+            if (VEC && c + 3 < N) {
+                *(f32x4 *)po = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < N) po[r] = v[r];
+            }
+        }
+    }
+}
+
+extern "C" int pccx_linear(const float *x, int M, int K, int ldx, const float *wp, const float *bias, int N, int relu,
+                           float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(x && wp && out, "pccx_linear: null pointer");
+    PCCX_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && ldx >= K && ldo >= N, "pccx_linear: bad shape M=%d K=%d N=%d ldx=%d ldo=%d", M,
+                   K, N, ldx, ldo);
+    if (M == 0) return PCCX_OK;
+    const int KT = (K + 15) / 16, MT = (N + 15) / 16;
+    const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    constexpr int MTB = 4;
+    dim3 grid((M + 127) / 128, (MT + MTB - 1) / MTB);
+    PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear: N=%d too large", N);
+    if (vec)
+        hipLaunchKernelGGL((linear_kernel<MTB, true>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp,
+                           KT, MT, bias, N, relu, out, ldo);
+    else
+        hipLaunchKernelGGL((linear_kernel<MTB, false>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp,
+                           KT, MT, bias, N, relu, out, ldo);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// out[g][c] = max_k x[g][k][c]   (torch.max(new_features, 3)[0], pointnet_sa_module.py:91)
+__global__ void group_max_kernel(const float *__restrict__ x, long long G, int Kn, int C, float *__restrict__ out)
+{
+    const long long total = G * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long gi = e / C;
+        const int c = (int)(e % C);
+        const float *p = x + (gi * Kn) * C + c;
+        float m = -INFINITY;
+        for (int k = 0; k < Kn; ++k) m = fmaxf(m, p[(size_t)k * C]);
+        out[e] = m;
+    }
+}
+
+extern "C" int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream)
+{
+    PCCX_CHECK_ARG(x && out && G >= 0 && Kn >= 1 && C >= 1, "pccx_group_max: bad arguments");
+    if (G == 0) return PCCX_OK;
+    long long blocks = ((long long)G * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)G, Kn, C, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// y = sigmoid(x) * spread - spread/2 (PPPF_AE.py:136-137), optionally rounded (AE.py:79-81).
+__global__ void sigmoid_spread_kernel(const float *__restrict__ x, long n, float spread, float half, int do_round,
+                                      float *__restrict__ y)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float s = 1.0f / (1.0f + expf(-x[i]));
+        float v = __fsub_rn(__fmul_rn(s, spread), half);
+        y[i] = do_round ? rintf(v) : v;
+    }
+}
+
+extern "C" int pccx_sigmoid_spread(const float *x, int64_t n, int L, int do_round, float *y, void *stream)
+{
+    PCCX_CHECK_ARG(x && y && n >= 0 && L >= 1, "pccx_sigmoid_spread: bad arguments");
+    if (n == 0) return PCCX_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sigmoid_spread_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n,
+                       (float)((double)L - 0.2), (float)(((double)L - 0.2) / 2), do_round, y);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// y = rint(x) (AE.STEQuantize.forward, AE.py:79-81)
+__global__ void round_kernel(const float *__restrict__ x, long n, float *__restrict__ y)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = rintf(x[i]);
+}
+
+extern "C" int pccx_round(const float *x, int64_t n, float *y, void *stream)
+{
+    PCCX_CHECK_ARG(x && y && n >= 0, "pccx_round: bad arguments");
+    if (n == 0) return PCCX_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(round_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, y);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// quantize_st forward value + dequantisation (pppe_pcd_ae.py:719-735, :873):
+//   scaled = (clamp(x,min,max) - min) / (max - min + 1e-9) * (levels-1); y_q = clamp(round(scaled), 0, levels-1)
+//   y_deq  = y_q / (levels-1) * (max - min) + min
+__global__ void quantize_st_kernel(const float *__restrict__ x, long n, float qmin, float qmax, float denom, float lm1,
+                                   float *__restrict__ yq, float *__restrict__ ydeq)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float xc = fminf(fmaxf(x[i], qmin), qmax);
+        const float scaled = __fmul_rn(__fdiv_rn(__fsub_rn(xc, qmin), denom), lm1);
+        const float q = fminf(fmaxf(rintf(scaled), 0.f), lm1);
+        yq[i] = q;
+        if (ydeq) ydeq[i] = __fadd_rn(__fmul_rn(__fdiv_rn(q, lm1), __fsub_rn(qmax, qmin)), qmin);
+    }
+}
+
+extern "C" int pccx_quantize_st(const float *x, int64_t n, float qmin, float qmax, int levels, float *y_q, float *y_deq,
+                                void *stream)
+{
+    PCCX_CHECK_ARG(x && y_q && n >= 0 && levels >= 2 && qmax > qmin, "pccx_quantize_st: bad arguments");
+    if (n == 0) return PCCX_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(quantize_st_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, qmin, qmax,
+                       (float)((double)(qmax - qmin) + 1e-9), (float)(levels - 1), y_q, y_deq);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

@@ -38,9 +38,17 @@ _SIGNATURES = {
     "pccx_prob_forward": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_range_encode": [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_range_decode": [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_packed_linear_floats": [C.c_int, C.c_int],
+    "pccx_pack_linear": [_P, C.c_int, C.c_int, _P],
+    "pccx_linear": [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
+    "pccx_group_max": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
+    "pccx_sigmoid_spread": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
+    "pccx_round": [_P, C.c_int64, _P, _P],
+    "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
 _RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
-             "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t}
+             "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
+             "pccx_packed_linear_floats": C.c_size_t}
 
 _lib = None
 

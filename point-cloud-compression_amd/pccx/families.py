@@ -1,0 +1,310 @@
+"""The reference's other two model families over libpccx.so (inference forward passes):
+
+  * PPPF_AE (PPPF_AE.py:114-150) = PointNet++ encoder built from PointnetSAModule
+    (pointnet_sa_module.py:38-93: FPS from index 0, ball query, gather, Conv-BN-ReLU stack, max)
+    + FoldingNet decoder (PPPF_AE.py:50-109)                          -- SURVEY 8a rows a18, a19
+  * PointCloudAE of pppe_pcd_ae.py:843-877 (MSG + two SA levels with kNN grouping, global conv,
+    quantize_st, PCN decoder)                                          -- SURVEY 8a row a21
+
+Same constructor arguments and state_dict keys as the reference (torch modules are parameter
+containers only).  Every layer is a HIP kernel behind the C ABI: selection ops from ops.py, the
+Conv/Linear stacks through pccx_linear with eval-mode BatchNorm folded into weight and bias at pack
+time, neighbour max through pccx_group_max.  Activations are kept channels-last ((rows, C)), so the
+reference's permutes disappear; torch only concatenates and reshapes buffers.
+These families are correctness-first (layer by layer through HBM); the fused, tuned path is the
+IPDAE codec in models.py / codec.py.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .ops import _stream
+
+
+class FoldedLinear:
+    """Conv1x1 / Linear (+ eval BatchNorm) (+ ReLU) packed for pccx_linear."""
+
+    def __init__(self, weight, bias, relu, bn=None, device="cuda"):
+        W = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).clone()
+        b = bias.detach().to("cpu", torch.float32).clone() if bias is not None else torch.zeros(W.shape[0])
+        if bn is not None:                                  # y = (z - mean) / sqrt(var + eps) * gamma + beta
+            scale = bn.weight.detach().cpu() / torch.sqrt(bn.running_var.detach().cpu() + bn.eps)
+            W = W * scale[:, None]
+            b = (b - bn.running_mean.detach().cpu()) * scale + bn.bias.detach().cpu()
+        self.N, self.K, self.relu = W.shape[0], W.shape[1], int(bool(relu))
+        W = W.contiguous()
+        wp = torch.zeros(_lib.load().pccx_packed_linear_floats(self.N, self.K), dtype=torch.float32)
+        _lib.call("pccx_pack_linear", W.data_ptr(), self.N, self.K, wp.data_ptr())
+        self.wp, self.b = wp.to(device), b.contiguous().to(device)
+
+    def __call__(self, x):
+        """x (M,K) f32 contiguous on the GPU -> (M,N)."""
+        M = x.shape[0]
+        out = torch.empty(M, self.N, device=x.device, dtype=torch.float32)
+        _lib.call("pccx_linear", x.data_ptr(), M, self.K, x.stride(0), self.wp.data_ptr(), self.b.data_ptr(), self.N,
+                  self.relu, out.data_ptr(), self.N, _stream())
+        return out
+
+
+def group_max(x):
+    """(G,Kn,C) -> (G,C)."""
+    G, Kn, Cc = x.shape
+    out = torch.empty(G, Cc, device=x.device, dtype=torch.float32)
+    _lib.call("pccx_group_max", x.contiguous().data_ptr(), G, Kn, Cc, out.data_ptr(), _stream())
+    return out
+
+
+def sigmoid_spread(x, L, do_round=False):
+    y = torch.empty_like(x)
+    _lib.call("pccx_sigmoid_spread", x.contiguous().data_ptr(), x.numel(), int(L), int(do_round), y.data_ptr(), _stream())
+    return y
+
+
+def round_(x):
+    y = torch.empty_like(x)
+    _lib.call("pccx_round", x.contiguous().data_ptr(), x.numel(), y.data_ptr(), _stream())
+    return y
+
+
+def _fold_stack(seq, device):
+    """[Conv, (BN), (ReLU), ...] -> list of FoldedLinear."""
+    mods = list(seq)
+    out, i = [], 0
+    while i < len(mods):
+        conv = mods[i]
+        i += 1
+        bn = None
+        if i < len(mods) and isinstance(mods[i], (nn.BatchNorm1d, nn.BatchNorm2d)):
+            bn = mods[i]
+            i += 1
+        relu = i < len(mods) and isinstance(mods[i], nn.ReLU)
+        if relu:
+            i += 1
+        out.append(FoldedLinear(conv.weight, conv.bias, relu, bn, device))
+    return out
+
+
+class _Packable(nn.Module):
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._packed = None
+        return r
+
+
+# =================================================================================================
+# PPPF_AE
+# =================================================================================================
+class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:38-56
+    def __init__(self, npoint, radius, nsample, mlp, use_xyz=True, in_channels=0):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.use_xyz = npoint, radius, nsample, use_xyz
+        last = in_channels + (3 if use_xyz else 0)
+        layers = []
+        for out in mlp:
+            layers += [nn.Conv2d(last, out, 1), nn.BatchNorm2d(out), nn.ReLU(inplace=True)]
+            last = out
+        self.mlp = nn.Sequential(*layers)
+
+    def run(self, stack, xyz, feats):
+        """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C'))."""
+        B = xyz.shape[0]
+        new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)                   # :66-68 (start index 0)
+        idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
+        grouped = ops.index_points(xyz, idx)                                        # :81 (not centred)
+        if feats is not None:
+            grouped = torch.cat([ops.index_points(feats, idx), grouped], dim=-1)    # :83 features first, xyz last
+        x = grouped.reshape(-1, grouped.shape[-1]).contiguous()
+        for layer in stack:
+            x = layer(x)                                                            # :90 Conv-BN-ReLU
+        return new_xyz, group_max(x.view(B * self.npoint, self.nsample, -1)).view(B, self.npoint, -1)   # :91
+
+
+class PointNetPP(nn.Module):                            # PPPF_AE.py:9-46
+    def __init__(self, points=512, sa1_mlp=(64, 64, 128), sa2_mlp=(128, 128, 128, 256), sa3_mlp=(256, 256, 512),
+                 feature_dim=1024):
+        super().__init__()
+        self.sa1 = PointnetSAModule(points, 0.2, 32, [3] + list(sa1_mlp), True, 0)
+        self.sa2 = PointnetSAModule(128, 0.4, 64, list(sa2_mlp), True, 128)
+        self.sa3 = PointnetSAModule(32, 0.8, 128, list(sa3_mlp) + [feature_dim], True, 256)
+
+
+class FoldingNet(nn.Module):                            # PPPF_AE.py:50-80
+    def __init__(self, points=512, grid_size=45, feature_dim=1024):
+        super().__init__()
+        self.grid_size, self.num_points = grid_size, grid_size * grid_size
+        self.mlp1 = nn.Sequential(nn.Conv1d(feature_dim + 2, points, 1), nn.ReLU(), nn.Conv1d(points, points, 1), nn.ReLU(),
+                                  nn.Conv1d(points, 3, 1))
+        self.mlp2 = nn.Sequential(nn.Conv1d(feature_dim + 3, 128, 1), nn.ReLU(), nn.Conv1d(128, 128, 1), nn.ReLU(),
+                                  nn.Conv1d(128, 3, 1))
+
+
+class PPPF_AE(_Packable):
+    """PPPF_AE.PPPF_AE (PPPF_AE.py:114-150)."""
+
+    def __init__(self, K=512, k=0, d=16, L=7, dim=1024):
+        super().__init__()
+        self.L, self.d, self.dim = L, d, dim
+        self.encoder = PointNetPP(points=K, feature_dim=dim)
+        self.decoder = FoldingNet(points=K, grid_size=d)
+        self.enc_proj = nn.Linear(dim, d)
+        self.dec_proj = nn.Linear(d, dim)
+        self._packed = None
+
+    def pack(self, device="cuda"):
+        e, dcd = self.encoder, self.decoder
+        self._packed = dict(sa=[_fold_stack(m.mlp, device) for m in (e.sa1, e.sa2, e.sa3)],
+                            enc=FoldedLinear(self.enc_proj.weight, self.enc_proj.bias, False, None, device),
+                            dec=FoldedLinear(self.dec_proj.weight, self.dec_proj.bias, False, None, device),
+                            mlp1=_fold_stack(dcd.mlp1, device), mlp2=_fold_stack(dcd.mlp2, device))
+        x = torch.linspace(-1, 1, dcd.grid_size)
+        gx, gy = torch.meshgrid(x, x, indexing="ij")
+        self._packed["grid"] = torch.stack([gx, gy], dim=-1).reshape(-1, 2).to(device)            # :82-88
+        return self
+
+    def forward(self, xyz):
+        """xyz (B,N,3) on the GPU -> (recon (B,d*d,3), latent (B,dim), latent_quantized (B,d))."""
+        if self._packed is None:
+            self.pack(xyz.device)
+        pk = self._packed
+        B = xyz.shape[0]
+        pts, feats = ops._f32c(xyz, "PPPF_AE"), None
+        for mod, stack in zip((self.encoder.sa1, self.encoder.sa2, self.encoder.sa3), pk["sa"]):
+            pts, feats = mod.run(stack, pts, feats)
+        g = group_max(feats)                                                        # :44 max over the 32 points
+        latent = sigmoid_spread(g, self.L)                                          # :136-137
+        q = round_(pk["enc"](latent))                                               # :139-142
+        lat_dec = pk["dec"](q)                                                      # :145
+        P = self.decoder.num_points
+        rep = lat_dec[:, None, :].expand(B, P, self.dim)
+        x = torch.cat([pk["grid"][None].expand(B, P, 2), rep], dim=-1).reshape(B * P, -1).contiguous()   # :99-101
+        for layer in pk["mlp1"]:
+            x = layer(x)                                                            # :104 coarse
+        x = torch.cat([x.view(B, P, 3), rep], dim=-1).reshape(B * P, -1).contiguous()                      # :106
+        for layer in pk["mlp2"]:
+            x = layer(x)                                                            # :107 fine
+        return x.view(B, P, 3), latent, q
+
+
+# =================================================================================================
+# pppe PointCloudAE
+# =================================================================================================
+def _c2(in_c, out_c):
+    return nn.Sequential(nn.Conv2d(in_c, out_c, 1, bias=False), nn.BatchNorm2d(out_c), nn.ReLU(inplace=True))
+
+
+class PointNetSetAbstraction(nn.Module):                # pppe_pcd_ae.py:573-611
+    def __init__(self, npoint, K, in_channel, mlp):
+        super().__init__()
+        self.npoint, self.K = npoint, K
+        last = in_channel + 3
+        layers = []
+        for out in mlp:
+            layers.append(_c2(last, out))
+            last = out
+        self.mlp_stack = nn.ModuleList(layers)
+
+    def run(self, stack, xyz, feats, start):
+        B, N, _ = xyz.shape
+        S = self.npoint
+        new_xyz = xyz if S == N else ops.index_points(xyz, ops.farthest_point_sample_batch(xyz, S, start))   # :593-597
+        nn_ = ops.knn_points(new_xyz, xyz, self.K, patch_scale=1.0)                  # :599-600 (nn - centre) * 1
+        grouped = nn_.knn
+        if feats is not None:
+            grouped = torch.cat([grouped, ops.index_points(feats, nn_.idx)], dim=-1)  # :606 xyz first
+        x = grouped.reshape(-1, grouped.shape[-1]).contiguous()
+        for layer in stack:
+            x = layer(x)
+        return new_xyz, group_max(x.view(B * S, self.K, -1)).view(B, S, -1)          # :610
+
+
+class PointNetSetAbstractionMSG(nn.Module):             # pppe_pcd_ae.py:614-632
+    def __init__(self, npoint, scales, in_channel):
+        super().__init__()
+        self.branches = nn.ModuleList([PointNetSetAbstraction(npoint, s["K"], in_channel, s["mlp"]) for s in scales])
+
+
+class PointNet2EncoderFull(nn.Module):                  # pppe_pcd_ae.py:637-667
+    def __init__(self, latent_dim=256):
+        super().__init__()
+        self.sa_modules = nn.ModuleList([
+            PointNetSetAbstractionMSG(512, [{"K": 16, "mlp": [32, 32, 64]}, {"K": 32, "mlp": [64, 64, 128]}], 0),
+            PointNetSetAbstraction(128, 32, 64 + 128, [128, 128, 256]),
+            PointNetSetAbstraction(32, 32, 256, [256, 256, 512])])
+        self.global_conv = nn.Sequential(nn.Conv1d(512, 512, 1, bias=False), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, latent_dim, 1))
+
+
+class PCNDecoderSmall(nn.Module):                       # pppe_pcd_ae.py:691-707
+    def __init__(self, latent_dim=256, coarse_points=512, final_points=8192):
+        super().__init__()
+        self.fc_coarse = nn.Sequential(nn.Linear(latent_dim, 512), nn.ReLU(), nn.Linear(512, coarse_points * 3))
+        self.expansion_mlp = nn.Sequential(nn.Linear(coarse_points * 3 + latent_dim, 1024), nn.ReLU(),
+                                           nn.Linear(1024, final_points * 3))
+        self.coarse_points, self.final_points = coarse_points, final_points
+
+
+class _PppeProbParams(nn.Module):                       # pppe_pcd_ae.py:751-772 (parameters only)
+    def __init__(self, feature_dim=512, hidden_channels=128, latent_bins=16, latent_channels=3):
+        super().__init__()
+        self.cond_proj = nn.Sequential(nn.Linear(feature_dim, hidden_channels), nn.ReLU(), nn.Linear(hidden_channels, hidden_channels))
+        self.combine = nn.Sequential(nn.Conv1d(latent_channels + hidden_channels, hidden_channels, 1), nn.ReLU(),
+                                     nn.Conv1d(hidden_channels, hidden_channels, 1))
+        self.mean_head = nn.Conv1d(hidden_channels, latent_channels, 1)
+        self.scale_head = nn.Conv1d(hidden_channels, latent_channels, 1)
+        self.pmf_head = nn.Conv1d(hidden_channels, latent_bins, 1)
+
+
+class PointCloudAE(_Packable):
+    """pppe_pcd_ae.PointCloudAE.forward (pppe_pcd_ae.py:843-877), eval mode."""
+
+    def __init__(self, latent_dim=64, latent_bins=16, npoints=8192):
+        super().__init__()
+        self.encoder = PointNet2EncoderFull(latent_dim=latent_dim)
+        self.decoder = PCNDecoderSmall(latent_dim=latent_dim, coarse_points=512, final_points=npoints)
+        self.prob = _PppeProbParams(512, 128, latent_bins, latent_dim)
+        self.latent_bins, self.latent_dim = latent_bins, latent_dim
+        self.q_min, self.q_max = 0.0, latent_bins - 1.0
+        self._packed = None
+
+    def pack(self, device="cuda"):
+        sa = self.encoder.sa_modules
+        self._packed = dict(
+            msg=[[FoldedLinear(l[0].weight, None, True, l[1], device) for l in br.mlp_stack] for br in sa[0].branches],
+            sa1=[FoldedLinear(l[0].weight, None, True, l[1], device) for l in sa[1].mlp_stack],
+            sa2=[FoldedLinear(l[0].weight, None, True, l[1], device) for l in sa[2].mlp_stack],
+            gconv=_fold_stack(self.encoder.global_conv, device),
+            coarse=_fold_stack(self.decoder.fc_coarse, device), expand=_fold_stack(self.decoder.expansion_mlp, device))
+        return self
+
+    def forward(self, x, starts):
+        """x (B,N,3) on the GPU; starts = [[msg_branch0, msg_branch1], sa2, sa3], each (B,) FPS start
+        indices (the reference draws them with torch.randint, pn_kit.py:321).
+        -> (coarse (B,512,3), fine (B,N,3), cond_feats (B,512), y_q (B,d), latent (B,d))."""
+        if self._packed is None:
+            self.pack(x.device)
+        pk = self._packed
+        x = ops._f32c(x, "PointCloudAE")
+        B = x.shape[0]
+        sa = self.encoder.sa_modules
+        outs, new_xyz = [], None
+        for br, stack, st in zip(sa[0].branches, pk["msg"], starts[0]):             # :617-632 (last branch's centroids win)
+            new_xyz, f = br.run(stack, x, None, st)
+            outs.append(f)
+        feats = torch.cat(outs, dim=-1).contiguous()
+        xyz, feats = sa[1].run(pk["sa1"], new_xyz, feats, starts[1])
+        xyz, feats = sa[2].run(pk["sa2"], xyz, feats, starts[2])
+        cond = group_max(feats)                                                      # :682 global max
+        latent = cond
+        for layer in pk["gconv"]:
+            latent = layer(latent)                                                   # :684
+        # quantize_st (:719-735) then dequantise (:873); the mean over N tiled copies (:875) is the value itself
+        y_q, y_deq = torch.empty_like(latent), torch.empty_like(latent)
+        _lib.call("pccx_quantize_st", latent.data_ptr(), latent.numel(), float(self.q_min), float(self.q_max),
+                  int(self.latent_bins), y_q.data_ptr(), y_deq.data_ptr(), _stream())
+        c = y_deq
+        for layer in pk["coarse"]:
+            c = layer(c)                                                             # :710
+        e = torch.cat([c, y_deq], dim=1).contiguous()                                # :711
+        for layer in pk["expand"]:
+            e = layer(e)                                                             # :712
+        return c.view(B, -1, 3), e.view(B, -1, 3), cond, y_q, latent

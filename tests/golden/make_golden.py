@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-from oracle import cport, ref_model  # noqa: E402
+from oracle import cport, ref_families, ref_model  # noqa: E402
 from tests import synth  # noqa: E402
 
 
@@ -55,8 +55,10 @@ def _bind_absent_third_party():
     ops.knn = knn
     ops.knn_points = knn.knn_points
     ops.knn_gather = knn.knn_gather
-    ops.ball_query = absent("pytorch3d.ball_query")
-    ops.sample_farthest_points = absent("pytorch3d.sample_farthest_points")
+    knn.knn_gather = ref_families.knn_gather         # oracle-defined, as knn_points
+    ops.knn_gather = knn.knn_gather
+    ops.ball_query = lambda p1, p2, K, radius: ref_families.ball_query(p1, p2, K, radius)[1]   # pointnet_sa_module.py:18 uses the result as idx
+    ops.sample_farthest_points = ref_families.sample_farthest_points
     loss.chamfer_distance = absent("pytorch3d.chamfer_distance")
     p3d.ops, p3d.loss = ops, loss
     pynt = types.ModuleType("pyntcloud")
@@ -180,7 +182,33 @@ def main():
         md["pmf"] = pm.numpy()
         md["cdf"] = ref_pn_kit.pmf_to_cdf(pm).numpy()
     np.savez_compressed(os.path.join(HERE, "model.npz"), **md)
-    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz"):
+    # ---------------------------------------------------------------- 5. other model families (eval mode)
+    import PPPF_AE as ref_PPPF
+    import pppe_pcd_ae as ref_pppe
+    fam = {}
+    m = ref_PPPF.PPPF_AE(K=512, k=0, d=16, L=7).eval()
+    m.load_state_dict(synth.family_tweak(ref_families.seeded_with_bn(m, synth.PPPF_SEED), "pppf"))
+    fam["pppf_keys"] = np.array(list(m.state_dict().keys()))
+    fam["pppf_shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+    with torch.no_grad():
+        rec, lat, q = m(torch.from_numpy(synth.pppf_input()))                  # PPPF_AE.py:128-150
+    fam["pppf_recon"], fam["pppf_latent_sample"], fam["pppf_q"] = rec.numpy(), lat[:, ::16].numpy(), q.numpy()
+    pm = ref_pppe.PointCloudAE(latent_dim=64, latent_bins=16, npoints=8192).eval()
+    pm.load_state_dict(synth.family_tweak(ref_families.seeded_with_bn(pm, synth.PPPE_SEED), "pppe"))
+    fam["pppe_keys"] = np.array(list(pm.state_dict().keys()))
+    fam["pppe_shapes"] = np.array([str(tuple(v.shape)) for v in pm.state_dict().values()])
+    x = torch.from_numpy(synth.pppe_input())
+    B = x.shape[0]
+    torch.manual_seed(77)      # the four torch.randint draws of pn_kit.py:321, in call order (:617-632, :596)
+    fam["pppe_starts"] = np.stack([torch.randint(0, n, (B,), dtype=torch.long).numpy() for n in (8192, 8192, 512, 128)])
+    torch.manual_seed(77)
+    with torch.no_grad():
+        coarse, fine, cond, y_q = pm(x)                                         # pppe_pcd_ae.py:858-877
+    fam["pppe_coarse"], fam["pppe_fine_sample"] = coarse.numpy(), fine[:, ::16].numpy()
+    fam["pppe_cond"], fam["pppe_yq"] = cond.numpy(), y_q[:, :, 0].numpy()
+    np.savez_compressed(os.path.join(HERE, "families.npz"), **fam)
+
+    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -113,3 +113,27 @@ def centres_case(S=64):
     rng = np.random.default_rng(51)
     q = rng.integers(0, 128, size=(S, 3))
     return ((q + 0.5) / 128.0).astype(np.float32)[None]
+
+
+# ---- other model families (PPPF_AE, pppe PointCloudAE) ------------------------------------------
+PPPF_SEED, PPPE_SEED = 31, 32
+
+
+def family_tweak(sd, family):
+    """Scale the bottleneck projections so the quantised symbols are not all zero."""
+    import torch
+    if family == "pppf":
+        sd["enc_proj.weight"] = sd["enc_proj.weight"] * 40.0
+    else:
+        sd["encoder.global_conv.3.weight"] = sd["encoder.global_conv.3.weight"] * 60.0
+        sd["encoder.global_conv.3.bias"] = sd["encoder.global_conv.3.bias"] + 7.5
+    return sd
+
+
+def pppf_input(B=2):
+    """(B,512,3) patches in [0,1]^3-ish coordinates with the +0.5 shift of sample_shapenet.py:161."""
+    return np.stack([cloud_synth.cad_cloud(200 + b, 512) - np.float32(0.5) + np.float32(0.5) for b in range(B)]).astype(np.float32)
+
+
+def pppe_input(B=1):
+    return np.stack([cloud_synth.cad_cloud(300 + b, 8192) for b in range(B)]).astype(np.float32)
