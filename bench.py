@@ -39,6 +39,17 @@ FLOP_PN = K_PATCH * (131 * 128 + 128 * 256 + 256 * 512 + 512 * D_LAT) * 2
 K_SMALL = K_PATCH // ALPHA
 FLOP_DEC = (D_LAT * 256 + 256 * 1024 + 1024 * K_SMALL * 128) * 2 + K_SMALL * (144 * 128 + 128 * 64 + 64 * 32 + 32 * 3) * 2
 STAGE_FLOP = {"sa_forward": FLOP_SA, "pn_forward": FLOP_PN, "ae_decode": FLOP_DEC}
+STAGE_KERNEL = {"sa_forward": "sa_forward_kernel", "pn_forward": "pn_forward_kernel", "ae_decode": "dec_main_kernel"}
+
+
+def measured_traffic(stage, batch):
+    """HBM bytes per launch of the stage's kernel from the committed PMC passes (profiles/round1_traffic.json,
+    collected at --batch 256 with rocprofv3 --pmc in separate runs); None when not applicable."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))["kernels"][STAGE_KERNEL[stage]]
+        return int(t["hbm_bytes_per_launch"] * batch / 256)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def seeded_state_dict(module, seed, gain=1.0, last_gain=None):
@@ -192,7 +203,7 @@ def main():
                        "clouds_per_gpu_per_step": B, "points_per_cloud": N_POINTS, "patches_per_cloud": S_PATCH,
                        "octree_mode": args.octree_mode, "sharding": f"file-sharded x{world}", "weights": "seeded random"},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS, "traffic": measured_traffic(dom, B),
                          "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P},
             "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
             "mfma_stage_tflops": {k: STAGE_FLOP[k] * P / (stages[k][0] * 1e-3) / 1e12 for k in STAGE_FLOP if k in stages},

@@ -135,6 +135,51 @@ __global__ void range_decode_kernel(const int32_t *__restrict__ cdf_int, const u
 
 #define RC_MAX_LDS_BYTES (60 * 1024)
 
+// ---- bulk renormalisation -----------------------------------------------------------------------
+// The E1/E2 loop of the reference coder shifts out one bit per iteration while the top bits of low
+// and high agree; that run is clz(low ^ high) bits long and can be emitted at once.  The E3
+// (underflow) loop runs while low = 01.., high = 10..: its length is the run of positions, from bit
+// 30 down, where low has 1 and high has 0, again one clz.  k consecutive E3 steps give
+//   low' = (low << k) & 0x7FFFFFFF,  high' = (high << k) | 0x80000000 | (2^k - 1),  pending += k,
+// and on the decoder value' = ((value << k) ^ 0x80000000) | next k bits (each step subtracts 2^30
+// before doubling; the k subtractions sum to 2^31 mod 2^32).  Bit-for-bit the same stream as the
+// one-bit-at-a-time form (tests compare against the oracle's literal restatement).
+struct BulkWriter {
+    uint8_t *buf;
+    int cap, n;
+    unsigned long long acc;     // low `na` bits are pending output
+    int na;
+    __device__ __forceinline__ void put(unsigned v, int cnt)          // cnt <= 32
+    {
+        if (cnt == 0) return;
+        acc = (acc << cnt) | (unsigned long long)v;
+        na += cnt;
+        while (na >= 8) {
+            if (n < cap) buf[n] = (uint8_t)(acc >> (na - 8));
+            ++n;
+            na -= 8;
+        }
+    }
+    __device__ __forceinline__ void run(int bit, unsigned long long cnt)
+    {
+        while (cnt > 0) {
+            const int c = cnt > 32 ? 32 : (int)cnt;
+            put(bit ? (c == 32 ? 0xFFFFFFFFu : ((1u << c) - 1u)) : 0u, c);
+            cnt -= c;
+        }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        if (na > 0) {
+            if (n < cap) buf[n] = (uint8_t)(acc << (8 - na));
+            ++n;
+            na = 0;
+        }
+    }
+};
+
+__device__ __forceinline__ unsigned ones(int m) { return m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u); }
+
 __global__ __launch_bounds__(64) void range_encode_lds_kernel(const int32_t *__restrict__ cdf_int, const float *__restrict__ latent_q,
                                                               int nsym, int Lp, int sym_offset, uint8_t *__restrict__ out, int cap,
                                                               int32_t *__restrict__ nbytes)
@@ -154,7 +199,7 @@ __global__ __launch_bounds__(64) void range_encode_lds_kernel(const int32_t *__r
     __syncthreads();
     int n_out = 0;
     if (lane == 0) {
-        BitWriter w{sout, cap, 0, 0u, 0};
+        BulkWriter w{sout, cap, 0, 0ull, 0};
         unsigned low = 0u, high = 0xFFFFFFFFu;
         unsigned long long pending = 0;
         for (int i = 0; i < nsym; ++i) {
@@ -166,23 +211,30 @@ __global__ __launch_bounds__(64) void range_encode_lds_kernel(const int32_t *__r
             high = (unsigned)((low - 1u) + (unsigned)((span * c_high) >> 16));
             low = (unsigned)(low + (unsigned)((span * c_low) >> 16));
             for (;;) {
-                if (high < 0x80000000u) {
-                    w.bit_pending(0, pending);
-                    low <<= 1; high <<= 1; high |= 1u;
-                } else if (low >= 0x80000000u) {
-                    w.bit_pending(1, pending);
-                    low <<= 1; high <<= 1; high |= 1u;
-                } else if (low >= 0x40000000u && high < 0xC0000000u) {
-                    ++pending;
-                    low <<= 1; low &= 0x7FFFFFFFu;
-                    high <<= 1; high |= 0x80000001u;
+                const unsigned x = low ^ high;
+                if ((int)x >= 0) {                                     // E1/E2 run: top bits agree
+                    const int m = x ? __clz(x) : 32;
+                    const unsigned b0 = low >> 31;
+                    w.put(b0, 1);
+                    w.run(!b0, pending);
+                    pending = 0;
+                    if (m > 1) w.put((low << 1) >> (32 - (m - 1)), m - 1);
+                    low = m >= 32 ? 0u : low << m;
+                    high = m >= 32 ? 0xFFFFFFFFu : ((high << m) | ones(m));
+                } else if ((low & 0x40000000u) && !(high & 0x40000000u)) {   // E3 run
+                    const unsigned t = (~low | high) << 1;
+                    const int k = t ? __clz(t) : 31;
+                    low = (low << k) & 0x7FFFFFFFu;
+                    high = (high << k) | 0x80000000u | ones(k);
+                    pending += k;
                 } else
                     break;
             }
         }
         ++pending;
-        if (low < 0x40000000u) w.bit_pending(0, pending);
-        else w.bit_pending(1, pending);
+        const int fb = low < 0x40000000u ? 0 : 1;
+        w.put(fb, 1);
+        w.run(!fb, pending);
         w.flush();
         n_out = w.n;
         nbytes[b] = w.n <= cap ? w.n : -w.n;
@@ -208,28 +260,30 @@ __global__ __launch_bounds__(64) void range_decode_lds_kernel(const int32_t *__r
     for (int i = lane; i < nb; i += 64) sin[i] = in[(size_t)b * stride + i];
     __syncthreads();
     if (lane == 0) {
-        int pos = 0, cached = 0;
-        unsigned cache = 0;
-        unsigned low = 0u, high = 0xFFFFFFFFu, value = 0u;
-        auto get = [&]() {
-            if (cached == 0) {
-                if (pos >= nb) { value <<= 1; return; }
-                cache = sin[pos++]; cached = 8;
+        // bit reader: `buf` holds `have` unread bits in its low end; bytes past the stream read as 0
+        unsigned long long buf = 0;
+        int have = 0, pos = 0;
+        auto getbits = [&](int m) -> unsigned {                        // m <= 32
+            if (m == 0) return 0u;
+            while (have < m) {
+                buf = (buf << 8) | (unsigned long long)(pos < nb ? sin[pos] : 0);
+                ++pos;
+                have += 8;
             }
-            value = (value << 1) | ((cache >> (cached - 1)) & 1u);
-            --cached;
+            have -= m;
+            return (unsigned)((buf >> have) & (m >= 32 ? 0xFFFFFFFFull : ((1ull << m) - 1ull)));
         };
-        for (int i = 0; i < 32; ++i) get();
+        unsigned low = 0u, high = 0xFFFFFFFFu, value = getbits(32);
         const int max_symbol = Lp - 2;
         for (int i = 0; i < nsym; ++i) {
             const unsigned short *ci = scdf + (size_t)i * Lp;
             const unsigned long long span = (unsigned long long)high - (unsigned long long)low + 1ull;
-            const unsigned count =
-                (unsigned)((((unsigned long long)value - (unsigned long long)low + 1ull) * 0x10000ull - 1ull) / span) & 0xFFFFu;
+            // largest s with cdf[s] <= ((value-low+1)*2^16 - 1) / span  <=>  (span*cdf[s]) >> 16 <= value - low
+            const unsigned off = value - low;
             int left = 0, right = max_symbol + 1;
             while (left + 1 < right) {
                 const int mid = (left + right) >> 1;
-                if ((unsigned)ci[mid] <= count) left = mid; else right = mid;
+                if ((unsigned)((span * (unsigned)ci[mid]) >> 16) <= off) left = mid; else right = mid;
             }
             const int s = left;
             ssym[i] = (unsigned char)s;
@@ -238,13 +292,20 @@ __global__ __launch_bounds__(64) void range_decode_lds_kernel(const int32_t *__r
             high = (unsigned)((low - 1u) + (unsigned)((span * c_high) >> 16));
             low = (unsigned)(low + (unsigned)((span * c_low) >> 16));
             for (;;) {
-                if (low >= 0x80000000u || high < 0x80000000u) {
-                    low <<= 1; high <<= 1; high |= 1u; get();
-                } else if (low >= 0x40000000u && high < 0xC0000000u) {
-                    low <<= 1; low &= 0x7FFFFFFFu;
-                    high <<= 1; high |= 0x80000001u;
-                    value -= 0x40000000u;
-                    get();
+                const unsigned x = low ^ high;
+                if ((int)x >= 0) {
+                    const int m = x ? __clz(x) : 32;
+                    const unsigned nbits = getbits(m);
+                    low = m >= 32 ? 0u : low << m;
+                    high = m >= 32 ? 0xFFFFFFFFu : ((high << m) | ones(m));
+                    value = m >= 32 ? nbits : ((value << m) | nbits);
+                } else if ((low & 0x40000000u) && !(high & 0x40000000u)) {
+                    const unsigned t = (~low | high) << 1;
+                    const int k = t ? __clz(t) : 31;
+                    const unsigned nbits = getbits(k);
+                    low = (low << k) & 0x7FFFFFFFu;
+                    high = (high << k) | 0x80000000u | ones(k);
+                    value = ((value << k) ^ 0x80000000u) | nbits;
                 } else
                     break;
             }

@@ -157,3 +157,47 @@ def test_range_coder_device_matches_oracle_bytes_and_round_trips(nets):
         assert np.array_equal(cport.range_decode(ci[b], got), sym[b])
         tot_ideal += -np.log2(pmf[b][np.arange(S * d), sym[b]]).sum() / 8
     assert abs(int(nb.sum()) - tot_ideal) <= 0.01 * tot_ideal + 2 * B
+
+
+def test_range_coder_adversarial_tables_match_oracle_bit_for_bit():
+    """Hand-made CDF tables that force long E3 (underflow) runs, long E1/E2 runs and 1-count
+    symbols: the bulk-renormalising device coder must equal the oracle's literal one-bit-at-a-time
+    restatement byte for byte, and decode back losslessly."""
+    rng = np.random.default_rng(12)
+    B, nsym, Lp = 24, 1024, 8
+    cdf = np.zeros((B, nsym, Lp), dtype=np.int64)
+    sym = np.zeros((B, nsym), dtype=np.int64)
+    for b in range(B):
+        kind = b % 6
+        for i in range(nsym):
+            if kind == 0:      # a sliver around the midpoint: symbol 3 straddles 0x8000 -> E3 runs
+                t = [0, 1, 2, 0x7FFF, 0x8001, 0xFFFD, 0xFFFE]
+                s = 3
+            elif kind == 1:    # 1-count symbols everywhere
+                t = [0] + sorted(rng.choice(np.arange(1, 0xFFFF), size=6, replace=False).tolist())
+                s = int(rng.integers(0, 7))
+            elif kind == 2:    # near-certain symbol, occasional rare ones
+                t = [0, 1, 2, 3, 4, 5, 0xFFFF]
+                s = 5 if rng.random() < 0.97 else int(rng.integers(0, 7))
+            elif kind == 3:    # alternate the two slivers either side of 0x8000
+                t = [0, 0x2000, 0x4000, 0x7FFF, 0x8000, 0x8001, 0xC000]
+                s = 3 + (i & 1)
+            elif kind == 4:    # uniform
+                t = [int(j * 65536 / 7) for j in range(7)]
+                s = int(rng.integers(0, 7))
+            else:              # random monotone table, random symbols
+                t = [0] + sorted(rng.choice(np.arange(1, 0xFFFF), size=6, replace=False).tolist())
+                s = int(rng.integers(0, 7))
+            cdf[b, i, :7] = t
+            cdf[b, i, 7] = 0          # entry Lp-1 is 0x10000 wrapped to 16 bits, as torchac stores it
+            sym[b, i] = s
+    q = (sym - 3).astype(np.float32)
+    ci = torch.from_numpy(cdf.astype(np.int32)).cuda()
+    by, nb = models.range_encode(ci, torch.from_numpy(q).cuda(), 7, cap=8192)
+    assert (nb > 0).all()
+    back = models.range_decode(ci, by, nb, 7)
+    assert np.array_equal(back.cpu().numpy(), q)
+    for b in range(B):
+        want = cport.range_encode(cdf[b].astype(np.int32), sym[b].astype(np.int16))
+        assert bytes(by[b, :int(nb[b])].cpu().numpy()) == want, f"stream {b} (kind {b % 6})"
+        assert np.array_equal(cport.range_decode(cdf[b].astype(np.int32), want), sym[b])
