@@ -82,6 +82,15 @@ PCCX_API int pccx_ball_query(const float *q, int B, int M, const float *ref, int
 PCCX_API int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, float *d2, int32_t *nn,
                           void *stream);
 
+/* D2 (point-to-plane) PSNR support (eval.py:58-60,73-81).  pccx_estimate_normals: PCA normal of
+ * every point over its K neighbours nbr (B,N,K) int64 (e.g. pccx_knn with K=30, as open3d's
+ * estimate_normals(KDTreeSearchParamKNN(knn=30))); unoriented.  pccx_point_plane_err:
+ * err[b,i] = ((X[b,i] - Y[b,nn[b,i]]) . normals_Y[b,nn[b,i]])^2. */
+PCCX_API int pccx_estimate_normals(const float *xyz, int B, int N, const int64_t *nbr, int K, float *normals,
+                                   void *stream);
+PCCX_API int pccx_point_plane_err(const float *X, int B, int P, const float *Y, const float *normals_Y, int Q,
+                                  const int32_t *nn, float *err, void *stream);
+
 /* ---- integer path: octree of the S sampled centres ------------------------------------------- */
 
 /* Bytes needed per cloud for the bit array (one byte per bit) of pccx_octree_encode. */

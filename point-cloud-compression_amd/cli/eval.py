@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """eval.py with the reference's command line (eval.py:20-35): D1 (point-to-point) PSNR, bpp from the
-three file sizes, Chamfer distance on min-max-normalised clouds, uniformity coefficient -> CSV with the
-reference's columns.  D2 (point-to-plane, needs open3d-style PCA normals) is not built yet: its column
-is written as NaN."""
+three file sizes, D2 (point-to-plane) PSNR with 30-NN PCA normals, Chamfer distance on min-max-normalised
+clouds, uniformity coefficient -> CSV with the reference's columns."""
 import argparse
 import os
 from glob import glob
@@ -47,7 +46,7 @@ def main():
         a = torch.from_numpy(plyio.read_point_cloud(f))[None].to(args.device)
         b = torch.from_numpy(plyio.read_point_cloud(decomp_f))[None].to(args.device)
         bits = sum(os.stat(os.path.join(args.compressed_path, name + e)).st_size * 8 for e in ('.s.bin', '.p.bin', '.c.bin'))
-        rows.append(dict(filename=name, p2pointPSNR=round(float(codec.d1_psnr(a, b)[0]), 3), p2planePSNR=float('nan'),
+        rows.append(dict(filename=name, p2pointPSNR=round(float(codec.d1_psnr(a, b)[0]), 3), p2planePSNR=round(float(codec.d2_psnr(a, b)[0]), 3),
                          chamfer_distance=float(codec.normalized_chamfer(a, b)[0]), n_points_input=a.shape[1],
                          n_points_output=b.shape[1], bpp=bits / a.shape[1],                 # eval.py:189
                          **{'uniformity coefficient': round(calc_uc(a, b), 3)}))

@@ -279,3 +279,105 @@ extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q,
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// D2 (point-to-plane) support for eval.py:58-60,73-81.
+//   normals_pca_kernel : per point, PCA of its K nearest neighbours (open3d estimate_normals with
+//                        KDTreeSearchParamKNN): fp64 covariance, analytic symmetric 3x3 eigen-solve,
+//                        eigenvector of the smallest eigenvalue.  The sign is arbitrary (as open3d's
+//                        unoriented normals); D2 squares the projection.  PARITY UNPINNED vs open3d.
+//   plane_err_kernel   : ((p - q) . n_q)^2 for every reconstructed p and its nearest original q.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ void normals_pca_kernel(const float *__restrict__ xyz, int N, const int64_t *__restrict__ nbr, int K,
+                                   float *__restrict__ normals)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *p = xyz + (size_t)b * N * 3;
+    const int64_t *nb = nbr + ((size_t)b * N + i) * K;
+    double m[3] = {0, 0, 0};
+    for (int k = 0; k < K; ++k)
+        for (int a = 0; a < 3; ++a) m[a] += (double)p[3 * nb[k] + a];
+    for (int a = 0; a < 3; ++a) m[a] /= K;
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    for (int k = 0; k < K; ++k) {
+        const double x = (double)p[3 * nb[k]] - m[0], y = (double)p[3 * nb[k] + 1] - m[1], z = (double)p[3 * nb[k] + 2] - m[2];
+        c00 += x * x; c01 += x * y; c02 += x * z; c11 += y * y; c12 += y * z; c22 += z * z;
+    }
+    c00 /= K; c01 /= K; c02 /= K; c11 /= K; c12 /= K; c22 /= K;
+    // smallest eigenvalue of the symmetric matrix (trigonometric closed form), on a scale-normalised copy
+    const double scale = fmax(fmax(fabs(c00), fabs(c11)), fmax(fabs(c22), fmax(fabs(c01), fmax(fabs(c02), fabs(c12)))));
+    double n[3] = {0, 0, 1};
+    if (scale > 0) {
+        const double a00 = c00 / scale, a01 = c01 / scale, a02 = c02 / scale, a11 = c11 / scale, a12 = c12 / scale, a22 = c22 / scale;
+        const double q = (a00 + a11 + a22) / 3;
+        const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+        const double p2 = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + 2 * p1;
+        double lam = q;
+        if (p2 > 0) {
+            const double pp = sqrt(p2 / 6);
+            const double b00 = (a00 - q) / pp, b01 = a01 / pp, b02 = a02 / pp, b11 = (a11 - q) / pp, b12 = a12 / pp, b22 = (a22 - q) / pp;
+            double r = (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02)) / 2;
+            r = r < -1 ? -1 : (r > 1 ? 1 : r);
+            const double phi = acos(r) / 3;
+            lam = q + 2 * pp * cos(phi + 2.0943951023931953);       // smallest eigenvalue (phi + 2*pi/3)
+        }
+        // eigenvector: the largest cross product of two rows of (A - lam I)
+        const double r0[3] = {a00 - lam, a01, a02}, r1[3] = {a01, a11 - lam, a12}, r2[3] = {a02, a12, a22 - lam};
+        double c0[3], c1[3], c2[3];
+        cross3(r0, r1, c0); cross3(r0, r2, c1); cross3(r1, r2, c2);
+        const double d0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+        const double d1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+        const double d2 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
+        const double *best = d0 >= d1 && d0 >= d2 ? c0 : (d1 >= d2 ? c1 : c2);
+        const double dm = fmax(d0, fmax(d1, d2));
+        if (dm > 0) {
+            const double inv = 1.0 / sqrt(dm);
+            n[0] = best[0] * inv; n[1] = best[1] * inv; n[2] = best[2] * inv;
+        }
+    }
+    float *o = normals + ((size_t)b * N + i) * 3;
+    o[0] = (float)n[0]; o[1] = (float)n[1]; o[2] = (float)n[2];
+}
+
+extern "C" int pccx_estimate_normals(const float *xyz, int B, int N, const int64_t *nbr, int K, float *normals, void *stream)
+{
+    PCCX_CHECK_ARG(xyz && nbr && normals, "pccx_estimate_normals: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && N >= 1 && K >= 1 && B <= 65535, "pccx_estimate_normals: bad shape");
+    if (B == 0) return PCCX_OK;
+    hipLaunchKernelGGL(normals_pca_kernel, dim3((N + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, xyz, N, nbr, K, normals);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+__global__ void plane_err_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, const float *__restrict__ nY,
+                                 int Q, const int32_t *__restrict__ nn, float *__restrict__ err)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float *x = X + ((size_t)b * P + i) * 3;
+    const int j = nn[(size_t)b * P + i];
+    const float *y = Y + ((size_t)b * Q + j) * 3, *n = nY + ((size_t)b * Q + j) * 3;
+    const double d = (double)(x[0] - y[0]) * n[0] + (double)(x[1] - y[1]) * n[1] + (double)(x[2] - y[2]) * n[2];
+    err[(size_t)b * P + i] = (float)(d * d);
+}
+
+extern "C" int pccx_point_plane_err(const float *X, int B, int P, const float *Y, const float *normals_Y, int Q,
+                                    const int32_t *nn, float *err, void *stream)
+{
+    PCCX_CHECK_ARG(X && Y && normals_Y && nn && err, "pccx_point_plane_err: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1 && B <= 65535, "pccx_point_plane_err: bad shape");
+    if (B == 0) return PCCX_OK;
+    hipLaunchKernelGGL(plane_err_kernel, dim3((P + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, normals_Y, Q, nn, err);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

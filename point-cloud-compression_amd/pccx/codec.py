@@ -115,6 +115,15 @@ def d1_psnr(orig, recon):
     return 10 * torch.log10(diag2 / mse)
 
 
+def d2_psnr(orig, recon, knn=30):
+    """eval.py:43-98 D2 (point-to-plane) PSNR: normals of the ORIGINAL by 30-NN PCA, error = squared
+    projection of (recon - nearest original) on that normal.  (B,) f64."""
+    normals = ops.estimate_normals(orig, knn)
+    mse = ops.point_plane_err(recon, orig, normals).double().mean(dim=1)
+    rng = orig.amax(dim=1).double() - orig.amin(dim=1).double()
+    return 10 * torch.log10((rng * rng).sum(dim=1) / mse)
+
+
 def normalized_chamfer(orig, recon):
     """eval.py:198-205: both clouds min-max normalised by the ORIGINAL's global min/max, then
     pytorch3d chamfer_distance.  Returns (B,) f64."""

@@ -169,6 +169,27 @@ def nn_dist(x, y, return_idx=False):
     return (d2, nn) if return_idx else d2
 
 
+def estimate_normals(xyz, knn=30):
+    """open3d estimate_normals(KDTreeSearchParamKNN(knn)) (eval.py:59-60): unoriented PCA normals (B,N,3)."""
+    xyz = _f32c(xyz, "estimate_normals")
+    B, N, _ = xyz.shape
+    idx = knn_points(xyz, xyz, min(knn, N), return_nn=False).idx
+    out = torch.empty(B, N, 3, device=xyz.device, dtype=torch.float32)
+    _lib.call("pccx_estimate_normals", xyz.data_ptr(), B, N, idx.data_ptr(), idx.shape[2], out.data_ptr(), _stream())
+    return out
+
+
+def point_plane_err(x, y, normals_y):
+    """Squared projection of (x - nearest y) on that y's normal, eval.py:79-81: (B,P)."""
+    x, y, normals_y = _f32c(x, "point_plane_err.x"), _f32c(y, "point_plane_err.y"), _f32c(normals_y, "point_plane_err.n")
+    B, P, _ = x.shape
+    _, nn = nn_dist(x, y, return_idx=True)
+    err = torch.empty(B, P, device=x.device, dtype=torch.float32)
+    _lib.call("pccx_point_plane_err", x.data_ptr(), B, P, y.data_ptr(), normals_y.data_ptr(), y.shape[1], nn.data_ptr(),
+              err.data_ptr(), _stream())
+    return err
+
+
 def chamfer_distance(x, y, batch_reduction="mean"):
     """pytorch3d.loss.chamfer_distance defaults (AE.py:67, eval.py:204): squared distances,
     point mean, both directions summed; returns (value, None)."""

@@ -108,3 +108,33 @@ def test_reference_mode_rejects_other_S(nets):
     cd = codec.Codec(ae, prob, K=K, octree_mode="reference")
     with pytest.raises(ValueError):
         cd.compress(torch.zeros(1, 4096, 3).cuda(), [0])
+
+
+def test_d2_psnr_and_normals_vs_float64_pca():
+    """eval.py:58-60,73-93 D2: 30-NN PCA normals (open3d semantics, PARITY UNPINNED: open3d is absent)
+    against a float64 numpy covariance + eigh, then the point-to-plane PSNR within 0.01 dB."""
+    from pccx import ops
+    orig = cloud_synth.cad_cloud(8, 4096)
+    rng = np.random.default_rng(1)
+    recon = (orig + rng.normal(0, 2e-3, orig.shape)).astype(np.float32)[rng.permutation(4096)[:3000]]
+    o, r = torch.from_numpy(orig)[None].cuda(), torch.from_numpy(recon)[None].cuda()
+    normals = ops.estimate_normals(o, 30)[0].cpu().numpy()
+    _, idx = cport.knn(orig, orig, 30)
+    want = np.zeros_like(normals, dtype=np.float64)
+    gap = np.zeros(orig.shape[0])
+    for i in range(orig.shape[0]):
+        nb = orig[idx[i]].astype(np.float64)
+        w, v = np.linalg.eigh(np.cov(nb.T, bias=True))
+        want[i], gap[i] = v[:, 0], (w[1] - w[0]) / max(w[2], 1e-30)
+    ok = gap > 1e-3                                   # well-defined normals (planar neighbourhoods)
+    assert ok.mean() > 0.8
+    dots = np.abs((normals[ok] * want[ok]).sum(1))
+    assert dots.min() > 1 - 1e-6
+    d2, nn = cport.nn_dist(recon, orig)
+    err = (((recon - orig[nn]).astype(np.float64) * want[nn]).sum(1)) ** 2
+    rngv = orig.max(0).astype(np.float64) - orig.min(0).astype(np.float64)
+    want_psnr = 10 * np.log10((rngv ** 2).sum() / err[ok[nn]].mean())
+    got_err = ops.point_plane_err(r, o, torch.from_numpy(normals)[None].cuda())[0].cpu().numpy().astype(np.float64)
+    got_psnr = 10 * np.log10((rngv ** 2).sum() / got_err[ok[nn]].mean())
+    assert abs(got_psnr - want_psnr) < 0.01
+    assert np.isfinite(float(codec.d2_psnr(o, r)[0]))
