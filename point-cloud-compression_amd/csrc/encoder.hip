@@ -55,9 +55,6 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
     // so pass 1 keeps just the 16 smallest distances sorted (one v_med3 per slot per candidate) and
     // pass 2 collects the indices below the 16th distance, plus ties at it in index order -- the
     // same set as the oracle's (distance, index) sort.
-#ifdef SA_SKIP_KNN
-    for (int i = tid; i < K; i += 256) for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)((i + s) % K);
-#else
     for (int i = tid; i < K; i += 256) {
         const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
         float td[16];
@@ -84,11 +81,7 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
             ties += tie ? 1 : 0;
         }
     }
-#endif
     __syncthreads();
-
-    // The MFMA phase outranks other workgroups' kNN phases (pure VALU) in issue arbitration.
-    __builtin_amdgcn_s_setprio(3);
 
     // conv0 (3 -> 32) also runs on the matrix core: one K=4 MFMA per 16 output channels with the bias
     // folded in as a fourth input of 1.0.  A = [w0 w1 w2 b] of channel 16*kt + (lane&15) at k = lane>>4;
