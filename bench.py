@@ -126,16 +126,24 @@ def main():
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
     ap.add_argument("--cpu-clouds", type=int, default=64, help="max clouds in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dist_backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the tiny collectives live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from pccx import codec, models, ops, synth
 
@@ -174,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_timer(None)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
@@ -183,7 +191,7 @@ def main():
     psnr = float(codec.d1_psnr(clouds, out).mean())
     if world > 1:
         # the only data-path-adjacent exchange: tiny per-rank quality summaries
-        summ = torch.tensor([bpp, psnr], device=dev, dtype=torch.float64)
+        summ = torch.tensor([bpp, psnr], device=cdev, dtype=torch.float64)
         gathered = [torch.zeros_like(summ) for _ in range(world)]
         dist.all_gather(gathered, summ)
         bpp, psnr = [float(x) for x in torch.stack(gathered).mean(0)]

@@ -188,6 +188,7 @@ extern "C" int pccx_ae_decode(const float *latent_q, int P, int d, int k, const 
                               float *patches_out, float scale, const float *centres, const float *nrm_center,
                               const float *nrm_longest, int S, double margin, float *pc_out, void *stream)
 {
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(latent_q && dec_blob && workspace, "pccx_ae_decode: null pointer");
     PCCX_CHECK_ARG(patches_out || pc_out, "pccx_ae_decode: need patches_out and/or pc_out");
     PCCX_CHECK_ARG(P >= 0 && d >= 1 && d <= 16 && k >= 1 && k <= 65535, "pccx_ae_decode: unsupported P=%d d=%d k=%d", P, d, k);

@@ -278,6 +278,7 @@ static int launch_pn(const float *patches, const float *feat, int P, int K, cons
 
 extern "C" int pccx_sa_forward(const float *patches, int P, int K, const float *enc_blob, float *feat, void *stream)
 {
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(patches && enc_blob && feat, "pccx_sa_forward: null pointer");
     CHECK_PK("pccx_sa_forward");
     if (P == 0) return PCCX_OK;
@@ -287,6 +288,7 @@ extern "C" int pccx_sa_forward(const float *patches, int P, int K, const float *
 extern "C" int pccx_pn_forward(const float *patches, const float *feat, int P, int K, const float *enc_blob, int d, int L,
                                float *latent_raw, float *latent, float *latent_q, void *stream)
 {
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(patches && feat && enc_blob && latent_raw && latent && latent_q, "pccx_pn_forward: null pointer");
     CHECK_PK("pccx_pn_forward");
     PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_pn_forward: unsupported d=%d L=%d", d, L);
@@ -297,6 +299,7 @@ extern "C" int pccx_pn_forward(const float *patches, const float *feat, int P, i
 extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *enc_blob, int d, int L, float *feat_ws,
                               float *latent_raw, float *latent, float *latent_q, void *stream)
 {
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(patches && enc_blob && feat_ws && latent_raw && latent && latent_q, "pccx_ae_encode: null pointer");
     CHECK_PK("pccx_ae_encode");
     PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode: unsupported d=%d L=%d", d, L);

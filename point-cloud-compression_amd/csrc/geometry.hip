@@ -100,6 +100,7 @@ __global__ void denormalize_kernel(const float *__restrict__ pc, int N, float on
 extern "C" int pccx_normalize(const float *pc, int B, int N, double margin, float *out, float *center, float *longest,
                               void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(pc && out && center && longest, "pccx_normalize: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1, "pccx_normalize: bad shape B=%d N=%d", B, N);
     if (B == 0) return PCCX_OK;
@@ -112,6 +113,7 @@ extern "C" int pccx_normalize(const float *pc, int B, int N, double margin, floa
 extern "C" int pccx_denormalize(const float *pc, int B, int N, double margin, const float *center, const float *longest,
                                 float *out, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(pc && out && center && longest, "pccx_denormalize: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1, "pccx_denormalize: bad shape B=%d N=%d", B, N);
     if (B == 0) return PCCX_OK;
@@ -142,6 +144,7 @@ __global__ void gather_kernel(const float *__restrict__ points, int N, int C, co
 
 extern "C" int pccx_gather(const float *points, int B, int N, int C, const int64_t *idx, int M, float *out, void *stream)
 {
+    if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(points && idx && out, "pccx_gather: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && C >= 1 && M >= 0, "pccx_gather: bad shape");
     if (B == 0 || M == 0) return PCCX_OK;
@@ -298,6 +301,7 @@ static int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t 
 extern "C" int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_t *start_idx, int64_t *idx_out,
                         float *workspace, void *stream)
 {
+    if (B == 0 || npoint == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(xyz && idx_out, "pccx_fps: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && npoint >= 0, "pccx_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
     if (B == 0 || npoint == 0) return PCCX_OK;

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
 extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, int K, float *dists, int64_t *idx,
                         float *nn, float patch_scale, void *stream)
 {
+    if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(q && ref && dists && idx, "pccx_knn: null pointer");
     PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1, "pccx_knn: bad shape B=%d M=%d N=%d", B, M, N);
     PCCX_CHECK_ARG(K >= 1 && K <= N && K <= 1024, "pccx_knn: need 1 <= K <= min(N,1024), got K=%d N=%d", K, N);
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
 extern "C" int pccx_ball_query(const float *q, int B, int M, const float *ref, int N, int K, float radius, float *dists,
                                int64_t *idx, void *stream)
 {
+    if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(q && ref && dists && idx, "pccx_ball_query: null pointer");
     PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1 && K >= 1, "pccx_ball_query: bad shape");
     PCCX_CHECK_ARG(B <= 65535, "pccx_ball_query: B=%d > 65535 unsupported", B);
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
 
 extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, float *d2, int32_t *nn, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(X && Y && d2, "pccx_nn_dist: null pointer");
     PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1, "pccx_nn_dist: bad shape");
     PCCX_CHECK_ARG(B <= 65535, "pccx_nn_dist: B=%d > 65535 unsupported", B);
@@ -350,6 +353,7 @@ __global__ void normals_pca_kernel(const float *__restrict__ xyz, int N, const i
 
 extern "C" int pccx_estimate_normals(const float *xyz, int B, int N, const int64_t *nbr, int K, float *normals, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(xyz && nbr && normals, "pccx_estimate_normals: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && K >= 1 && B <= 65535, "pccx_estimate_normals: bad shape");
     if (B == 0) return PCCX_OK;
@@ -374,6 +378,7 @@ __global__ void plane_err_kernel(const float *__restrict__ X, int P, const float
 extern "C" int pccx_point_plane_err(const float *X, int B, int P, const float *Y, const float *normals_Y, int Q,
                                     const int32_t *nn, float *err, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(X && Y && normals_Y && nn && err, "pccx_point_plane_err: null pointer");
     PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1 && B <= 65535, "pccx_point_plane_err: bad shape");
     if (B == 0) return PCCX_OK;

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
 extern "C" int pccx_linear(const float *x, int M, int K, int ldx, const float *wp, const float *bias, int N, int relu,
                            float *out, int ldo, void *stream)
 {
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && wp && out, "pccx_linear: null pointer");
     PCCX_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && ldx >= K && ldo >= N, "pccx_linear: bad shape M=%d K=%d N=%d ldx=%d ldo=%d", M,
                    K, N, ldx, ldo);
@@ -140,6 +141,7 @@ __global__ void group_max_kernel(const float *__restrict__ x, long long G, int K
 
 extern "C" int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream)
 {
+    if (G == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && out && G >= 0 && Kn >= 1 && C >= 1, "pccx_group_max: bad arguments");
     if (G == 0) return PCCX_OK;
     long long blocks = ((long long)G * C + 255) / 256;
@@ -162,6 +164,7 @@ __global__ void sigmoid_spread_kernel(const float *__restrict__ x, long n, float
 
 extern "C" int pccx_sigmoid_spread(const float *x, int64_t n, int L, int do_round, float *y, void *stream)
 {
+    if (n == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && y && n >= 0 && L >= 1, "pccx_sigmoid_spread: bad arguments");
     if (n == 0) return PCCX_OK;
     long blocks = (n + 255) / 256;
@@ -180,6 +183,7 @@ __global__ void round_kernel(const float *__restrict__ x, long n, float *__restr
 
 extern "C" int pccx_round(const float *x, int64_t n, float *y, void *stream)
 {
+    if (n == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && y && n >= 0, "pccx_round: bad arguments");
     if (n == 0) return PCCX_OK;
     long blocks = (n + 255) / 256;
@@ -207,6 +211,7 @@ __global__ void quantize_st_kernel(const float *__restrict__ x, long n, float qm
 extern "C" int pccx_quantize_st(const float *x, int64_t n, float qmin, float qmax, int levels, float *y_q, float *y_deq,
                                 void *stream)
 {
+    if (n == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && y_q && n >= 0 && levels >= 2 && qmax > qmin, "pccx_quantize_st: bad arguments");
     if (n == 0) return PCCX_OK;
     long blocks = (n + 255) / 256;

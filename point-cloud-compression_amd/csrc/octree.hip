@@ -159,6 +159,7 @@ extern "C" int pccx_octree_bits_capacity(int S) { return 1 + 8 * S * OCT_MAX_DEP
 extern "C" int pccx_octree_encode(const float *centres, int B, int S, int N, double min_bpp, uint8_t *bits, int32_t *nbits,
                                   int32_t *depth, uint8_t *bytes, int32_t *nbytes, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(centres && bits && nbits && depth && bytes && nbytes, "pccx_octree_encode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && S >= 1 && S <= 1024 && N >= 1, "pccx_octree_encode: need 1 <= S <= 1024, N >= 1 (S=%d N=%d)", S, N);
     if (B == 0) return PCCX_OK;
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void octree_decode_full_kernel(const uint8_t *
 extern "C" int pccx_octree_decode(const uint8_t *bytes, int stride, const int32_t *nbytes, int B, int mode, int S_out,
                                   float *out, int32_t *count, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(bytes && nbytes && out, "pccx_octree_decode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && stride >= 1 && S_out >= 1, "pccx_octree_decode: bad shape");
     PCCX_CHECK_ARG(mode == 0 || mode == 1, "pccx_octree_decode: mode must be 0 (reference) or 1 (full)");

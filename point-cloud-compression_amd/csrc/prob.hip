@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__res
 extern "C" int pccx_prob_forward(const float *centres, int B, int S, int d, int L, const float *prob_blob, float *pmf,
                                  float *cdf, int32_t *cdf_int, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(centres && prob_blob, "pccx_prob_forward: null pointer");
     PCCX_CHECK_ARG(pmf || cdf || cdf_int, "pccx_prob_forward: no output requested");
     PCCX_CHECK_ARG(B >= 0 && S >= 16 && S % 16 == 0, "pccx_prob_forward: need S %% 16 == 0 (S=%d)", S);

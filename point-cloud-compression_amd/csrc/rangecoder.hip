@@ -318,6 +318,7 @@ __global__ __launch_bounds__(64) void range_decode_lds_kernel(const int32_t *__r
 extern "C" int pccx_range_encode(const int32_t *cdf_int, const float *latent_q, int B, int nsym, int L, uint8_t *out, int cap,
                                  int32_t *nbytes, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(cdf_int && latent_q && out && nbytes, "pccx_range_encode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && cap >= 8, "pccx_range_encode: bad shape");
     if (B == 0) return PCCX_OK;
@@ -337,6 +338,7 @@ extern "C" int pccx_range_encode(const int32_t *cdf_int, const float *latent_q, 
 extern "C" int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int stride, const int32_t *nbytes, int B, int nsym,
                                  int L, float *latent_q, void *stream)
 {
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(cdf_int && in && nbytes && latent_q, "pccx_range_decode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && stride >= 1, "pccx_range_decode: bad shape");
     if (B == 0) return PCCX_OK;

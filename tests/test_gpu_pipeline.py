@@ -138,3 +138,49 @@ def test_d2_psnr_and_normals_vs_float64_pca():
     got_psnr = 10 * np.log10((rngv ** 2).sum() / got_err[ok[nn]].mean())
     assert abs(got_psnr - want_psnr) < 0.01
     assert np.isfinite(float(codec.d2_psnr(o, r)[0]))
+
+
+@pytest.mark.parametrize("Kc,dc,Lc,N", [(128, 16, 7, 8192), (512, 16, 7, 8192), (64, 8, 5, 2048), (256, 12, 9, 4096)])
+def test_other_patch_sizes_and_bottlenecks_full_mode(Kc, dc, Lc, N):
+    """The other --K / --d / --L settings of compress.py:30-34 (S != 64 needs octree_mode='full'; the
+    reference itself asserts there, compress.py:102): GPU vs the oracle's own full-mode pipeline."""
+    kc = Kc // 2
+    ae = models.AE(Kc, kc, dc, Lc)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, 3, last_gain={"pn.mlp_Modules.3.0": 40.0}))
+    prob = models.ConditionalProbabilityModel(Lc, dc)
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, 4, gain=2.0))
+    oae = ref_model.AE(Kc, kc, dc, Lc).eval()
+    oae.load_state_dict(ae.state_dict())
+    oprob = ref_model.ConditionalProbabilityModel(Lc, dc).eval()
+    oprob.load_state_dict(prob.state_dict())
+    S = N * 2 // Kc
+    clouds = cloud_synth.cad_batch(500 + Kc, 2, N)
+    starts = np.array([1, N - 1])
+    cd = codec.Codec(ae.pack("cuda"), prob.pack("cuda"), K=Kc, octree_mode="full")
+    comp = cd.compress(torch.from_numpy(clouds).cuda(), starts, keep_extras=True)
+    out = cd.decompress(comp, S=S)
+    assert out.shape == (2, S * kc, 3)
+    torch.set_num_threads(8)
+    for b in range(2):
+        o, _ = ref_pipeline.compress_one(clouds[b], oae, oprob, int(starts[b]), K=Kc, octree_mode="full")
+        s, p, c = comp.files(b)
+        assert s == o["s"] and c == o["c"]
+        assert np.array_equal(comp.extras["rec_sampled"][b].cpu().numpy(), o["rec_sampled"])
+        lat = comp.extras["latent"].view(2, S, dc)[b].cpu().numpy()
+        np.testing.assert_allclose(lat, o["latent"], rtol=0, atol=5e-5)
+        q = comp.extras["latent_q"].view(2, S, dc)[b].cpu().numpy()
+        bad = q != o["latent_q"]
+        assert (np.abs(o["latent"][bad] - np.floor(o["latent"][bad]) - 0.5) < 1e-4).all()
+        want, _ = ref_pipeline.decompress_one(s, p, c, oae, oprob, octree_mode="full", latent_q_override=q.copy())
+        np.testing.assert_allclose(out[b].cpu().numpy(), want, rtol=0, atol=2e-5 * float(comp.c[b, 3]))
+
+
+def test_empty_batch_is_a_no_op(nets):
+    ae, prob, _, _ = nets
+    from pccx import ops
+    z = torch.zeros(0, 8192, 3).cuda()
+    xn, c, l = ops.normalize(z)
+    assert xn.shape == (0, 8192, 3) and c.shape == (0, 3)
+    assert ops.farthest_point_sample_batch(z, 64, torch.zeros(0, dtype=torch.int32)).shape == (0, 64)
+    r, lt, q = ae.encode(torch.zeros(0, K, 3).cuda())
+    assert q.shape == (0, d)
