@@ -57,6 +57,12 @@ PCCX_API int pccx_denormalize(const float *pc, int B, int N, double margin, cons
 PCCX_API int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_t *start_idx,
                       int64_t *idx_out, float *workspace, void *stream);
 
+/* 63-bit Morton keys over the bounding box [lo, lo+extent]^3 (lo_host: 3 floats on the HOST), used to
+ * cut clouds larger than one block into spatially compact 8192-point blocks (BASELINE configs[3]).
+ * xyz: (n,3) f32; keys: (n) int64. */
+PCCX_API int pccx_morton_keys(const float *xyz, int64_t n, const float *lo_host, float extent, int64_t *keys,
+                              void *stream);
+
 /* pn_kit.index_points (pn_kit.py:332-360) / pytorch3d knn_gather (pointnet_sa_module.py:28):
  * out[b,m,:] = points[b, idx[b,m], :].  points: (B,N,C); idx: (B,M) int64 (negative -> row 0,
  * the clamp of pointnet_sa_module.py:27); out: (B,M,C). */

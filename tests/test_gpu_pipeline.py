@@ -184,3 +184,32 @@ def test_empty_batch_is_a_no_op(nets):
     assert ops.farthest_point_sample_batch(z, 64, torch.zeros(0, dtype=torch.int32)).shape == (0, 64)
     r, lt, q = ae.encode(torch.zeros(0, K, 3).cuda())
     assert q.shape == (0, d)
+
+
+def test_large_cloud_block_partition_and_sharding(nets):
+    """configs[3]: a 100k-point room-like cloud is cut into 8192-point Morton blocks (S stays 64); the
+    partition is a permutation, blocks are spatially compact, and 2-way sharding covers every block."""
+    from pccx import large
+    ae, prob, _, _ = nets
+    rng = np.random.default_rng(100)
+    N = 100_000
+    walls = [np.stack([rng.random(N // 5) * 8, rng.random(N // 5) * 6, np.full(N // 5, z)], 1) for z in (0.0, 3.0)]
+    walls += [np.stack([rng.random(N // 5) * 8, np.full(N // 5, y), rng.random(N // 5) * 3], 1) for y in (0.0, 6.0)]
+    walls += [np.stack([2 + rng.random(N // 5), 2 + rng.random(N // 5) * 2, rng.random(N // 5)], 1)]
+    pc = torch.from_numpy(np.concatenate(walls).astype(np.float32)).cuda()
+    blocks, order, n_last = large.split_blocks(pc)
+    nb = (N + 8191) // 8192
+    assert blocks.shape == (nb, 8192, 3) and n_last == N - (nb - 1) * 8192
+    assert torch.equal(torch.sort(order).values, torch.arange(N, device=pc.device))        # a permutation
+    assert torch.equal(blocks.view(-1, 3)[:N], pc[order])
+    ext = (blocks.amax(1) - blocks.amin(1)).amax(1)
+    assert float(ext.median()) < 0.6 * float((pc.amax(0) - pc.amin(0)).max())            # compact blocks
+    cd = codec.Codec(ae, prob, K=K, octree_mode="reference")
+    seen = []
+    for rank in range(2):
+        parts, nblk, _, _ = large.compress_large(cd, pc, rank=rank, world=2, batch=4)
+        for ids, comp in parts:
+            out = cd.decompress(comp)
+            assert out.shape == (len(ids), 64 * k, 3) and torch.isfinite(out).all()
+            seen += ids
+    assert sorted(seen) == list(range(nb))
