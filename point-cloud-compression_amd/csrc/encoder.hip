@@ -245,12 +245,8 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
 static int launch_sa(const float *patches, int P, int K, const float *enc_blob, float *feat, hipStream_t st)
 {
     const size_t sa_lds = (size_t)(2 * 4 * 64 + 4 * 8 * 64) * 16 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(sa_forward_kernel, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, feat);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;

@@ -287,12 +287,8 @@ static int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t 
 {
     const int use_lds = (size_t)N * 12 + 256 <= 150 * 1024;
     const size_t shmem = 256 + (use_lds ? (size_t)N * 12 : 0);
-    static bool attr_set = false;   // per template instance
-    if (!attr_set) {
-        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<PPT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<PPT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(fps_kernel<PPT>, dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out, use_lds);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;

@@ -163,12 +163,8 @@ extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, i
     int Kp = 2;
     while (Kp < K) Kp <<= 1;
     size_t shmem = (size_t)Kp * 8 + (size_t)N * 4 + (256 + 4 + 3 + 1) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(knn_kernel, dim3(M, B), dim3(256), shmem, (hipStream_t)stream, q, M, ref, N, K, Kp, dists, idx, nn,
                        patch_scale);
     PCCX_CHECK_LAUNCH();

@@ -35,12 +35,19 @@ class Compressed:
     def bpp(self):
         return self.bits().double() / self.n_points
 
+    def to_host(self):
+        """One device->host transfer of everything the three files need (cached)."""
+        if getattr(self, "_host", None) is None:
+            sn, pn = self.s_nbytes.cpu().numpy(), self.p_nbytes.cpu().numpy()
+            sb = self.s_bytes[:, :max(int(sn.max()), 1)].cpu().numpy() if len(sn) else np.zeros((0, 1), np.uint8)
+            pb = self.p_bytes[:, :max(int(pn.max()), 1)].cpu().numpy() if len(pn) else np.zeros((0, 1), np.uint8)
+            self._host = (sb, sn, pb, pn, self.c.cpu().numpy().astype(np.float32))
+        return self._host
+
     def files(self, b):
         """The three byte strings compress.py:139-152 writes for cloud b."""
-        s = bytes(self.s_bytes[b, :int(self.s_nbytes[b])].cpu().numpy())
-        p = bytes(self.p_bytes[b, :int(self.p_nbytes[b])].cpu().numpy())
-        c = self.c[b].cpu().numpy().astype(np.float32).tobytes()
-        return s, p, c
+        sb, sn, pb, pn, c = self.to_host()
+        return bytes(sb[b, :sn[b]]), bytes(pb[b, :pn[b]]), c[b].tobytes()
 
 
 class Codec:

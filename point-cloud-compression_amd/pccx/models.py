@@ -52,6 +52,20 @@ def _host(t):
     return t.detach().to("cpu", torch.float32).contiguous()
 
 
+_WS = {}
+
+
+def workspace(tag, numel, device):
+    """Persistent scratch buffers (HBM is 288 GB: keep the big intermediates resident instead of going
+    through the allocator every call).  Stream-ordered reuse is safe: every consumer of a buffer is
+    enqueued before its next producer on the same stream."""
+    key = (tag, str(device))
+    t = _WS.get(key)
+    if t is None or t.numel() < numel:
+        _WS[key] = t = torch.empty(int(numel), device=device, dtype=torch.float32)
+    return t[:numel]
+
+
 def _pack(fn_name, size, tensors, ints):
     keep = [_host(t) for t in tensors]
     blob = torch.zeros(size, dtype=torch.float32)
@@ -115,7 +129,7 @@ class AE(nn.Module):
         x = _f32c(patches, "AE.encode")
         P, K, _ = x.shape
         enc, _ = self._blobs(x.device)
-        ws = torch.empty(P * K * 128, device=x.device, dtype=torch.float32)
+        ws = workspace("sa_feat", P * K * 128, x.device)
         outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
         with stage("sa_forward"):
             _lib.call("pccx_sa_forward", x.data_ptr(), P, K, enc.data_ptr(), ws.data_ptr(), _stream())
@@ -130,7 +144,7 @@ class AE(nn.Module):
         q = _f32c(latent_q, "AE.decode")
         P = q.shape[0]
         _, dec = self._blobs(q.device)
-        ws = torch.empty(_lib.load().pccx_ae_decode_workspace_floats(P), device=q.device, dtype=torch.float32)
+        ws = workspace("dec_h2", _lib.load().pccx_ae_decode_workspace_floats(P), q.device)
         if centres is None:
             out = torch.empty(P, self.k, 3, device=q.device, dtype=torch.float32)
             _lib.call("pccx_ae_decode", q.data_ptr(), P, self.d, self.k, dec.data_ptr(), ws.data_ptr(), out.data_ptr(),
