@@ -88,6 +88,12 @@ PCCX_API int pccx_ball_query(const float *q, int B, int M, const float *ref, int
 PCCX_API int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, float *d2, int32_t *nn,
                           void *stream);
 
+/* Backward of chamfer_distance (batch mean of both directions' point means; AE.py:57-70,
+ * pppe_pcd_ae.py:817-838) for fixed argmins nn_xy (B,P), nn_yx (B,Q) from pccx_nn_dist:
+ * gX (B,P,3), gY (B,Q,3) receive grad_out * dL/dX, dL/dY (buffers are zeroed here). */
+PCCX_API int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
+                               const int32_t *nn_yx, float grad_out, float *gX, float *gY, void *stream);
+
 /* D2 (point-to-plane) PSNR support (eval.py:58-60,73-81).  pccx_estimate_normals: PCA normal of
  * every point over its K neighbours nbr (B,N,K) int64 (e.g. pccx_knn with K=30, as open3d's
  * estimate_normals(KDTreeSearchParamKNN(knn=30))); unoriented.  pccx_point_plane_err:

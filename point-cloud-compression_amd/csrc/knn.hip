@@ -382,3 +382,51 @@ extern "C" int pccx_point_plane_err(const float *X, int B, int P, const float *Y
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Gradient of pytorch3d-style chamfer_distance (AE.py:57-70 get_loss, pppe_pcd_ae.py:817-838):
+//   L = mean_b [ mean_i min_j |x_i - y_j|^2 + mean_j min_i |x_i - y_j|^2 ]
+// With the argmins fixed, dL/dx_i = 2 wx (x_i - y_nn(i)) + sum_{j: nn'(j) = i} 2 wy (x_i - y_j),
+// wx = g/(B P), wy = g/(B Q), and symmetrically for y.  The second term is a scatter: fp32 atomics
+// (one 12-byte row per lane; order-dependent in the last bits, as any atomic sum).
+// ------------------------------------------------------------------------------------------
+__global__ void chamfer_grad_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, int Q,
+                                    const int32_t *__restrict__ nn_xy, const int32_t *__restrict__ nn_yx, float wx, float wy,
+                                    float *__restrict__ gX, float *__restrict__ gY)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *x = X + (size_t)b * P * 3, *y = Y + (size_t)b * Q * 3;
+    float *gx = gX + (size_t)b * P * 3, *gy = gY + (size_t)b * Q * 3;
+    if (t < P) {
+        const int j = nn_xy[(size_t)b * P + t];
+        for (int a = 0; a < 3; ++a) {
+            const float d = 2.f * wx * (x[3 * t + a] - y[3 * j + a]);
+            atomicAdd(&gx[3 * t + a], d);
+            atomicAdd(&gy[3 * j + a], -d);
+        }
+    }
+    if (t < Q) {
+        const int i = nn_yx[(size_t)b * Q + t];
+        for (int a = 0; a < 3; ++a) {
+            const float d = 2.f * wy * (y[3 * t + a] - x[3 * i + a]);
+            atomicAdd(&gy[3 * t + a], d);
+            atomicAdd(&gx[3 * i + a], -d);
+        }
+    }
+}
+
+extern "C" int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
+                                 const int32_t *nn_yx, float grad_out, float *gX, float *gY, void *stream)
+{
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(X && Y && nn_xy && nn_yx && gX && gY, "pccx_chamfer_grad: null pointer");
+    PCCX_CHECK_ARG(P >= 1 && Q >= 1 && B <= 65535, "pccx_chamfer_grad: bad shape");
+    PCCX_CHECK_HIP(hipMemsetAsync(gX, 0, sizeof(float) * (size_t)B * P * 3, (hipStream_t)stream));
+    PCCX_CHECK_HIP(hipMemsetAsync(gY, 0, sizeof(float) * (size_t)B * Q * 3, (hipStream_t)stream));
+    const int n = P > Q ? P : Q;
+    hipLaunchKernelGGL(chamfer_grad_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, nn_xy, nn_yx,
+                       grad_out / ((float)B * P), grad_out / ((float)B * Q), gX, gY);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

@@ -190,9 +190,32 @@ def point_plane_err(x, y, normals_y):
     return err
 
 
+class _ChamferFn(torch.autograd.Function):
+    """Differentiable chamfer_distance (batch mean): forward = two nn_dist launches, backward =
+    pccx_chamfer_grad with the argmins saved from the forward."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        dxy, nxy = nn_dist(x, y, return_idx=True)
+        dyx, nyx = nn_dist(y, x, return_idx=True)
+        ctx.save_for_backward(x, y, nxy, nyx)
+        return (dxy.double().mean(dim=1) + dyx.double().mean(dim=1)).mean().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, nxy, nyx = ctx.saved_tensors
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
+        _lib.call("pccx_chamfer_grad", x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), y.shape[1], nxy.data_ptr(),
+                  nyx.data_ptr(), float(g), gx.data_ptr(), gy.data_ptr(), _stream())
+        return gx, gy
+
+
 def chamfer_distance(x, y, batch_reduction="mean"):
     """pytorch3d.loss.chamfer_distance defaults (AE.py:67, eval.py:204): squared distances,
-    point mean, both directions summed; returns (value, None)."""
+    point mean, both directions summed; returns (value, None).  Differentiable w.r.t. x and y for
+    batch_reduction="mean" (the loss of AE.py:57-70 / pppe_pcd_ae.py:817-838)."""
+    if batch_reduction == "mean" and (x.requires_grad or y.requires_grad):
+        return _ChamferFn.apply(_f32c(x, "chamfer.x"), _f32c(y, "chamfer.y")), None
     dxy, dyx = nn_dist(x, y), nn_dist(y, x)
     per = dxy.double().mean(dim=1) + dyx.double().mean(dim=1)
     if batch_reduction == "mean":

@@ -194,3 +194,23 @@ def test_octree_full_mode_round_trip_on_device():
             assert np.array_equal(out[b].cpu().numpy(), want)
             cells = cport.get_decode_from_pc(pcs[b], 1, int(depth[b]))
             assert np.array_equal(np.unique(out[b].cpu().numpy(), axis=0), cells)   # decode inverts encode
+
+
+@pytest.mark.parametrize("P,Q", [(300, 500), (2048, 2048), (1, 7)])
+def test_chamfer_backward_matches_autograd_of_the_definition(P, Q):
+    """Loss of AE.py:57-70: the HIP forward/backward against torch autograd on the brute-force
+    definition (float64, CPU).  Tolerance 1e-5 relative (fp32 atomics vs an fp64 sum)."""
+    rng = np.random.default_rng(P * 7 + Q)
+    x = rng.random((2, P, 3)).astype(np.float32)
+    y = rng.random((2, Q, 3)).astype(np.float32)
+    xg, yg = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    loss, _ = ops.chamfer_distance(xg, yg)
+    (loss * 3.0).backward()
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    yr = torch.from_numpy(y).double().requires_grad_(True)
+    d = ((xr[:, :, None, :] - yr[:, None, :, :]) ** 2).sum(-1)
+    ref = (d.min(2).values.mean(1) + d.min(1).values.mean(1)).mean()
+    (ref * 3.0).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * float(ref.detach())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(yg.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-9)
