@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
     ap.add_argument("--cpu-clouds", type=int, default=64, help="max clouds in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
+    ap.add_argument("--pcie", action="store_true",
+                    help="also move the clouds host->device and the streams / reconstruction device->host inside the "
+                         "timed region (the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU")
     args = ap.parse_args()
@@ -161,7 +164,16 @@ def main():
     clouds = torch.from_numpy(np.concatenate([base] * ((B + base.shape[0] - 1) // base.shape[0]))[:B]).to(dev)
     starts = torch.from_numpy((np.arange(B) * 97 + rank) % N_POINTS).to(dev)
 
+    host_clouds = clouds.cpu().pin_memory() if args.pcie else None
+
     def step():
+        if args.pcie:
+            x = host_clouds.to(dev, non_blocking=True)
+            comp = cd.compress(x, starts)
+            comp.to_host()                                   # .s.bin / .p.bin / .c.bin bytes to the host
+            out = cd.decompress(comp)
+            out.cpu()                                        # reconstructed XYZ to the host
+            return comp, out
         comp = cd.compress(clouds, starts)
         return comp, cd.decompress(comp)
 
@@ -209,7 +221,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "IPDAE K=256 d=16 L=7, 8192-pt CAD-like synthetic clouds (configs[1])",
                        "clouds_per_gpu_per_step": B, "points_per_cloud": N_POINTS, "patches_per_cloud": S_PATCH,
-                       "octree_mode": args.octree_mode, "sharding": f"file-sharded x{world}", "weights": "seeded random"},
+                       "octree_mode": args.octree_mode, "sharding": f"file-sharded x{world}", "weights": "seeded random",
+                       "pcie_inclusive": bool(args.pcie)},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS, "traffic": measured_traffic(dom, B),
                          "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P},
