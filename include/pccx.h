@@ -231,6 +231,47 @@ PCCX_API int pccx_round(const float *x, int64_t n, float *y, void *stream);
 PCCX_API int pccx_quantize_st(const float *x, int64_t n, float qmin, float qmax, int levels, float *y_q,
                               float *y_deq, void *stream);
 
+/* ---- training-step primitives (train_pppe_pcd_ae.py:184-226): train-mode BatchNorm, the
+ *      backward of the generic layers, loss pieces, gradient clipping and Adam.  Rows are channels-last.
+ *      `sums` arguments are scratch of 2*C doubles. ------------------------------------------------ */
+PCCX_API int pccx_pack_linear_device(const float *W, int N, int K, int transpose, float *wp, void *stream);
+/* dW (N,K) += dZ^T (M,N) . X (M,K)   (dW must be initialised by the caller) */
+PCCX_API int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N, int K, int ldz, int ldx,
+                            float *dW, void *stream);
+/* BatchNorm{1,2}d in training mode (pppe_pcd_ae.py:556-568): batch moments per channel, running stats
+ * updated with `momentum` (running_* may be NULL); then y = [relu]((z-mean)*rstd*gamma+beta). */
+PCCX_API int pccx_bn_train_stats(const float *Z, int64_t M, int C, float eps, float momentum, double *sums,
+                                 float *mean, float *rstd, float *running_mean, float *running_var,
+                                 void *stream);
+PCCX_API int pccx_bn_relu_forward(const float *Z, int64_t M, int C, const float *mean, const float *rstd,
+                                  const float *gamma, const float *beta, int relu, float *Y, void *stream);
+/* backward of BN(train)+ReLU: dZ, and g_gamma / g_beta ACCUMULATED into the parameter gradients */
+PCCX_API int pccx_bn_relu_backward(const float *dY, const float *Y, const float *Z, int64_t M, int C,
+                                   const float *mean, const float *rstd, const float *gamma, double *sums,
+                                   float *dZ, float *g_gamma, float *g_beta, void *stream);
+PCCX_API int pccx_col_sum(const float *dY, int64_t M, int C, double *sums, float *g_bias, void *stream);
+PCCX_API int pccx_relu_backward(const float *dY, const float *Y, int64_t n, float *dZ, void *stream);
+PCCX_API int pccx_group_max_arg(const float *x, int64_t G, int Kn, int C, float *out, int32_t *arg,
+                                void *stream);
+PCCX_API int pccx_group_max_backward(const float *dOut, const int32_t *arg, int64_t G, int Kn, int C,
+                                     float *dX, void *stream);
+/* backward of pccx_gather: dF (B,N,C) = scatter-add of dG (B,Mrows, row stride ldg >= C) through idx */
+PCCX_API int pccx_gather_backward(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N,
+                                  int C, float *dF, void *stream);
+/* F.smooth_l1_loss(a, b, reduction="mean") * n summed into value[0] (double); grad = grad_scale * dl/da */
+PCCX_API int pccx_smooth_l1(const float *a, const float *b, int64_t n, float grad_scale, double *value,
+                            float *grad, void *stream);
+PCCX_API int pccx_quantize_st_backward(const float *x, const float *d_ydeq, int64_t n, float qmin, float qmax,
+                                       int levels, float *dx, void *stream);
+PCCX_API int pccx_rate_from_logits(const float *logits, const float *y_q, int B, int bins, int ld_yq,
+                                   float *out, void *stream);
+/* clip_grad_norm_ + torch.optim.Adam: accumulate sum g^2 over all tensors into acc (zeroed by the caller),
+ * then one pccx_adam_step per tensor reads the norm on the device (gnorm_sq may be NULL = no clipping). */
+PCCX_API int pccx_sumsq_accumulate(const float *g, int64_t n, double *acc, void *stream);
+PCCX_API int pccx_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                            const double *gnorm_sq, float max_norm, float lr, float beta1, float beta2,
+                            float eps, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

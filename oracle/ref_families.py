@@ -228,7 +228,8 @@ class PointCloudAE(nn.Module):
         latent, cond = self.encoder(x, starts)                                     # :865
         xc = torch.clamp(latent, self.q_min, self.q_max)                           # quantize_st (:719-735)
         scaled = (xc - self.q_min) / (self.q_max - self.q_min + 1e-9) * (self.latent_bins - 1)
-        y_q = torch.clamp(torch.round(scaled), 0, self.latent_bins - 1)
+        y_q = torch.round(scaled).detach() + (scaled - scaled.detach())            # straight-through (:732)
+        y_q = torch.clamp(y_q, 0, self.latent_bins - 1)
         y_deq = (y_q / (self.latent_bins - 1)) * (self.q_max - self.q_min) + self.q_min   # :873
         coarse, fine = self.decoder(y_deq)      # mean over N identical tiled copies == the value itself (:875)
         return coarse, fine, cond, y_q, latent

@@ -1,0 +1,41 @@
+"""CPU restatement (torch autograd) of one iteration of train_pppe_pcd_ae.train_one_epoch
+(train_pppe_pcd_ae.py:184-226) without the CUDA autocast / GradScaler branch: forward in train mode,
+estimate_bits_per_point_conditional (pppe_pcd_ae.py:882-917), RateDistortionLoss('hybrid')
+(pppe_pcd_ae.py:807-838), backward, clip_grad_norm_(ae + prob, 1.0), Adam step.
+
+TEST INFRASTRUCTURE ONLY.  Chamfer is evaluated by brute force (pytorch3d is absent; PARITY UNPINNED).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def chamfer_autograd(x, y):
+    d = ((x[:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)
+    return (d.min(2).values.mean(1) + d.min(1).values.mean(1)).mean()
+
+
+def prob_forward(pr, y, cond):
+    """pppe_pcd_ae.ConditionalProbabilityModel.forward (:774-802) on one column (all N are identical)."""
+    c = pr.cond_proj(cond)
+    x = torch.cat([y, c], dim=1).unsqueeze(-1)
+    h = pr.combine(x)
+    return F.softmax(pr.pmf_head(h), dim=1).clamp(min=1e-9)            # (B,K,1)
+
+
+def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, chamfer_chunk=None):
+    model.train()
+    opt.zero_grad()
+    coarse, fine, cond, y_q, _ = model(batch_x, starts)
+    with torch.no_grad():
+        pmf = prob_forward(model.prob, y_q.detach(), cond.detach())
+        idx0 = torch.clamp(y_q[:, 0].long(), 0, pmf.shape[1] - 1).view(-1, 1, 1)
+        fbpp = (-torch.log2(torch.gather(pmf, 1, idx0).clamp(min=1e-9))).mean()
+    chamfer = chamfer_autograd(fine, batch_x)
+    l1 = F.smooth_l1_loss(fine, batch_x, reduction="mean")
+    dist = 0.7 * chamfer + 0.3 * l1
+    rate = torch.clamp(fbpp, min=0.0, max=100.0)
+    loss = dist + lam * rate
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(list(model.parameters()), grad_clip)
+    opt.step()
+    return float(loss), float(dist), float(rate)

@@ -1,0 +1,481 @@
+// train.hip -- backward / training-mode primitives for the step of train_pppe_pcd_ae.py:184-226
+// (BASELINE configs[4]): the pppe PointCloudAE forward in TRAIN mode (BatchNorm on batch
+// statistics), Chamfer + smooth-L1 loss, backward, gradient clipping, Adam.
+//
+// Everything works on row-major "channels last" activations (rows = batch x points x neighbours), like
+// linear.hip.  GEMM-shaped backward passes run on the fp32 matrix cores:
+//   dX = dZ . W         -> pccx_linear with the transposed weight packed on the device
+//   dW = dZ^T . X       -> linear_dw_kernel below (reduction over rows = the MFMA k dimension)
+// Column reductions (BatchNorm moments, bias / gamma / beta gradients) accumulate in double through
+// atomics; Adam / clipping are elementwise.  Correctness-first: parity against torch autograd on the
+// oracle restatement (tests/test_train_step.py), not tuned.
+#include <math.h>
+
+#include "common.h"
+#include "mfma_chain.h"
+
+#define ROWS_PER_BLOCK 256
+
+// ---- device-side packing of W (N,K) [or its transpose] into MFMA A fragments (weights change every step)
+__global__ void pack_linear_dev_kernel(const float *__restrict__ W, int N, int K, int transpose, float *__restrict__ wp)
+{
+    // logical matrix A (rows R, cols Cc): A = W (R=N, Cc=K) or W^T (R=K, Cc=N)
+    const int R = transpose ? K : N, Cc = transpose ? N : K;
+    const int KT = (Cc + 15) / 16, MT = (R + 15) / 16;
+    const long total = (long)KT * MT * 256;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r4 = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        const long f = e >> 8;
+        const int mt = (int)(f % MT), kt = (int)(f / MT);
+        const int row = 16 * mt + (lane & 15), col = 16 * kt + 4 * (lane >> 4) + r4;
+        float v = 0.f;
+        if (row < R && col < Cc) v = transpose ? W[(size_t)col * K + row] : W[(size_t)row * K + col];
+        wp[e] = v;
+    }
+}
+
+extern "C" int pccx_pack_linear_device(const float *W, int N, int K, int transpose, float *wp, void *stream)
+{
+    PCCX_CHECK_ARG(W && wp && N >= 1 && K >= 1, "pccx_pack_linear_device: bad arguments");
+    const int R = transpose ? K : N, Cc = transpose ? N : K;
+    const long total = (long)((Cc + 15) / 16) * ((R + 15) / 16) * 256;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_linear_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, N, K, transpose, wp);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- dW[N][K] += sum_m dZ[m][n] * X[m][k]: one wave per (16 n x 16 k) tile and row slice
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict__ dZ, const float *__restrict__ X, long M, int N,
+                                                        int K, int ldz, int ldx, int rows_per_slice, float *__restrict__ dW)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int nt = blockIdx.x, kt = blockIdx.y * 4 + w;
+    if (kt * 16 >= K) return;
+    const long m0 = (long)blockIdx.z * rows_per_slice;
+    const long m1 = m0 + rows_per_slice < M ? m0 + rows_per_slice : M;
+    const int n = nt * 16 + c, k = kt * 16 + c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long m = m0; m < m1; m += 4) {
+        const long mm = m + g;                                       // MFMA k index = row within the 4-row step
+        const float a = (mm < m1 && n < N) ? dZ[(size_t)mm * ldz + n] : 0.f;     // A[i = n][k = g]
+        const float b = (mm < m1 && k < K) ? X[(size_t)mm * ldx + k] : 0.f;      // B[k = g][j = k]
+        acc = mfma16(a, b, acc);
+    }
+    // D[i = n-row 4g+r][j = k-col c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nn = nt * 16 + 4 * g + r;
+        if (nn < N && k < K) atomicAdd(&dW[(size_t)nn * K + k], acc[r]);
+    }
+}
+
+extern "C" int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N, int K, int ldz, int ldx, float *dW, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dZ && X && dW && N >= 1 && K >= 1 && ldz >= N && ldx >= K, "pccx_linear_dw: bad arguments");
+    int slices = (int)((M + 2047) / 2048);
+    if (slices > 1024) slices = 1024;
+    int rps = (int)((M + slices - 1) / slices);
+    rps = (rps + 3) / 4 * 4;
+    slices = (int)((M + rps - 1) / rps);
+    dim3 grid((N + 15) / 16, ((K + 15) / 16 + 3) / 4, slices);
+    PCCX_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "pccx_linear_dw: shape too large");
+    hipLaunchKernelGGL(linear_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- column reductions -----------------------------------------------------------------------------
+// mode 0: out0[c] += sum z, out1[c] += sum z^2                       (BatchNorm moments)
+// mode 1: out0[c] += sum dy*(y>0)*xhat, out1[c] += sum dy*(y>0)      (BatchNorm-ReLU backward: dgamma, dbeta)
+// mode 2: out0[c] += sum dy                                          (bias gradient)
+__global__ void col_reduce_kernel(int mode, const float *__restrict__ A, const float *__restrict__ Y, const float *__restrict__ Z,
+                                  const float *__restrict__ mean, const float *__restrict__ rstd, long M, int C,
+                                  double *__restrict__ out0, double *__restrict__ out1)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;                                   // 4 row lanes per block
+    if (c >= C) return;
+    const long m0 = (long)blockIdx.y * ROWS_PER_BLOCK;
+    const long m1 = m0 + ROWS_PER_BLOCK < M ? m0 + ROWS_PER_BLOCK : M;
+    double s0 = 0, s1 = 0;
+    const float mu = mode == 1 ? mean[c] : 0.f, rs = mode == 1 ? rstd[c] : 0.f;
+    for (long m = m0 + rl; m < m1; m += 4) {
+        const size_t e = (size_t)m * C + c;
+        if (mode == 0) {
+            const double z = A[e];
+            s0 += z; s1 += z * z;
+        } else if (mode == 1) {
+            const float d = Y[e] > 0.f ? A[e] : 0.f;
+            s0 += (double)d * (double)((Z[e] - mu) * rs);
+            s1 += d;
+        } else {
+            s0 += A[e];
+        }
+    }
+    atomicAdd(&out0[c], s0);
+    if (mode != 2) atomicAdd(&out1[c], s1);
+}
+
+static int launch_col_reduce(int mode, const float *A, const float *Y, const float *Z, const float *mean, const float *rstd,
+                             int64_t M, int C, double *o0, double *o1, hipStream_t st)
+{
+    dim3 grid((C + 63) / 64, (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    PCCX_CHECK_ARG(grid.y <= 65535u, "column reduction: M=%ld rows too many", (long)M);
+    PCCX_CHECK_HIP(hipMemsetAsync(o0, 0, sizeof(double) * C, st));
+    if (o1) PCCX_CHECK_HIP(hipMemsetAsync(o1, 0, sizeof(double) * C, st));
+    hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, st, mode, A, Y, Z, mean, rstd, (long)M, C, o0, o1);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// BatchNorm (training) statistics: mean[c], rstd[c] = 1/sqrt(var_biased + eps); running stats updated as torch
+// does (momentum, unbiased variance).  sums: workspace of 2*C doubles.
+__global__ void bn_finalize_kernel(const double *__restrict__ s0, const double *__restrict__ s1, long M, int C, float eps,
+                                   float momentum, float *__restrict__ mean, float *__restrict__ rstd,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = s0[c] / (double)M;
+    double var = s1[c] / (double)M - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+extern "C" int pccx_bn_train_stats(const float *Z, int64_t M, int C, float eps, float momentum, double *sums, float *mean,
+                                   float *rstd, float *running_mean, float *running_var, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(Z && sums && mean && rstd && C >= 1, "pccx_bn_train_stats: bad arguments");
+    int rc = launch_col_reduce(0, Z, nullptr, nullptr, nullptr, nullptr, M, C, sums, sums + C, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, sums + C, (long)M, C, eps,
+                       momentum, mean, rstd, running_mean, running_var);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// y = relu((z - mean) * rstd * gamma + beta)
+__global__ void bn_relu_fwd_kernel(const float *__restrict__ Z, long n, int C, const float *__restrict__ mean,
+                                   const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   int relu, float *__restrict__ Y)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float v = (Z[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+        Y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+extern "C" int pccx_bn_relu_forward(const float *Z, int64_t M, int C, const float *mean, const float *rstd, const float *gamma,
+                                    const float *beta, int relu, float *Y, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(Z && mean && rstd && gamma && beta && Y, "pccx_bn_relu_forward: null pointer");
+    long blocks = ((long)M * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Z, (long)M * C, C, mean, rstd,
+                       gamma, beta, relu, Y);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// dz = gamma*rstd/M * (M*dyh - dbeta - xhat*dgamma), dyh = dy*(y>0)
+__global__ void bn_relu_bwd_apply_kernel(const float *__restrict__ dY, const float *__restrict__ Y, const float *__restrict__ Z,
+                                         long n, int C, long M, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                         const float *__restrict__ gamma, const double *__restrict__ dgamma,
+                                         const double *__restrict__ dbeta, float *__restrict__ dZ)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const double d = Y[i] > 0.f ? dY[i] : 0.f;
+        const double xh = (double)((Z[i] - mean[c]) * rstd[c]);
+        dZ[i] = (float)((double)gamma[c] * rstd[c] / (double)M * ((double)M * d - dbeta[c] - xh * dgamma[c]));
+    }
+}
+
+// dgamma/dbeta: 2*C doubles (also the parameter gradients, written as float to g_gamma / g_beta)
+__global__ void cast_d2f_kernel(const double *__restrict__ a, int n, float *__restrict__ o, int accumulate)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = accumulate ? o[i] + (float)a[i] : (float)a[i];
+}
+
+extern "C" int pccx_bn_relu_backward(const float *dY, const float *Y, const float *Z, int64_t M, int C, const float *mean,
+                                     const float *rstd, const float *gamma, double *sums, float *dZ, float *g_gamma,
+                                     float *g_beta, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dY && Y && Z && mean && rstd && gamma && sums && dZ && g_gamma && g_beta, "pccx_bn_relu_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_col_reduce(1, dY, Y, Z, mean, rstd, M, C, sums, sums + C, st);
+    if (rc) return rc;
+    long blocks = ((long)M * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dY, Y, Z, (long)M * C, C, (long)M, mean,
+                       rstd, gamma, sums, sums + C, dZ);
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, g_gamma, 1);
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums + C, C, g_beta, 1);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// bias gradient: g_bias[c] += sum_m dY[m][c]
+extern "C" int pccx_col_sum(const float *dY, int64_t M, int C, double *sums, float *g_bias, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dY && sums && g_bias, "pccx_col_sum: null pointer");
+    int rc = launch_col_reduce(2, dY, nullptr, nullptr, nullptr, nullptr, M, C, sums, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, g_bias, 1);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// dz = dy * (y > 0)
+__global__ void relu_bwd_kernel(const float *__restrict__ dY, const float *__restrict__ Y, long n, float *__restrict__ dZ)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dZ[i] = Y[i] > 0.f ? dY[i] : 0.f;
+}
+
+extern "C" int pccx_relu_backward(const float *dY, const float *Y, int64_t n, float *dZ, void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dY && Y && dZ, "pccx_relu_backward: null pointer");
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dY, Y, (long)n, dZ);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- max over neighbours with argmax, and its backward ----------------------------------------------
+__global__ void group_max_arg_kernel(const float *__restrict__ x, long G, int Kn, int C, float *__restrict__ out,
+                                     int32_t *__restrict__ arg)
+{
+    const long total = G * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long gi = e / C;
+        const int c = (int)(e % C);
+        const float *p = x + (gi * Kn) * C + c;
+        float m = -INFINITY;
+        int a = 0;
+        for (int k = 0; k < Kn; ++k) {
+            const float v = p[(size_t)k * C];
+            if (v > m) { m = v; a = k; }                               // first maximum, as torch.max
+        }
+        out[e] = m;
+        arg[e] = a;
+    }
+}
+
+__global__ void group_max_bwd_kernel(const float *__restrict__ dOut, const int32_t *__restrict__ arg, long G, int Kn, int C,
+                                     float *__restrict__ dX)
+{
+    const long total = G * Kn * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long gk = e / C;
+        const int k = (int)(gk % Kn);
+        const long gi = gk / Kn;
+        dX[e] = arg[gi * C + c] == k ? dOut[gi * C + c] : 0.f;
+    }
+}
+
+extern "C" int pccx_group_max_arg(const float *x, int64_t G, int Kn, int C, float *out, int32_t *arg, void *stream)
+{
+    if (G == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(x && out && arg && Kn >= 1 && C >= 1, "pccx_group_max_arg: bad arguments");
+    long blocks = ((long)G * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(group_max_arg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)G, Kn, C, out, arg);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_group_max_backward(const float *dOut, const int32_t *arg, int64_t G, int Kn, int C, float *dX, void *stream)
+{
+    if (G == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dOut && arg && dX && Kn >= 1 && C >= 1, "pccx_group_max_backward: bad arguments");
+    long blocks = ((long)G * Kn * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dOut, arg, (long)G, Kn, C, dX);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- backward of index_points / knn_gather: dF[b, idx[b,m], c0:c0+C] += dG[b, m, :]  (dG row stride ldg) ------
+__global__ void scatter_add_rows_kernel(const float *__restrict__ dG, int ldg, const int64_t *__restrict__ idx, int Mrows, int N,
+                                        int C, float *__restrict__ dF)
+{
+    const int b = blockIdx.y;
+    const long total = (long)Mrows * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / C;
+        const int c = (int)(e % C);
+        long i = idx[(size_t)b * Mrows + m];
+        if (i < 0) i = 0;
+        atomicAdd(&dF[((size_t)b * N + (size_t)i) * C + c], dG[((size_t)b * Mrows + m) * ldg + c]);
+    }
+}
+
+extern "C" int pccx_gather_backward(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N, int C, float *dF,
+                                    void *stream)
+{
+    if (B == 0 || Mrows == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dG && idx && dF && ldg >= C && B <= 65535, "pccx_gather_backward: bad arguments");
+    PCCX_CHECK_HIP(hipMemsetAsync(dF, 0, sizeof(float) * (size_t)B * N * C, (hipStream_t)stream));
+    long blocks = ((long)Mrows * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, dG, ldg, idx, Mrows, N,
+                       C, dF);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- smooth L1 (beta = 1, mean reduction; pppe_pcd_ae.py:822,826): value into out[0] (double), gradient * scale ----
+__global__ void smooth_l1_kernel(const float *__restrict__ a, const float *__restrict__ b, long n, float gscale,
+                                 double *__restrict__ value, float *__restrict__ grad)
+{
+    double s = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i], ad = fabsf(d);
+        s += ad < 1.f ? 0.5 * (double)d * d : (double)ad - 0.5;
+        if (grad) grad[i] = gscale * (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f));
+    }
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(value, s);
+}
+
+extern "C" int pccx_smooth_l1(const float *a, const float *b, int64_t n, float grad_scale, double *value, float *grad, void *stream)
+{
+    PCCX_CHECK_ARG(a && b && value && n >= 1, "pccx_smooth_l1: bad arguments");
+    PCCX_CHECK_HIP(hipMemsetAsync(value, 0, sizeof(double), (hipStream_t)stream));
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, grad_scale, value,
+                       grad);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- backward of quantize_st + dequantise (pppe_pcd_ae.py:719-735,873): straight-through inside the clamps ----
+__global__ void ste_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dydeq, long n, float qmin, float qmax,
+                               float factor, float lm1, float *__restrict__ dx)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float scaled = (fminf(fmaxf(v, qmin), qmax) - qmin) * factor;
+        const bool pass = v >= qmin && v <= qmax && scaled >= 0.f && scaled <= lm1;
+        dx[i] = pass ? dydeq[i] * ((qmax - qmin) / lm1) * factor : 0.f;
+    }
+}
+
+extern "C" int pccx_quantize_st_backward(const float *x, const float *d_ydeq, int64_t n, float qmin, float qmax, int levels, float *dx,
+                                         void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(x && d_ydeq && dx && levels >= 2 && qmax > qmin, "pccx_quantize_st_backward: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const float factor = (float)((double)(levels - 1) / ((double)(qmax - qmin) + 1e-9));
+    hipLaunchKernelGGL(ste_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, d_ydeq, (long)n, qmin, qmax, factor,
+                       (float)(levels - 1), dx);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- gradient clipping (clip_grad_norm_, train_pppe_pcd_ae.py:215,219) and Adam -------------------------------
+__global__ void sumsq_kernel(const float *__restrict__ g, long n, double *__restrict__ acc)
+{
+    double s = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += (double)g[i] * g[i];
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
+extern "C" int pccx_sumsq_accumulate(const float *g, int64_t n, double *acc, void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(g && acc, "pccx_sumsq_accumulate: null pointer");
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, acc);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad); the clip factor min(1, max_norm/(norm+1e-6)) is read from the
+// device-side squared norm so no host sync sits inside the step.
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
+                            const double *__restrict__ gnorm_sq, float max_norm, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2)
+{
+    float clip = 1.f;
+    if (gnorm_sq) {
+        const float norm = (float)sqrt(*gnorm_sq);
+        clip = fminf(1.f, max_norm / (norm + 1e-6f));
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int pccx_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const double *gnorm_sq,
+                              float max_norm, float lr, float beta1, float beta2, float eps, int step, void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step >= 1, "pccx_adam_step: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n,
+                       gnorm_sq, max_norm, lr, beta1, beta2, eps, bc1, bc2);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// bits per point of the conditional model as train_pppe_pcd_ae.py uses it (pppe_pcd_ae.py:882-917): softmax over
+// the K bins of logits (B,K), probability of bin idx0[b] (first latent channel), -log2(clamp(p, 1e-9)), batch mean.
+__global__ void rate_kernel(const float *__restrict__ logits, const float *__restrict__ yq0, int B, int Kb, int ldy,
+                            float *__restrict__ out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double tot = 0;
+    for (int b = 0; b < B; ++b) {
+        const float *l = logits + (size_t)b * Kb;
+        float mx = -INFINITY;
+        for (int k = 0; k < Kb; ++k) mx = fmaxf(mx, l[k]);
+        float sum = 0.f;
+        for (int k = 0; k < Kb; ++k) sum += expf(l[k] - mx);
+        int idx = (int)yq0[(size_t)b * ldy];
+        idx = idx < 0 ? 0 : (idx > Kb - 1 ? Kb - 1 : idx);
+        const float pr = fmaxf(fmaxf(expf(l[idx] - mx) / sum, 1e-9f), 1e-9f);   // softmax clamp(min=1e-9), then clamp again (:798,:912)
+        tot += -log2f(pr);
+    }
+    out[0] = (float)(tot / B);
+}
+
+extern "C" int pccx_rate_from_logits(const float *logits, const float *y_q, int B, int bins, int ld_yq, float *out, void *stream)
+{
+    PCCX_CHECK_ARG(logits && y_q && out && B >= 1 && bins >= 1, "pccx_rate_from_logits: bad arguments");
+    hipLaunchKernelGGL(rate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logits, y_q, B, bins, ld_yq, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

@@ -48,6 +48,21 @@ _SIGNATURES = {
     "pccx_group_max": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_sigmoid_spread": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_round": [_P, C.c_int64, _P, _P],
+    "pccx_pack_linear_device": [_P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_linear_dw": [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_bn_train_stats": [_P, C.c_int64, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P],
+    "pccx_bn_relu_forward": [_P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P],
+    "pccx_bn_relu_backward": [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pccx_col_sum": [_P, C.c_int64, C.c_int, _P, _P, _P],
+    "pccx_relu_backward": [_P, _P, C.c_int64, _P, _P],
+    "pccx_group_max_arg": [_P, C.c_int64, C.c_int, C.c_int, _P, _P, _P],
+    "pccx_group_max_backward": [_P, _P, C.c_int64, C.c_int, C.c_int, _P, _P],
+    "pccx_gather_backward": [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_smooth_l1": [_P, _P, C.c_int64, C.c_float, _P, _P, _P],
+    "pccx_quantize_st_backward": [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P],
+    "pccx_rate_from_logits": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_sumsq_accumulate": [_P, C.c_int64, _P, _P],
+    "pccx_adam_step": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
 _RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,

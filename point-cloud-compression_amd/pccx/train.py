@@ -1,0 +1,306 @@
+"""The training step of train_pppe_pcd_ae.py:184-226 (BASELINE configs[4]) on libpccx.so.
+
+    coarse, recon, feats, y = ae(batch_x)                         # forward, BatchNorm in TRAIN mode
+    fbpp = estimate_bits_per_point_conditional(y, feats, prob)    # no-grad rate term
+    loss, dist, rate = criterion(recon, batch_x, fbpp, lam)       # hybrid: 0.7 Chamfer + 0.3 smooth-L1
+    loss.backward(); clip_grad_norm_(params, 1.0); optimizer.step()   # Adam
+
+torch.autograd only sequences the backward: every Function below is a pair of HIP launches behind the
+C ABI (include/pccx.h, csrc/train.hip); parameters and optimizer state are plain tensors in HBM.
+fp32 throughout (the reference's CUDA autocast path is not reproduced).  Correctness-first.
+"""
+import math
+
+import torch
+
+from . import _lib, families, ops
+from .ops import _stream
+
+_SCRATCH = {}
+
+
+def _sums(C, device):
+    t = _SCRATCH.get((C, str(device)))
+    if t is None:
+        t = _SCRATCH[(C, str(device))] = torch.empty(2 * C, device=device, dtype=torch.float64)
+    return t
+
+
+def _packed(W, transpose):
+    N, K = W.shape
+    R, Cc = (K, N) if transpose else (N, K)
+    wp = torch.empty(_lib.load().pccx_packed_linear_floats(R, Cc), device=W.device, dtype=torch.float32)
+    _lib.call("pccx_pack_linear_device", W.data_ptr(), N, K, int(transpose), wp.data_ptr(), _stream())
+    return wp
+
+
+def _linear_raw(x, wp, bias, N, K):
+    M = x.shape[0]
+    out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _lib.call("pccx_linear", x.data_ptr(), M, K, x.stride(0), wp.data_ptr(), bias.data_ptr() if bias is not None else None, N, 0,
+              out.data_ptr(), N, _stream())
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """z = x W^T (+ b): nn.Linear / 1x1 Conv on channels-last rows."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        W2 = W.reshape(W.shape[0], -1).contiguous()
+        ctx.save_for_backward(x, W2)
+        ctx.has_bias, ctx.wshape = b is not None, W.shape
+        return _linear_raw(x, _packed(W2, False), b, W2.shape[0], W2.shape[1])
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, W2 = ctx.saved_tensors
+        dz = dz.contiguous()
+        N, K = W2.shape
+        M = x.shape[0]
+        dx = _linear_raw(dz, _packed(W2, True), None, K, N) if ctx.needs_input_grad[0] else None      # dX = dZ . W
+        dW = torch.zeros_like(W2)
+        _lib.call("pccx_linear_dw", dz.data_ptr(), x.data_ptr(), M, N, K, N, x.stride(0), dW.data_ptr(), _stream())
+        db = None
+        if ctx.has_bias:
+            db = torch.zeros(N, device=dz.device, dtype=torch.float32)
+            _lib.call("pccx_col_sum", dz.data_ptr(), M, N, _sums(N, dz.device).data_ptr(), db.data_ptr(), _stream())
+        return dx, dW.view(ctx.wshape), db
+
+
+class BnReluFn(torch.autograd.Function):
+    """BatchNorm (training statistics, running buffers updated in place) followed by ReLU."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, bn):
+        z = z.contiguous()
+        M, Cc = z.shape
+        mean = torch.empty(Cc, device=z.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _lib.call("pccx_bn_train_stats", z.data_ptr(), M, Cc, float(bn.eps), float(bn.momentum), _sums(Cc, z.device).data_ptr(),
+                  mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _stream())
+        y = torch.empty_like(z)
+        _lib.call("pccx_bn_relu_forward", z.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  1, y.data_ptr(), _stream())
+        bn.num_batches_tracked += 1
+        ctx.save_for_backward(z, y, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, y, mean, rstd, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, Cc = z.shape
+        dz = torch.empty_like(z)
+        gg, gb = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        _lib.call("pccx_bn_relu_backward", dy.data_ptr(), y.data_ptr(), z.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
+                  gamma.data_ptr(), _sums(Cc, z.device).data_ptr(), dz.data_ptr(), gg.data_ptr(), gb.data_ptr(), _stream())
+        return dz, gg, gb, None
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        y = torch.empty_like(z)
+        # relu through the same elementwise kernel as its backward mask: y = max(z, 0)
+        _lib.call("pccx_relu_backward", z.contiguous().data_ptr(), z.contiguous().data_ptr(), z.numel(), y.data_ptr(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dz = torch.empty_like(y)
+        _lib.call("pccx_relu_backward", dy.contiguous().data_ptr(), y.data_ptr(), y.numel(), dz.data_ptr(), _stream())
+        return dz
+
+
+class GroupMaxFn(torch.autograd.Function):
+    """(G,Kn,C) -> (G,C), torch.max over the neighbour axis (first maximum on ties)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        G, Kn, Cc = x.shape
+        out = torch.empty(G, Cc, device=x.device, dtype=torch.float32)
+        arg = torch.empty(G, Cc, device=x.device, dtype=torch.int32)
+        _lib.call("pccx_group_max_arg", x.data_ptr(), G, Kn, Cc, out.data_ptr(), arg.data_ptr(), _stream())
+        ctx.save_for_backward(arg)
+        ctx.shape = (G, Kn, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        G, Kn, Cc = ctx.shape
+        dx = torch.empty(G, Kn, Cc, device=dout.device, dtype=torch.float32)
+        _lib.call("pccx_group_max_backward", dout.contiguous().data_ptr(), arg.data_ptr(), G, Kn, Cc, dx.data_ptr(), _stream())
+        return dx
+
+
+class GatherFn(torch.autograd.Function):
+    """index_points(feats (B,N,C), idx (B,S,K)) with gradient to feats."""
+
+    @staticmethod
+    def forward(ctx, feats, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = feats.shape
+        return ops.index_points(feats, idx)
+
+    @staticmethod
+    def backward(ctx, dg):
+        (idx,) = ctx.saved_tensors
+        B, N, Cc = ctx.shape
+        dg = dg.contiguous()
+        M = idx[0].numel()
+        df = torch.empty(B, N, Cc, device=dg.device, dtype=torch.float32)
+        _lib.call("pccx_gather_backward", dg.data_ptr(), Cc, idx.contiguous().data_ptr(), B, M, N, Cc, df.data_ptr(), _stream())
+        return df, None
+
+
+class QuantizeSTFn(torch.autograd.Function):
+    """quantize_st (pppe_pcd_ae.py:719-735) -> (y_q, y_dequant); straight-through gradient."""
+
+    @staticmethod
+    def forward(ctx, latent, qmin, qmax, levels):
+        latent = latent.contiguous()
+        yq, ydeq = torch.empty_like(latent), torch.empty_like(latent)
+        _lib.call("pccx_quantize_st", latent.data_ptr(), latent.numel(), float(qmin), float(qmax), int(levels), yq.data_ptr(),
+                  ydeq.data_ptr(), _stream())
+        ctx.save_for_backward(latent)
+        ctx.cfg = (float(qmin), float(qmax), int(levels))
+        ctx.mark_non_differentiable(yq)
+        return yq, ydeq
+
+    @staticmethod
+    def backward(ctx, _dyq, dydeq):
+        (latent,) = ctx.saved_tensors
+        dx = torch.empty_like(latent)
+        _lib.call("pccx_quantize_st_backward", latent.data_ptr(), dydeq.contiguous().data_ptr(), latent.numel(), *ctx.cfg,
+                  dx.data_ptr(), _stream())
+        return dx, None, None, None
+
+
+class SmoothL1Fn(torch.autograd.Function):
+    """F.smooth_l1_loss(a, b, reduction='mean') (pppe_pcd_ae.py:822,826); gradient to a."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        val = torch.empty(1, device=a.device, dtype=torch.float64)
+        _lib.call("pccx_smooth_l1", a.data_ptr(), b.data_ptr(), a.numel(), 0.0, val.data_ptr(), None, _stream())
+        ctx.save_for_backward(a, b)
+        return (val / a.numel()).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        val = torch.empty(1, device=a.device, dtype=torch.float64)
+        grad = torch.empty_like(a)
+        _lib.call("pccx_smooth_l1", a.data_ptr(), b.data_ptr(), a.numel(), float(g) / a.numel(), val.data_ptr(), grad.data_ptr(),
+                  _stream())
+        return grad, None
+
+
+# ------------------------------------------------------------------------------------------------
+def _sa_train(mod, xyz, feats, start):
+    """PointNetSetAbstraction.forward (pppe_pcd_ae.py:586-611) in train mode, channels-last."""
+    B, N, _ = xyz.shape
+    S = mod.npoint
+    new_xyz = xyz if S == N else ops.index_points(xyz, ops.farthest_point_sample_batch(xyz, S, start))
+    nn_ = ops.knn_points(new_xyz, xyz, mod.K, patch_scale=1.0)
+    grouped = nn_.knn                                                       # no gradient: xyz is data
+    if feats is not None:
+        grouped = torch.cat([grouped, GatherFn.apply(feats, nn_.idx)], dim=-1)
+    x = grouped.reshape(-1, grouped.shape[-1])
+    for layer in mod.mlp_stack:                                             # conv (no bias) -> BN -> ReLU
+        x = BnReluFn.apply(LinearFn.apply(x, layer[0].weight, None), layer[1].weight, layer[1].bias, layer[1])
+    return new_xyz, GroupMaxFn.apply(x.view(B * S, mod.K, -1)).view(B, S, -1)
+
+
+def forward_train(model, x, starts):
+    """PointCloudAE.forward (pppe_pcd_ae.py:858-877) with BatchNorm in train mode.
+    -> (coarse (B,512,3), fine (B,N,3), cond (B,512), y_q (B,d))."""
+    enc, dec = model.encoder, model.decoder
+    B = x.shape[0]
+    sa = enc.sa_modules
+    outs, new_xyz = [], None
+    for br, st in zip(sa[0].branches, starts[0]):
+        new_xyz, f = _sa_train(br, x, None, st)
+        outs.append(f)
+    feats = torch.cat(outs, dim=-1)
+    xyz, feats = _sa_train(sa[1], new_xyz, feats, starts[1])
+    xyz, feats = _sa_train(sa[2], xyz, feats, starts[2])
+    cond = GroupMaxFn.apply(feats)                                          # global max over the 32 points
+    gc = enc.global_conv
+    h = BnReluFn.apply(LinearFn.apply(cond, gc[0].weight, None), gc[1].weight, gc[1].bias, gc[1])
+    latent = LinearFn.apply(h, gc[3].weight, gc[3].bias)
+    y_q, y_deq = QuantizeSTFn.apply(latent, model.q_min, model.q_max, model.latent_bins)
+    c = LinearFn.apply(ReluFn.apply(LinearFn.apply(y_deq, dec.fc_coarse[0].weight, dec.fc_coarse[0].bias)),
+                       dec.fc_coarse[2].weight, dec.fc_coarse[2].bias)
+    e = torch.cat([c, y_deq], dim=1)
+    fine = LinearFn.apply(ReluFn.apply(LinearFn.apply(e, dec.expansion_mlp[0].weight, dec.expansion_mlp[0].bias)),
+                          dec.expansion_mlp[2].weight, dec.expansion_mlp[2].bias)
+    return c.view(B, -1, 3), fine.view(B, -1, 3), cond, y_q
+
+
+@torch.no_grad()
+def estimate_bits_per_point(model, y_q, cond):
+    """estimate_bits_per_point_conditional (pppe_pcd_ae.py:882-917): every one of the N tiled columns is
+    identical, so one column per cloud is evaluated; returns the scalar fbpp."""
+    pr = model.prob
+    lin = lambda t, m, relu: (ReluFn.apply if relu else (lambda v: v))(LinearFn.apply(t, m.weight, m.bias))
+    c = lin(lin(cond, pr.cond_proj[0], True), pr.cond_proj[2], False)
+    h = lin(lin(torch.cat([y_q, c], dim=1), pr.combine[0], True), pr.combine[2], False)
+    logits = lin(h, pr.pmf_head, False).contiguous()
+    out = torch.empty(1, device=y_q.device, dtype=torch.float32)
+    _lib.call("pccx_rate_from_logits", logits.data_ptr(), y_q.contiguous().data_ptr(), y_q.shape[0], logits.shape[1], y_q.shape[1],
+              out.data_ptr(), _stream())
+    return out.reshape(())
+
+
+def rd_loss(fine, target, fbpp, lam, alpha=0.7, max_rate=100.0):
+    """RateDistortionLoss('hybrid') (pppe_pcd_ae.py:807-838): alpha*Chamfer + (1-alpha)*smooth-L1 + lam*rate."""
+    chamfer, _ = ops.chamfer_distance(fine, target)
+    l1 = SmoothL1Fn.apply(fine, target)
+    dist = alpha * chamfer + (1 - alpha) * l1
+    rate = fbpp.clamp(0.0, max_rate)
+    return dist + lam * rate, dist.detach(), rate.detach()
+
+
+class Adam:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) + clip_grad_norm_(max_norm) as HIP kernels."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def step(self, max_norm=None):
+        self.t += 1
+        live = [(p, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        acc = None
+        if max_norm is not None and live:
+            acc = torch.zeros(1, device=live[0][0].device, dtype=torch.float64)
+            for p, _, _ in live:
+                _lib.call("pccx_sumsq_accumulate", p.grad.contiguous().data_ptr(), p.numel(), acc.data_ptr(), _stream())
+        for p, m, v in live:
+            _lib.call("pccx_adam_step", p.data_ptr(), p.grad.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                      acc.data_ptr() if acc is not None else None, float(max_norm or 0.0), float(self.lr), float(self.betas[0]),
+                      float(self.betas[1]), float(self.eps), self.t, _stream())
+        return acc
+
+
+def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0):
+    """One iteration of train_one_epoch (train_pppe_pcd_ae.py:184-226).  ``opt`` covers ae + prob
+    parameters as the reference's optimizer does; returns (loss, dist, rate) as python floats."""
+    for p in opt.params:
+        p.grad = None
+    coarse, fine, cond, y_q = forward_train(model, batch_x, starts)
+    fbpp = estimate_bits_per_point(model, y_q, cond.detach())
+    loss, dist, rate = rd_loss(fine, batch_x, fbpp, lam)
+    loss.backward()
+    opt.step(max_norm=grad_clip)
+    return float(loss), float(dist), float(rate)
