@@ -117,6 +117,51 @@ def cpu_baseline(max_clouds, budget_s):
             "ms_per_cloud": 1e3 * tot / n}
 
 
+def bench_pppe_train(args, world, rank, dev, cdev):
+    """Secondary workload: one optimisation step of the pppe fast path per "step" (forward in train mode,
+    hybrid Chamfer + smooth-L1 loss, backward, clip, Adam; data-parallel gradient all-reduce when N > 1)."""
+    import torch.distributed as dist
+    from pccx import families, synth, train
+    Bt = 4                                                   # train_pppe_pcd_ae.py: batch_size 4
+    model = families.PointCloudAE(64, 16, N_POINTS)
+    model.load_state_dict(seeded_state_dict(model, 32))
+    for k, v in model.state_dict().items():                  # sane BatchNorm statistics
+        if k.endswith("running_var"):
+            v.fill_(1.0)
+    model = model.to(dev)
+    opt = train.Adam(model.parameters(), lr=1e-3)
+    x = torch.from_numpy(np.stack([synth.cad_cloud(900 + rank * Bt + i, N_POINTS) for i in range(Bt)])).to(dev)
+    rng = np.random.default_rng(rank)
+    starts = [[rng.integers(0, N_POINTS, Bt), rng.integers(0, N_POINTS, Bt)], rng.integers(0, 512, Bt), rng.integers(0, 128, Bt)]
+    for _ in range(args.warmup):
+        out = train.train_step(model, opt, x, starts, lam=1e-3, data_parallel=world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = train.train_step(model, opt, x, starts, lam=1e-3, data_parallel=world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": world * Bt * args.steps / dt,
+            "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU, fp32",
+                       "parallelism": f"dp{world}", "weights": "seeded random"},
+            "roofline": None, "cpu_baseline": None, "loss": out[0],
+            "note": "secondary, correctness-first path: unfused layers, weights re-packed every step"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +171,9 @@ def main():
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
     ap.add_argument("--cpu-clouds", type=int, default=64, help="max clouds in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
+    ap.add_argument("--workload", default="ipdae", choices=["ipdae", "pppe-train"],
+                    help="ipdae = the headline compress+decompress path (default); pppe-train = the training step of "
+                         "configs[4] (train_pppe_pcd_ae.py:184-226, batch 4 x 8192 per GPU), a secondary measurement")
     ap.add_argument("--pcie", action="store_true",
                     help="also move the clouds host->device and the streams / reconstruction device->host inside the "
                          "timed region (the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
@@ -149,6 +197,9 @@ def main():
             dist.init_process_group("gloo")
 
     from pccx import codec, models, ops, synth
+
+    if args.workload == "pppe-train":
+        return bench_pppe_train(args, world, rank, dev, cdev)
 
     ae = models.AE(K_PATCH, K_SMALL, D_LAT, L_LEV)
     ae.load_state_dict(seeded_state_dict(ae, AE_SEED, last_gain=AE_LAST_GAIN))

@@ -45,3 +45,39 @@ def max_over_ranks(seconds, device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def allreduce_mean_(tensors, bucket_bytes=64 << 20):
+    """Data-parallel gradient averaging (the one collective of the configs[4] training step): flatten the
+    tensors into buckets of ``bucket_bytes`` (xGMI is point-to-point, ring all-reduce is per-link bound, so
+    a few large messages beat many small ones; the pppe model is 116 MB of fp32 gradients = 2 buckets),
+    all-reduce each bucket over the default process group (RCCL on GPUs, gloo in the CPU rehearsal) and
+    scatter the averages back in place.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    n_buckets, cur, size = 0, [], 0
+
+    def flush():
+        nonlocal cur, size, n_buckets
+        if not cur:
+            return
+        flat = torch.cat([t.reshape(-1) for t in cur])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+        off = 0
+        for t in cur:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        cur, size = [], 0
+        n_buckets += 1
+
+    for t in tensors:
+        if t is None:
+            continue
+        cur.append(t)
+        size += t.numel() * t.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+    return n_buckets

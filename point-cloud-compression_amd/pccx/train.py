@@ -293,14 +293,19 @@ class Adam:
         return acc
 
 
-def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0):
+def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_parallel=False):
     """One iteration of train_one_epoch (train_pppe_pcd_ae.py:184-226).  ``opt`` covers ae + prob
-    parameters as the reference's optimizer does; returns (loss, dist, rate) as python floats."""
+    parameters as the reference's optimizer does; returns (loss, dist, rate) as python floats.
+    data_parallel=True averages the gradients over the ranks of the default process group (bucketed
+    all-reduce, dist.allreduce_mean_) between backward and the clipped Adam step."""
     for p in opt.params:
         p.grad = None
     coarse, fine, cond, y_q = forward_train(model, batch_x, starts)
     fbpp = estimate_bits_per_point(model, y_q, cond.detach())
     loss, dist, rate = rd_loss(fine, batch_x, fbpp, lam)
     loss.backward()
+    if data_parallel:
+        from . import dist as pdist
+        pdist.allreduce_mean_([p.grad for p in opt.params])
     opt.step(max_norm=grad_clip)
-    return float(loss), float(dist), float(rate)
+    return float(loss.detach()), float(dist), float(rate)

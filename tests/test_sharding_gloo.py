@@ -63,3 +63,33 @@ def test_fps_start_is_sharding_independent():
 def test_single_process_fallback_needs_no_process_group():
     g = pdist.gather_summaries([1, 2, 3, 4, 5, 6])
     assert g.shape == (1, 6) and pdist.max_over_ranks(3.5) == 3.5
+
+
+def _ar_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(rank)
+    grads = [torch.randn(s, generator=g) for s in ((7, 3), (1000,), (64, 64), (5,), (300, 40))] + [None]
+    keep = [t.clone() for t in grads if t is not None]
+    nb = pdist.allreduce_mean_(grads, bucket_bytes=4096)          # forces several buckets
+    q.put((rank, nb, [t.numpy() for t in grads if t is not None], [t.numpy() for t in keep]))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks():
+    """The collective of the data-parallel training step: bucketed mean over ranks equals the plain mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ar_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] >= 2
+    for i in range(len(res[0][2])):
+        want = (res[0][3][i] + res[1][3][i]) / 2
+        np.testing.assert_allclose(res[0][2][i], want, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(res[1][2][i], want, rtol=1e-6, atol=1e-7)
