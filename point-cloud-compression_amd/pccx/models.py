@@ -59,7 +59,7 @@ def workspace(tag, numel, device):
     """Persistent scratch buffers (HBM is 288 GB: keep the big intermediates resident instead of going
     through the allocator every call).  Stream-ordered reuse is safe: every consumer of a buffer is
     enqueued before its next producer on the same stream."""
-    key = (tag, str(device))
+    key = (tag, str(device), torch.cuda.current_stream().cuda_stream)      # one buffer per stream: streams run concurrently
     t = _WS.get(key)
     if t is None or t.numel() < numel:
         _WS[key] = t = torch.empty(int(numel), device=device, dtype=torch.float32)
