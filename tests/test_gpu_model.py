@@ -201,3 +201,34 @@ def test_range_coder_adversarial_tables_match_oracle_bit_for_bit():
         want = cport.range_encode(cdf[b].astype(np.int32), sym[b].astype(np.int16))
         assert bytes(by[b, :int(nb[b])].cpu().numpy()) == want, f"stream {b} (kind {b % 6})"
         assert np.array_equal(cport.range_decode(cdf[b].astype(np.int32), want), sym[b])
+
+
+@pytest.mark.parametrize("L,nsym", [(3, 1000), (2, 77), (15, 1024), (31, 130), (62, 257), (63, 64), (64, 200), (7, 1)])
+def test_range_coder_other_alphabets_and_ragged_lengths(L, nsym):
+    """Alphabet sizes that change the lane layout of the device decoder (64 // (L+1) symbols per block of
+    lanes; L = 64 takes the one-lane-per-cloud kernel) and stream lengths that are not multiples of a
+    block: bytes equal the oracle's, and the round trip is lossless."""
+    rng = np.random.default_rng(100 * L + nsym)
+    B, Lp = 5, L + 1
+    cdf = np.zeros((B, nsym, Lp), dtype=np.int64)
+    sym = rng.integers(0, L, size=(B, nsym))
+    for b in range(B):
+        for i in range(nsym):
+            if b == 0:        # uniform-ish
+                cdf[b, i, :L] = (np.arange(L) * 65536) // L
+            elif b == 1:      # one dominant symbol, 1-count rest
+                k = int(rng.integers(0, L))
+                w = np.ones(L, dtype=np.int64); w[k] = 65536 - (L - 1)
+                cdf[b, i, 1:L] = np.cumsum(w)[:-1]
+            else:             # random strictly increasing
+                cdf[b, i, 1:L] = np.sort(rng.choice(np.arange(1, 0xFFFF), size=L - 1, replace=False))
+    ci = torch.from_numpy(cdf.astype(np.int32)).cuda()
+    q = (sym - L // 2).astype(np.float32)
+    by, nb = models.range_encode(ci, torch.from_numpy(q).cuda(), L, cap=4 * nsym + 16)
+    assert (nb > 0).all()
+    back = models.range_decode(ci, by, nb, L)
+    assert np.array_equal(back.cpu().numpy(), q)
+    for b in range(B):
+        want = cport.range_encode(cdf[b].astype(np.int32), sym[b].astype(np.int16))
+        assert bytes(by[b, :int(nb[b])].cpu().numpy()) == want, f"stream {b}"
+        assert np.array_equal(cport.range_decode(cdf[b].astype(np.int32), want), sym[b])
