@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="clouds per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="clouds per GPU per step")
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
     ap.add_argument("--cpu-clouds", type=int, default=64, help="max clouds in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")

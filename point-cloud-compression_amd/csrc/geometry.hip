@@ -103,7 +103,6 @@ extern "C" int pccx_normalize(const float *pc, int B, int N, double margin, floa
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(pc && out && center && longest, "pccx_normalize: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1, "pccx_normalize: bad shape B=%d N=%d", B, N);
-    if (B == 0) return PCCX_OK;
     hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, pc, N, (float)(1.0 - margin), out,
                        center, longest);
     PCCX_CHECK_LAUNCH();
@@ -116,7 +115,6 @@ extern "C" int pccx_denormalize(const float *pc, int B, int N, double margin, co
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(pc && out && center && longest, "pccx_denormalize: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1, "pccx_denormalize: bad shape B=%d N=%d", B, N);
-    if (B == 0) return PCCX_OK;
     int gx = (3 * N + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(denormalize_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, pc, N, (float)(1.0 - margin),
@@ -147,7 +145,6 @@ extern "C" int pccx_gather(const float *points, int B, int N, int C, const int64
     if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(points && idx && out, "pccx_gather: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && C >= 1 && M >= 0, "pccx_gather: bad shape");
-    if (B == 0 || M == 0) return PCCX_OK;
     size_t total = (size_t)M * C;
     int gx = (int)((total + 255) / 256);
     if (gx > 2048) gx = 2048;
@@ -300,7 +297,6 @@ extern "C" int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_
     if (B == 0 || npoint == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(xyz && idx_out, "pccx_fps: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && npoint >= 0, "pccx_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
-    if (B == 0 || npoint == 0) return PCCX_OK;
     hipStream_t st = (hipStream_t)stream;
     if (N <= 1024) return launch_fps<1>(xyz, B, N, npoint, start_idx, idx_out, st);
     if (N <= 2048) return launch_fps<2>(xyz, B, N, npoint, start_idx, idx_out, st);

@@ -159,7 +159,6 @@ extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, i
     PCCX_CHECK_ARG(K >= 1 && K <= N && K <= 1024, "pccx_knn: need 1 <= K <= min(N,1024), got K=%d N=%d", K, N);
     PCCX_CHECK_ARG(N <= 32768, "pccx_knn: N=%d > 32768 unsupported", N);
     PCCX_CHECK_ARG(B <= 65535, "pccx_knn: B=%d > 65535 unsupported", B);
-    if (B == 0 || M == 0) return PCCX_OK;
     int Kp = 2;
     while (Kp < K) Kp <<= 1;
     size_t shmem = (size_t)Kp * 8 + (size_t)N * 4 + (256 + 4 + 3 + 1) * 4;
@@ -210,7 +209,6 @@ extern "C" int pccx_ball_query(const float *q, int B, int M, const float *ref, i
     PCCX_CHECK_ARG(q && ref && dists && idx, "pccx_ball_query: null pointer");
     PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1 && K >= 1, "pccx_ball_query: bad shape");
     PCCX_CHECK_ARG(B <= 65535, "pccx_ball_query: B=%d > 65535 unsupported", B);
-    if (B == 0 || M == 0) return PCCX_OK;
     hipLaunchKernelGGL(ball_query_kernel, dim3((M + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q, M, ref, N, K,
                        radius * radius, dists, idx);
     PCCX_CHECK_LAUNCH();
@@ -272,7 +270,6 @@ extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q,
     PCCX_CHECK_ARG(X && Y && d2, "pccx_nn_dist: null pointer");
     PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1, "pccx_nn_dist: bad shape");
     PCCX_CHECK_ARG(B <= 65535, "pccx_nn_dist: B=%d > 65535 unsupported", B);
-    if (B == 0) return PCCX_OK;
     int gx = (P + 256 * NND_XPT - 1) / (256 * NND_XPT);
     hipLaunchKernelGGL(nn_dist_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
     PCCX_CHECK_LAUNCH();
@@ -352,7 +349,6 @@ extern "C" int pccx_estimate_normals(const float *xyz, int B, int N, const int64
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(xyz && nbr && normals, "pccx_estimate_normals: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && K >= 1 && B <= 65535, "pccx_estimate_normals: bad shape");
-    if (B == 0) return PCCX_OK;
     hipLaunchKernelGGL(normals_pca_kernel, dim3((N + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, xyz, N, nbr, K, normals);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
@@ -377,7 +373,6 @@ extern "C" int pccx_point_plane_err(const float *X, int B, int P, const float *Y
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(X && Y && normals_Y && nn && err, "pccx_point_plane_err: null pointer");
     PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1 && B <= 65535, "pccx_point_plane_err: bad shape");
-    if (B == 0) return PCCX_OK;
     hipLaunchKernelGGL(plane_err_kernel, dim3((P + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, normals_Y, Q, nn, err);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;

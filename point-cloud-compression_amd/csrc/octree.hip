@@ -162,7 +162,6 @@ extern "C" int pccx_octree_encode(const float *centres, int B, int S, int N, dou
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(centres && bits && nbits && depth && bytes && nbytes, "pccx_octree_encode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && S >= 1 && S <= 1024 && N >= 1, "pccx_octree_encode: need 1 <= S <= 1024, N >= 1 (S=%d N=%d)", S, N);
-    if (B == 0) return PCCX_OK;
     int T = 64;
     while (T < S) T <<= 1;
     const int cap = pccx_octree_bits_capacity(S);
@@ -278,7 +277,6 @@ extern "C" int pccx_octree_decode(const uint8_t *bytes, int stride, const int32_
     PCCX_CHECK_ARG(bytes && nbytes && out, "pccx_octree_decode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && stride >= 1 && S_out >= 1, "pccx_octree_decode: bad shape");
     PCCX_CHECK_ARG(mode == 0 || mode == 1, "pccx_octree_decode: mode must be 0 (reference) or 1 (full)");
-    if (B == 0) return PCCX_OK;
     if (mode == 0) {
         PCCX_CHECK_ARG(S_out == 64, "pccx_octree_decode: reference mode always yields 64 points (octree_np.py:100), S_out=%d",
                        S_out);

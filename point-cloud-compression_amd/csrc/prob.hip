@@ -146,7 +146,6 @@ extern "C" int pccx_prob_forward(const float *centres, int B, int S, int d, int 
     PCCX_CHECK_ARG(pmf || cdf || cdf_int, "pccx_prob_forward: no output requested");
     PCCX_CHECK_ARG(B >= 0 && S >= 16 && S % 16 == 0, "pccx_prob_forward: need S %% 16 == 0 (S=%d)", S);
     PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1 && L <= 15 && d * L <= 128, "pccx_prob_forward: unsupported d=%d L=%d", d, L);
-    if (B == 0) return PCCX_OK;
     hipLaunchKernelGGL(prob_forward_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, centres, S, d, L, prob_blob, pmf, cdf,
                        cdf_int);
     PCCX_CHECK_LAUNCH();

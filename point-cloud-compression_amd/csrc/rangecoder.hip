@@ -346,7 +346,6 @@ extern "C" int pccx_range_encode(const int32_t *cdf_int, const float *latent_q, 
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(cdf_int && latent_q && out && nbytes, "pccx_range_encode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && cap >= 8, "pccx_range_encode: bad shape");
-    if (B == 0) return PCCX_OK;
     const size_t lds = (size_t)nsym * 8 + (size_t)((cap + 3) / 4) * 4;
     if (lds <= RC_MAX_LDS_BYTES) {
         hipLaunchKernelGGL(range_encode_wave_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cdf_int, latent_q, nsym, L + 1,
@@ -366,7 +365,6 @@ extern "C" int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int 
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(cdf_int && in && nbytes && latent_q, "pccx_range_decode: null pointer");
     PCCX_CHECK_ARG(B >= 0 && nsym >= 0 && L >= 1 && stride >= 1, "pccx_range_decode: bad shape");
-    if (B == 0) return PCCX_OK;
     const size_t lds = (((size_t)nsym * (L + 1) * 2 + 3) & ~(size_t)3) + (size_t)((stride + 3) / 4) * 4 + (size_t)nsym;
     if (lds <= RC_MAX_LDS_BYTES && L >= 2 && L + 1 <= 64) {
         hipLaunchKernelGGL(range_decode_wave_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cdf_int, in, stride, nbytes, nsym,
