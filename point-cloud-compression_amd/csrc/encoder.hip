@@ -23,6 +23,13 @@
 // Output layout feat[P][8][K][16]: 16-channel groups are contiguous per point, which is what the
 // PointNet kernel loads as its B operand (one 16-byte load per lane, 1 KiB per wave).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restrict__ x, int K, const float *__restrict__ blob,
                                                          float *__restrict__ feat)
 {
@@ -51,12 +58,39 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
     }
     __syncthreads();
 
-    // ---- phase 1: kNN-16 inside the patch (pn_kit.py:190, K=16).  Only the SET matters (max-pool),
-    // so pass 1 keeps just the 16 smallest distances sorted (one v_med3 per slot per candidate) and
-    // pass 2 collects the indices below the 16th distance, plus ties at it in index order -- the
-    // same set as the oracle's (distance, index) sort.
+    // ---- phase 1: kNN-16 inside the patch (pn_kit.py:190, K=16).  Only the SET matters (max-pool).
+    // Fast path, one pass: the candidate index rides in the low bits of the distance (key = distance bits with
+    // the low log2(K) bits replaced by j; distances are >= 0 so their bit patterns order like the floats), and 17
+    // sorted keys are kept with one v_med3_u32 per slot per candidate.  Truncation is monotone, so whenever the
+    // 16th and 17th keys differ in their distance part every selected candidate is strictly nearer than every
+    // other one and the 16 indices are exactly the oracle's set.  Otherwise (a tie or near-tie at the boundary)
+    // the lane takes the exact two-pass selection: 16 smallest distances by v_med3_f32, then the indices below
+    // the 16th distance plus ties at it in index order -- the oracle's (distance, index) sort.
+    unsigned jmask = 15u;
+    while ((int)jmask < K - 1) jmask = 2u * jmask + 1u;
     for (int i = tid; i < K; i += 256) {
         const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
+        unsigned tk[17];
+#pragma unroll
+        for (int s = 0; s < 17; ++s) tk[s] = 0xFFFFFFFFu;
+        for (int j0 = 0; j0 < K; j0 += 4) {              // K % 16 == 0; four broadcast reads in flight
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                d[u] = pccx_sqdist(px, py, pz, sx[3 * (j0 + u)], sx[3 * (j0 + u) + 1], sx[3 * (j0 + u) + 2]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned key = (__float_as_uint(d[u]) & ~jmask) | (unsigned)(j0 + u);
+#pragma unroll
+                for (int s = 16; s >= 1; --s) tk[s] = umed3(tk[s - 1], key, tk[s]);
+                tk[0] = min(tk[0], key);
+            }
+        }
+        if (((tk[15] ^ tk[16]) & ~jmask) != 0u) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)(tk[s] & jmask);
+            continue;
+        }
         float td[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) td[s] = INFINITY;

@@ -115,6 +115,41 @@ def test_sa_knn_ties_on_lattice_patch(nets):
     np.testing.assert_allclose(latent.cpu().numpy(), olat.numpy(), rtol=0, atol=5e-5)
 
 
+def _sa_features(ae, patches):
+    """ae.sa through the C ABI: (P,K,3) -> (P,128,K) feature map (device layout [P][8][K][16])."""
+    from pccx import _lib
+    x = torch.from_numpy(patches).cuda().contiguous()
+    P, Kp, _ = x.shape
+    enc, _ = ae._blobs(x.device)
+    feat = torch.empty(P * 8 * Kp * 16, device="cuda", dtype=torch.float32)
+    _lib.call("pccx_sa_forward", x.data_ptr(), P, Kp, enc.data_ptr(), feat.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return feat.view(P, 8, Kp, 16).permute(0, 1, 3, 2).reshape(P, 128, Kp).cpu().numpy()
+
+
+def test_sa_feature_map_with_ties_and_near_ties_at_the_16th_neighbour(nets):
+    """The in-patch kNN-16 selects with the candidate index packed into the low bits of the distance and
+    falls back to the exact (distance, index) rule when ranks 16 and 17 agree in the kept bits.  Patches
+    built to hit both sides of that test: exact ties (lattice), distances that differ only in the last few
+    mantissa bits (a jittered shell around point 0, seen from point 0 every neighbour is a near-tie),
+    duplicated points, and an ordinary random patch.  A wrong neighbour changes that point's features far
+    beyond the tolerance."""
+    ae, _, oae, _ = nets
+    rng = np.random.default_rng(5)
+    lattice = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(4), indexing="ij"), -1).reshape(-1, 3)
+    lattice = ((lattice[rng.permutation(256)] - 3.5) * 0.05).astype(np.float32)
+    dirs = rng.normal(size=(255, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    radius = 0.3 * (1.0 + rng.integers(-40, 41, size=(255, 1)) * 2.0 ** -24)      # +-40 ulp of radial jitter
+    shell = np.concatenate([np.zeros((1, 3)), dirs * radius]).astype(np.float32)
+    dup = rng.uniform(-0.4, 0.4, size=(128, 3)).astype(np.float32)
+    dup = np.concatenate([dup, dup])[rng.permutation(256)]
+    rand = rng.uniform(-0.5, 0.5, size=(256, 3)).astype(np.float32)
+    patches = np.stack([lattice, shell, dup, rand])
+    got = _sa_features(ae, patches)
+    with torch.no_grad():
+        _, want = oae.sa(torch.from_numpy(patches).permute(0, 2, 1))
+    np.testing.assert_allclose(got, want.numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_decode_reassembly_matches_decompress_ops(nets):
     """pc_out path = decompress.py:104-116: / scale, + centres, denormalize."""
     ae, _, oae, _ = nets
