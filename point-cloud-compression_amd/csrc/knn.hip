@@ -224,10 +224,16 @@ extern "C" int pccx_ball_query(const float *q, int B, int M, const float *ref, i
 // ------------------------------------------------------------------------------------------
 #define NND_TILE 1024
 #define NND_XPT 4
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two reference points per step: the three differences, squares and the two adds run as packed fp32
+// (v_pk_add_f32 / v_pk_mul_f32, no contraction: the file is built with -ffp-contract=off), the same
+// operation sequence per pair as pccx_sqdist.  Without the argmin the update is one v_min3_f32.
+template <bool WANT_NN>
 __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, int Q,
                                                       float *__restrict__ d2, int32_t *__restrict__ nn)
 {
-    __shared__ float ty[NND_TILE * 3];
+    __shared__ __attribute__((aligned(8))) float tyx[NND_TILE], tyy[NND_TILE], tyz[NND_TILE];
     const int b = blockIdx.y, tid = threadIdx.x;
     const float *xp = X + (size_t)b * P * 3;
     const float *yp = Y + (size_t)b * Q * 3;
@@ -241,16 +247,27 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
         best[j] = INFINITY; bi[j] = -1;
     }
     for (int base = 0; base < Q; base += NND_TILE) {
-        int cnt = Q - base < NND_TILE ? Q - base : NND_TILE;
+        const int cnt = Q - base < NND_TILE ? Q - base : NND_TILE;
+        const int cnt2 = (cnt + 1) & ~1;                  // an odd tail repeats its last point: no effect on min / first argmin
         __syncthreads();
-        for (int t = tid; t < cnt * 3; t += 256) ty[t] = yp[(size_t)base * 3 + t];
+        for (int t = tid; t < cnt2; t += 256) {
+            const size_t src = (size_t)(base + (t < cnt ? t : cnt - 1)) * 3;
+            tyx[t] = yp[src]; tyy[t] = yp[src + 1]; tyz[t] = yp[src + 2];
+        }
         __syncthreads();
-        for (int t = 0; t < cnt; ++t) {
-            float yx = ty[3 * t], yy = ty[3 * t + 1], yz = ty[3 * t + 2];
+        for (int t = 0; t < cnt2; t += 2) {
+            const f32x2 yx = *(const f32x2 *)&tyx[t], yy = *(const f32x2 *)&tyy[t], yz = *(const f32x2 *)&tyz[t];
 #pragma unroll
             for (int j = 0; j < NND_XPT; ++j) {
-                float d = pccx_sqdist(x[j][0], x[j][1], x[j][2], yx, yy, yz);
-                if (d < best[j]) { best[j] = d; bi[j] = base + t; }
+                const f32x2 dx = x[j][0] - yx, dy = x[j][1] - yy, dz = x[j][2] - yz;
+                f32x2 d = dx * dx;
+                d = d + dy * dy;
+                d = d + dz * dz;
+                if (WANT_NN) {
+                    if (d.x < best[j]) { best[j] = d.x; bi[j] = base + t; }
+                    if (d.y < best[j]) { best[j] = d.y; bi[j] = base + t + 1; }
+                } else
+                    best[j] = fminf(fminf(best[j], d.x), d.y);
             }
         }
     }
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
         int i = blockIdx.x * (256 * NND_XPT) + j * 256 + tid;
         if (i < P) {
             d2[(size_t)b * P + i] = best[j];
-            if (nn) nn[(size_t)b * P + i] = bi[j];
+            if (WANT_NN) nn[(size_t)b * P + i] = bi[j];
         }
     }
 }
@@ -271,7 +288,10 @@ extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q,
     PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1, "pccx_nn_dist: bad shape");
     PCCX_CHECK_ARG(B <= 65535, "pccx_nn_dist: B=%d > 65535 unsupported", B);
     int gx = (P + 256 * NND_XPT - 1) / (256 * NND_XPT);
-    hipLaunchKernelGGL(nn_dist_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
+    if (nn)
+        hipLaunchKernelGGL(nn_dist_kernel<true>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
+    else
+        hipLaunchKernelGGL(nn_dist_kernel<false>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
