@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table for the hot path: every kernel of SURVEY 8(a) on its configs[1] shape
+(1024 clouds x 8192 points, S=64 patches of K=256; PPPF shapes for ball query), timed with HIP events
+on the stream the kernels are launched on, against the bound SURVEY 8(d) assigns to it.
+
+  python tools/kernel_rooflines.py [--clouds 1024] [--iters 5] > profiles/<round>_kernel_rooflines.json
+
+`achieved` = algorithmic bytes (or flops) per launch / average launch time; the algorithmic figures are
+SURVEY 8(d)'s per-cloud numbers, repeated in DESIGN.md.  Peaks: HBM 8 TB/s, fp32 matrix 157.3 TFLOP/s,
+fp32 vector without FMA 39.3 T instr-lanes/s x2 for packed math (MI355X_MICROARCH.md).
+No oracle, no reference: this only times the product path.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "point-cloud-compression_amd"))
+from pccx import models, ops, synth  # noqa: E402
+
+HBM_PEAK = 8000.0          # GB/s
+MFMA_F32_PEAK = 157.3      # TFLOP/s
+VALU_F32_PEAK = 78.6       # TFLOP/s of non-fused packed fp32 (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+
+
+def timed(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clouds", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    B, N, S, K, k, d, L = args.clouds, 8192, 64, 256, 128, 16, 7
+    dev = torch.device("cuda:0")
+    base = np.stack([synth.cad_cloud(11 + i, N) for i in range(32)])
+    clouds = torch.from_numpy(np.concatenate([base] * ((B + 31) // 32))[:B]).to(dev)
+    starts = torch.from_numpy((np.arange(B) * 97) % N).to(dev)
+    rows = []
+
+    def row(name, ms, bound, work, unit, peak, note):
+        ach = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
+        rows.append({"kernel": name, "ms_per_launch": round(ms, 4), "bound": bound, "achieved": round(ach, 2), "peak": peak,
+                     "unit": unit, "frac": round(ach / peak, 4), "algorithmic_work_per_launch": work, "note": note})
+
+    xyz, center, longest = ops.normalize(clouds)
+    row("normalize", timed(lambda: ops.normalize(clouds), args.iters), "hbm", B * N * 12 * 3, "GB/s", HBM_PEAK,
+        "2 reads + 1 write of the cloud")
+    ms = timed(lambda: ops.farthest_point_sample_batch(xyz, S, starts), args.iters)
+    row("fps (LDS/register side)", ms, "lds", B * S * N * 20, "GB/s", HBM_PEAK, "S*N*20 B per cloud; resident in registers+LDS, "
+        "so this exceeds the HBM peak by design: latency-bound on S dependent rounds")
+    row("fps (HBM minimum)", ms, "hbm", B * N * 12, "GB/s", HBM_PEAK, "the cloud is read once")
+    idx = ops.farthest_point_sample_batch(xyz, S, starts)
+    centres = ops.index_points(xyz, idx)
+    row("gather (index_points)", timed(lambda: ops.index_points(xyz, idx), args.iters), "hbm", B * S * (12 + 8 + 12), "GB/s",
+        HBM_PEAK, "S rows per cloud: launch-latency bound")
+    ms = timed(lambda: ops.knn_points(centres, xyz, K, True, 2.0), args.iters)
+    row("knn patching K=256", ms, "hbm", B * (S * N * 12 + S * K * (12 + 4 + 8)), "GB/s", HBM_PEAK,
+        "S*N*12 B of candidate reads per cloud (L2/LDS side; HBM minimum 98 KB) + outputs")
+    qb = xyz[:, :512].contiguous()
+    cb = ops.sample_farthest_points(qb, 128)[0]
+    ms = timed(lambda: ops.ball_query(cb, qb, 64, 0.2), args.iters)
+    row("ball_query 128x512 r=0.2 nsample=64", ms, "hbm", B * (128 * 512 * 12 + 128 * 64 * 8), "GB/s", HBM_PEAK,
+        "PPPF sa1 shape (pointnet_sa_module.py:18); candidates broadcast from LDS")
+    patches = ops.knn_points(centres, xyz, K, True, 2.0)[2]
+    ms = timed(lambda: ops.octree_encode(centres, N, 0.25), args.iters)
+    row("octree_encode (depth search + bits + bytes)", ms, "hbm", B * (S * 12 + 400), "GB/s", HBM_PEAK, "one wave per cloud: latency bound")
+    other = clouds.roll(1, 0).contiguous()
+    ms = timed(lambda: ops.nn_dist(clouds, other), args.iters)
+    row("nn_dist (Chamfer / D1, one direction)", ms, "valu", B * N * N * 8, "TFLOP/s", VALU_F32_PEAK,
+        "8 flop per pair, packed fp32 without FMA; fused-tiled HBM traffic is 196 KB per cloud")
+    row("nn_dist as unfused bytes", ms, "hbm", B * N * N * 12, "GB/s", HBM_PEAK, "8192^2*12 B per cloud per direction if read from HBM "
+        "per pair (SURVEY 8d) -- served from LDS tiles instead")
+
+    ae = models.AE(K, k, d, L)
+    prob = models.ConditionalProbabilityModel(L, d)
+    ae.pack(dev)
+    prob.pack(dev)
+    pt = patches.reshape(B * S, K, 3)
+    for _ in range(2):
+        ae.encode(pt)
+    t = ops.StageTimer()
+    ops.set_timer(t)
+    for _ in range(args.iters):
+        lq = ae.encode(pt)[2]
+    st = t.totals_ms()
+    ops.set_timer(None)
+    for name, flop in (("sa_forward", 84.7e6), ("pn_forward", 96.7e6)):
+        row(name, st[name][0] / st[name][1], "mfma", B * S * flop, "TFLOP/s", MFMA_F32_PEAK,
+            "fp32 matrix cores; flop per patch from the layer shapes of AE.py:16-17")
+    row("ae_decode (head + main)", timed(lambda: ae.decode(lq), args.iters), "mfma", B * S * 41.4e6, "TFLOP/s", MFMA_F32_PEAK,
+        "fp32 matrix cores; AE.py:19-27")
+    ms = timed(lambda: prob.run(centres, ("cdf_int",)), args.iters)
+    row("prob_forward", ms, "mfma", B * 0.063e9, "TFLOP/s", MFMA_F32_PEAK, "one workgroup per cloud, NT=1: latency/L2 bound")
+    cdf = prob.run(centres, ("cdf_int",))["cdf_int"]
+    q = torch.randint(-3, 4, (B, S * d), device=dev).float()
+    ms = timed(lambda: models.range_encode(cdf, q, L), args.iters)
+    rows.append({"kernel": "range_encode", "ms_per_launch": round(ms, 4), "bound": "latency", "achieved": round(B * S * d / ms / 1e6, 2),
+                 "unit": "G symbols/s", "note": "serial per cloud: %.0f ns per symbol per stream" % (ms * 1e6 / (S * d))})
+    by, nb = models.range_encode(cdf, q, L)
+    ms = timed(lambda: models.range_decode(cdf, by, nb, L), args.iters)
+    rows.append({"kernel": "range_decode", "ms_per_launch": round(ms, 4), "bound": "latency", "achieved": round(B * S * d / ms / 1e6, 2),
+                 "unit": "G symbols/s", "note": "serial per cloud: %.0f ns per symbol per stream" % (ms * 1e6 / (S * d))})
+    print(json.dumps({"device": torch.cuda.get_device_name(0), "clouds_per_launch": B, "points_per_cloud": N, "rows": rows}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
