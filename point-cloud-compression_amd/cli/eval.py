@@ -53,7 +53,7 @@ def main():
     df = pd.DataFrame(rows, columns=['filename', 'p2pointPSNR', 'p2planePSNR', 'chamfer_distance', 'n_points_input',
                                      'n_points_output', 'bpp', 'uniformity coefficient'])
     if len(df):
-        print(f"Done! The average p2pointPSNR: {round(df.p2pointPSNR.mean(), 3)} | chamfer distance: "
+        print(f"Done! The average p2pointPSNR: {round(df.p2pointPSNR.mean(), 3)} | p2plane PSNR: {round(df.p2planePSNR.mean(), 3)} | chamfer distance: "
               f"{round(df.chamfer_distance.mean(), 8)} | bpp: {round(df.bpp.mean(), 3)} | uc: {round(df['uniformity coefficient'].mean(), 3)}")
     os.makedirs(os.path.dirname(os.path.abspath(args.output_file)), exist_ok=True)
     df.to_csv(args.output_file)
