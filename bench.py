@@ -119,7 +119,7 @@ def cpu_baseline(max_clouds, budget_s):
 
 def bench_pppe_train(args, world, rank, dev, cdev):
     """Secondary workload: one optimisation step of the pppe fast path per "step" (forward in train mode,
-    hybrid Chamfer + smooth-L1 loss, backward, clip, Adam; data-parallel gradient all-reduce when N > 1)."""
+    Chamfer rate-distortion loss as the script builds it, backward, clip, Adam; data-parallel gradient all-reduce when N > 1)."""
     import torch.distributed as dist
     from pccx import families, synth, train
     Bt = 4                                                   # train_pppe_pcd_ae.py: batch_size 4

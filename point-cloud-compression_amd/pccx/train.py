@@ -2,7 +2,7 @@
 
     coarse, recon, feats, y = ae(batch_x)                         # forward, BatchNorm in TRAIN mode
     fbpp = estimate_bits_per_point_conditional(y, feats, prob)    # no-grad rate term
-    loss, dist, rate = criterion(recon, batch_x, fbpp, lam)       # hybrid: 0.7 Chamfer + 0.3 smooth-L1
+    loss, dist, rate = criterion(recon, batch_x, fbpp, lam)       # get_loss("chamfer"): Chamfer + lam * rate
     loss.backward(); clip_grad_norm_(params, 1.0); optimizer.step()   # Adam
 
 torch.autograd only sequences the backward: every Function below is a pair of HIP launches behind the
@@ -260,11 +260,17 @@ def estimate_bits_per_point(model, y_q, cond):
     return out.reshape(())
 
 
-def rd_loss(fine, target, fbpp, lam, alpha=0.7, max_rate=100.0):
-    """RateDistortionLoss('hybrid') (pppe_pcd_ae.py:807-838): alpha*Chamfer + (1-alpha)*smooth-L1 + lam*rate."""
-    chamfer, _ = ops.chamfer_distance(fine, target)
-    l1 = SmoothL1Fn.apply(fine, target)
-    dist = alpha * chamfer + (1 - alpha) * l1
+def rd_loss(fine, target, fbpp, lam, loss_type="chamfer", alpha=0.7, max_rate=100.0):
+    """RateDistortionLoss (pppe_pcd_ae.py:807-838): distortion + lam * clamp(rate).  loss_type "chamfer" is what the
+    training script builds (get_loss("chamfer"), train_pppe_pcd_ae.py:48); "l1" = smooth-L1; anything else is the
+    class's hybrid alpha*Chamfer + (1-alpha)*smooth-L1."""
+    if loss_type == "chamfer":
+        dist, _ = ops.chamfer_distance(fine, target)
+    elif loss_type == "l1":
+        dist = SmoothL1Fn.apply(fine, target)
+    else:
+        chamfer, _ = ops.chamfer_distance(fine, target)
+        dist = alpha * chamfer + (1 - alpha) * SmoothL1Fn.apply(fine, target)
     rate = fbpp.clamp(0.0, max_rate)
     return dist + lam * rate, dist.detach(), rate.detach()
 
@@ -293,7 +299,7 @@ class Adam:
         return acc
 
 
-def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_parallel=False):
+def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_parallel=False, loss_type="chamfer"):
     """One iteration of train_one_epoch (train_pppe_pcd_ae.py:184-226).  ``opt`` covers ae + prob
     parameters as the reference's optimizer does; returns (loss, dist, rate) as python floats.
     data_parallel=True averages the gradients over the ranks of the default process group (bucketed
@@ -302,7 +308,7 @@ def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_paralle
         p.grad = None
     coarse, fine, cond, y_q = forward_train(model, batch_x, starts)
     fbpp = estimate_bits_per_point(model, y_q, cond.detach())
-    loss, dist, rate = rd_loss(fine, batch_x, fbpp, lam)
+    loss, dist, rate = rd_loss(fine, batch_x, fbpp, lam, loss_type)
     loss.backward()
     if data_parallel:
         from . import dist as pdist

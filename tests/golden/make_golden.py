@@ -10,6 +10,9 @@ What is executed from the reference, unmodified, imported from /root/reference:
     byte_array_to_binary_array / farthest_point_sample_batch / index_points /
     normalize / denormalize / pmf_to_cdf / PointNet / MLP / SetAbstraction (pn_kit.py)
   * AE.AE / AE.ConditionalProbabilityModel                           (AE.py)
+  * PPPF_AE.PPPF_AE, pppe_pcd_ae.PointCloudAE forward                 (PPPF_AE.py, pppe_pcd_ae.py)
+  * train_pppe_pcd_ae.set_model_and_loss / train_one_epoch (two iterations on CPU, scaler=None) with
+    pppe_pcd_ae.RateDistortionLoss / estimate_bits_per_point_conditional (train_pppe_pcd_ae.py:171-252)
 
 pn_kit.py and AE.py import pytorch3d, pyntcloud and plyfile at module import; none
 of the three is installed in the image (no network).  Their NAMES are bound here
@@ -35,7 +38,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-from oracle import cport, ref_families, ref_model  # noqa: E402
+from oracle import cport, ref_families, ref_model, ref_train  # noqa: E402
 from tests import synth  # noqa: E402
 
 
@@ -59,7 +62,7 @@ def _bind_absent_third_party():
     ops.knn_gather = knn.knn_gather
     ops.ball_query = lambda p1, p2, K, radius: ref_families.ball_query(p1, p2, K, radius)[1]   # pointnet_sa_module.py:18 uses the result as idx
     ops.sample_farthest_points = ref_families.sample_farthest_points
-    loss.chamfer_distance = absent("pytorch3d.chamfer_distance")
+    loss.chamfer_distance = ref_train.chamfer_distance   # oracle-defined (documented pytorch3d semantics; PARITY UNPINNED)
     p3d.ops, p3d.loss = ops, loss
     pynt = types.ModuleType("pyntcloud")
     pynt.PyntCloud = absent("pyntcloud.PyntCloud")
@@ -208,7 +211,59 @@ def main():
     fam["pppe_cond"], fam["pppe_yq"] = cond.numpy(), y_q[:, :, 0].numpy()
     np.savez_compressed(os.path.join(HERE, "families.npz"), **fam)
 
-    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz"):
+    # ---------------------------------------------------------------- 6. the pppe training step (configs[4])
+    # The reference's own loop body: train_one_epoch is called once per iteration with a one-batch loader, the
+    # criterion it is handed is the reference's get_loss("chamfer") behind a recorder that keeps the exact
+    # scalars, scaler=None (the CPU branch, train_pppe_pcd_ae.py:221-224).  pytorch3d's chamfer_distance and
+    # knn_points are the oracle's definitions (module docstring).
+    import argparse
+    import tempfile
+    import train_pppe_pcd_ae as ref_script
+    tr = {}
+    Nt, Bt, lr = 2048, 2, 1e-3
+    targs = argparse.Namespace(device="cpu", K=64, L=16, N=Nt, max_steps=100, warmup_steps=2, step_window=10 ** 9,
+                               model_save_folder=tempfile.mkdtemp())
+    ae, prob, crit = ref_script.set_model_and_loss(targs)                     # train_pppe_pcd_ae.py:43-49
+    ae.load_state_dict(synth.family_tweak(ref_families.seeded_with_bn(ae, synth.PPPE_SEED), "pppe"))
+    opt = torch.optim.Adam(list(ae.parameters()), lr=lr)                        # :274-276
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100)          # :278
+    xt = torch.from_numpy(synth.train_input(Bt, Nt))
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.log = inner, []
+
+        def forward(self, rec, tgt, fbpp, lam):
+            out = self.inner(rec, tgt, fbpp, lam)
+            self.log.append((float(out[0]), float(out[1]), float(out[2]), float(lam), float(fbpp)))
+            return out
+
+    class Bar:
+        def set_postfix(self, *a, **k): pass
+        def update(self, *a): pass
+
+    rec = Recorder(crit)
+    names = [k for k, _ in ae.named_parameters()]
+    tr["param_names"] = np.array(names)
+    gstep, starts = 0, []
+    for it in range(2):
+        torch.manual_seed(500 + it)                  # the four torch.randint draws of pn_kit.py:321 in this forward
+        starts.append(np.stack([torch.randint(0, n, (Bt,), dtype=torch.long).numpy() for n in (Nt, Nt, 512, 128)]))
+        torch.manual_seed(500 + it)
+        gstep = ref_script.train_one_epoch([(xt, 0)], ae, prob, rec, opt, sched, None, targs, it, gstep, Bar())
+        sd = dict(ae.named_parameters())
+        tr[f"params_{it}"] = np.concatenate([synth.sample64(sd[k].detach().numpy()) for k in names])
+        tr[f"grads_{it}"] = np.concatenate([synth.sample64(sd[k].grad.numpy()) if sd[k].grad is not None
+                                             else np.full(synth.sample64(sd[k].detach().numpy()).shape, np.nan, np.float32) for k in names])
+        tr[f"lr_{it}"] = np.float64(opt.param_groups[0]["lr"])
+    tr["scalars"] = np.array(rec.log, dtype=np.float64)          # per iteration: loss, dist, rate, lambda_eff, fbpp
+    tr["starts"] = np.stack(starts)
+    tr["bn_running_mean_sample"] = np.concatenate([synth.sample64(v.numpy()) for k, v in ae.named_buffers() if k.endswith("running_mean")])
+    tr["bn_running_var_sample"] = np.concatenate([synth.sample64(v.numpy()) for k, v in ae.named_buffers() if k.endswith("running_var")])
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **tr)
+
+    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz", "train_step.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -137,3 +137,14 @@ def pppf_input(B=2):
 
 def pppe_input(B=1):
     return np.stack([cloud_synth.cad_cloud(300 + b, 8192) for b in range(B)]).astype(np.float32)
+
+
+def train_input(B=2, N=2048):
+    """Batch of the training-step fixture (tests/golden/train_step.npz)."""
+    return np.stack([cloud_synth.cad_cloud(700 + b, N) for b in range(B)]).astype(np.float32)
+
+
+def sample64(a):
+    """Up to 64 evenly strided entries of a tensor, flattened (keeps the fixtures small)."""
+    f = np.asarray(a).reshape(-1)
+    return f[:: max(1, f.size // 64)][:64].astype(np.float32)

@@ -155,3 +155,42 @@ def test_range_coder_round_trip_and_size():
     for s in (0, 6):
         sym2 = np.full(p.shape[0], s, dtype=np.int16)
         assert np.array_equal(cport.range_decode(ci, cport.range_encode(ci, sym2)), sym2)
+
+
+def test_training_step_oracle_matches_reference_run():
+    """oracle/ref_train.py + oracle/ref_families.py against two iterations of the reference's own
+    train_one_epoch (tests/golden/train_step.npz: get_loss("chamfer"), lambda warm-up, clip_grad_norm_ 1.0,
+    Adam, cosine LR; FPS start draws replayed from the fixture).  pytorch3d's chamfer_distance / knn_points
+    are the oracle's definitions in both runs (parity unpinned for those two)."""
+    import torch
+    from oracle import ref_families as rf, ref_train
+    g = np.load(os.path.join(G, "train_step.npz"))
+    names = list(g["param_names"])
+    o = rf.PointCloudAE(64, 16, 2048)
+    o.load_state_dict(synth.family_tweak(rf.seeded_with_bn(o, synth.PPPE_SEED), "pppe"))
+    assert [k for k, _ in o.named_parameters()] == names
+    opt = torch.optim.Adam(o.parameters(), lr=1e-3)
+    x = torch.from_numpy(synth.train_input(2, 2048))
+    torch.set_num_threads(8)
+    for it in range(2):
+        st = g["starts"][it]
+        if it == 1:
+            opt.param_groups[0]["lr"] = float(g["lr_0"])                   # scheduler.step() after iteration 0
+        loss, dist, rate = ref_train.train_step(o, opt, x, [[st[0], st[1]], st[2], st[3]], lam=float(g["scalars"][it, 3]),
+                                                loss_type="chamfer")
+        want = g["scalars"][it]
+        tol = 1e-5 if it == 0 else 3e-3          # first-step Adam is g/|g|: entries with |g| near eps move by up to 2*lr either way
+        assert abs(loss - want[0]) <= tol * abs(want[0]), (it, loss, want)
+        assert abs(dist - want[1]) <= tol * abs(want[1]), (it, dist, want)
+        assert abs(rate - want[2]) <= (1e-5 if it == 0 else 1e-2) * abs(want[2]), (it, rate, want)
+        sd = dict(o.named_parameters())
+        got_p = np.concatenate([synth.sample64(sd[k].detach().numpy()) for k in names])
+        got_g = np.concatenate([synth.sample64(sd[k].grad.numpy()) if sd[k].grad is not None
+                                else np.full(synth.sample64(sd[k].detach().numpy()).shape, np.nan, np.float32) for k in names])
+        wp, wg = g[f"params_{it}"], g[f"grads_{it}"]
+        assert np.array_equal(np.isnan(got_g), np.isnan(wg))               # the same parameters receive no gradient
+        m = ~np.isnan(wg)
+        if it == 0:
+            assert np.abs(got_g[m] - wg[m]).max() <= 2e-3 * np.abs(wg[m]).max()   # restated layers sum in another order
+        d = np.abs(got_p - wp)
+        assert d.max() <= 2.2e-3 * (it + 1) and np.median(d) <= 1e-6 * (1 if it == 0 else 100), (it, d.max(), np.median(d))

@@ -95,7 +95,8 @@ def test_backward_primitives_match_autograd():
 
 
 @pytest.mark.gpu
-def test_training_step_matches_autograd_and_adam():
+@pytest.mark.parametrize("loss_type", ["chamfer", "hybrid"])
+def test_training_step_matches_autograd_and_adam(loss_type):
     """End to end, two iterations.  Activations that sit at a ReLU / max-pool decision flip between the two
     implementations (they differ by ~1e-5), so encoder gradients agree to ~0.5 % of each tensor's largest entry,
     decoder gradients to 1e-5; first-step Adam moves every entry by ~lr*sign(g), so a few near-zero gradients may
@@ -116,8 +117,8 @@ def test_training_step_matches_autograd_and_adam():
     torch.set_num_threads(8)
     noise = set()
     for step in range(2):
-        ol = ref_train.train_step(o, oopt, torch.from_numpy(x), starts, lam=0.5)
-        gl = train.train_step(g, gopt, torch.from_numpy(x).cuda(), starts, lam=0.5)
+        ol = ref_train.train_step(o, oopt, torch.from_numpy(x), starts, lam=0.5, loss_type=loss_type)
+        gl = train.train_step(g, gopt, torch.from_numpy(x).cuda(), starts, lam=0.5, loss_type=loss_type)
         tol_loss = 2e-5 if step == 0 else 2e-3          # step 1 starts from parameters that already differ slightly
         assert abs(gl[0] - ol[0]) <= tol_loss * abs(ol[0]) + 1e-7, (step, gl, ol)
         assert abs(gl[2] - ol[2]) <= (1e-4 if step == 0 else 1e-2) * abs(ol[2]) + 1e-6   # a flipped symbol moves the step-1 rate
@@ -146,3 +147,52 @@ def test_training_step_matches_autograd_and_adam():
         ob, gb = dict(o.named_buffers()), dict(g.named_buffers())
         for k, v in ob.items():                         # BatchNorm running statistics
             np.testing.assert_allclose(gb[k].cpu().numpy(), v.numpy(), rtol=5e-2 if step else 1e-4, atol=5e-3 if step else 1e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_training_step_matches_reference_run():
+    """The HIP training step against two iterations of the reference's own train_one_epoch
+    (tests/golden/train_step.npz, generated by tests/golden/make_golden.py section 6): loss / distortion / rate
+    per iteration, clipped gradients after the first, sampled parameters after each Adam step."""
+    import os
+    from pccx import families, train
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_step.npz"))
+    names = list(gold["param_names"])
+    o = _models(2048)
+    g = families.PointCloudAE(64, 16, 2048)
+    g.load_state_dict(o.state_dict())
+    g = g.cuda()
+    assert [k for k, _ in g.named_parameters()] == names
+    opt = train.Adam(g.parameters(), lr=1e-3)
+    x = torch.from_numpy(synth.train_input(2, 2048)).cuda()
+    for it in range(2):
+        st = gold["starts"][it]
+        if it == 1:
+            opt.lr = float(gold["lr_0"])                                   # CosineAnnealingLR.step() after iteration 0
+        loss, dist, rate = train.train_step(g, opt, x, [[st[0], st[1]], st[2], st[3]], lam=float(gold["scalars"][it, 3]),
+                                            loss_type="chamfer")
+        want = gold["scalars"][it]
+        lam = float(want[3])
+        tol = 2e-5 if it == 0 else 3e-3
+        assert abs(dist - want[1]) <= tol * abs(want[1]) + 1e-7, (it, dist, want)
+        # the rate is -log2 pmf of ONE symbol per cloud (channel 0, pppe_pcd_ae.py:906-915): after the first Adam
+        # step a latent within rounding distance of a bin edge may land in the neighbouring bin
+        assert abs(rate - want[2]) <= (1e-4 if it == 0 else 5e-2) * abs(want[2]) + 1e-6, (it, rate, want)
+        assert abs(loss - (dist + lam * rate)) <= 1e-5 * abs(loss), (it, loss, dist, rate)
+        if it == 0:
+            assert abs(loss - want[0]) <= tol * abs(want[0]) + 1e-7, (it, loss, want)
+        sd = dict(g.named_parameters())
+        got_p = np.concatenate([synth.sample64(sd[k].detach().cpu().numpy()) for k in names])
+        wp, wg = gold[f"params_{it}"], gold[f"grads_{it}"]
+        if it == 0:
+            gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values() if p.grad is not None)))
+            coef = min(1.0, 1.0 / (gn + 1e-6))                             # the fixture holds .grad after clip_grad_norm_
+            got_g = np.concatenate([synth.sample64(sd[k].grad.cpu().numpy()) * coef if sd[k].grad is not None
+                                    else np.full(synth.sample64(sd[k].detach().cpu().numpy()).shape, np.nan, np.float32) for k in names])
+            assert np.array_equal(np.isnan(got_g), np.isnan(wg))
+            m = ~np.isnan(wg)
+            assert np.abs(got_g[m] - wg[m]).max() <= 1e-2 * np.abs(wg[m]).max()
+        d = np.abs(got_p - wp)
+        assert d.max() <= 2.2e-3 * (it + 1), (it, d.max())
+        if it == 0:
+            assert np.median(d) <= 0.05 * 1e-3 and (d > 1e-4).mean() < 0.25, (np.median(d), (d > 1e-4).mean())
