@@ -23,6 +23,10 @@ def read_point_cloud(filepath):                                   # pn_kit.py:25
     return plyio.read_point_cloud(filepath)
 
 
+def read_point_clouds(file_path_list):                             # pn_kit.py:33-37 (host I/O, serial here)
+    return np.array([plyio.read_point_cloud(f) for f in file_path_list])
+
+
 def save_point_cloud(pc, filename, path='./viewing/'):            # pn_kit.py:39-42
     plyio.save_point_cloud(pc, os.path.join(path, filename))
 
@@ -84,6 +88,23 @@ def decode_sampled_np(codes, scale, mode=None):                   # pn_kit.py:42
             pts, _ = ops.octree_decode(by, nby, "full", max(int(cnt[0]), 1))
         out.append(pts[0].cpu().numpy())
     return np.stack(out, axis=0)
+
+
+# -- helpers of the training scripts (train.py:164-201), not on the compress/decompress path: tensor plumbing only
+def n_scale_batch(batch_pc, margin=0.01):                         # pn_kit.py:68-87
+    ext = batch_pc.max(dim=1)[0] - batch_pc.min(dim=1)[0]
+    scaling = (1 - margin) / ext.max(dim=1)[0]
+    return batch_pc * scaling.view(-1, 1, 1), scaling
+
+
+def d_n_scale_batch(batch_pc, scaling):                           # pn_kit.py:89-96
+    return batch_pc / scaling.view(-1, 1, 1)
+
+
+def estimate_bits_from_pmf(pmf, sym):                             # pn_kit.py:439-450
+    L = pmf.shape[-1]
+    p = torch.gather(pmf.reshape(-1, L), 1, sym.reshape(-1, 1))
+    return torch.sum(-torch.log2(p.clamp(min=1e-3)))
 
 
 def pmf_to_cdf(pmf):                                              # pn_kit.py:452-461
