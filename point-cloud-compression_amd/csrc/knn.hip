@@ -1,4 +1,5 @@
-// knn.hip -- neighbour search kernels for gfx950: exact K-nearest (radix select in LDS), ball query
+// knn.hip -- neighbour search kernels for gfx950: exact K-nearest (register-resident histogram select; radix
+// select in LDS for large N / K), ball query
 // (ordered wave compaction) and one-directional nearest-neighbour distances (LDS-tiled all-pairs
 // min-reduce, the building block of Chamfer distance and D1-PSNR).
 //
@@ -150,6 +151,182 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// exact kNN, fast path (N <= 8192, K <= 256): one 256-thread workgroup per query, keys in REGISTERS.
+//   1. 32 squared distances per thread (uint keys)
+//   2. a histogram pass over the top 11 key bits (exponent + 3 mantissa bits: 1/8-octave bins) and a scan
+//      find the bin holding the K-th smallest: every key in a lower bin is selected (set A), the keys of
+//      that bin (set B, typically a few dozen) compete for the remaining r = K - |A| places.  Only when B
+//      is larger than KNN_CAPB is the bin refined by the next 11 and then the last 9 key bits.
+//   3. A and B are compacted into LDS; each B key counts the B keys below it (composite (distance,
+//      index) order, so ties resolve to the lower index) and joins A when its rank is < r.  If B is still
+//      too large after all 31 bits, its keys are all EQUAL and the r lowest indices are taken by an
+//      ordered pass (the index order is the register order).
+//   4. the K winners, one per thread, are sorted by a bitonic network in registers: partners inside a
+//      wave by lane exchange, the three cross-wave steps through LDS
+//   5. dists / idx / gathered (optionally centred + scaled) neighbours
+// ------------------------------------------------------------------------------------------
+#define KNN_PPT 32
+#define KNN_BINS 2048
+#define KNN_CAPB 256
+
+__device__ __forceinline__ unsigned long long knn_exchange(unsigned long long v, int stride)
+{
+    const unsigned lo = __shfl_xor((unsigned)v, stride), hi = __shfl_xor((unsigned)(v >> 32), stride);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// One level of the MSB-first search: histogram of bits [PSH-1 : SH] over the keys whose higher bits equal P,
+// scan for the bin where the running count reaches r.  On return P includes the bin, r is the rank wanted inside
+// it (1 <= r <= cnt) and cnt its population.
+template <int PSH, int SH, int WIDTH>
+__device__ __forceinline__ void knn_level(const unsigned (&key)[KNN_PPT], int *hist, int *s_wsum, int *s_found, int tid,
+                                          unsigned &P, int &r, int &cnt)
+{
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 256; ++t) hist[t * 256 + tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KNN_PPT; ++t)
+        if ((key[t] >> PSH) == P) atomicAdd(&hist[(key[t] >> SH) & ((1u << WIDTH) - 1u)], 1);
+    __syncthreads();
+    int own[KNN_BINS / 256], s = 0;                                       // thread t owns bins 8t .. 8t+7
+#pragma unroll
+    for (int t = 0; t < KNN_BINS / 256; ++t) { own[t] = hist[tid * (KNN_BINS / 256) + t]; s += own[t]; }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    for (int k = 0; k < w; ++k) incl += s_wsum[k];
+    int excl = incl - s;
+    if (excl < r && r <= incl) {
+#pragma unroll
+        for (int t = 0; t < KNN_BINS / 256; ++t) {
+            if (excl < r && r <= excl + own[t]) { s_found[0] = tid * (KNN_BINS / 256) + t; s_found[1] = excl; s_found[2] = own[t]; }
+            excl += own[t];
+        }
+    }
+    __syncthreads();
+    P = (P << WIDTH) | (unsigned)s_found[0];
+    r -= s_found[1];
+    cnt = s_found[2];
+}
+
+__global__ __launch_bounds__(256, 4) void knn_fast_kernel(const float *__restrict__ q, int M, const float *__restrict__ ref,
+                                                       int N, int K, float *__restrict__ dists, int64_t *__restrict__ idx,
+                                                       float *__restrict__ nn, float patch_scale)
+{
+    __shared__ int hist[KNN_BINS];
+    __shared__ unsigned long long selA[256], selB[KNN_CAPB];
+    __shared__ int s_wsum[4], s_found[3], s_cnt[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = blockIdx.x, b = blockIdx.y;
+    const float *rp = ref + (size_t)b * N * 3;
+    const size_t qo = ((size_t)b * M + m) * 3;
+    const float qx = q[qo], qy = q[qo + 1], qz = q[qo + 2];
+    const size_t ob = ((size_t)b * M + m) * K;
+
+    unsigned key[KNN_PPT];
+#pragma unroll
+    for (int t = 0; t < KNN_PPT; ++t) {
+        const int i = t * 256 + tid;
+        key[t] = i < N ? __float_as_uint(pccx_sqdist(qx, qy, qz, rp[3 * i], rp[3 * i + 1], rp[3 * i + 2])) : 0x7FFFFFFFu;
+    }
+    if (tid < 2) s_cnt[tid] = 0;
+
+    // ---- the K-th smallest key, MSB first: keys with (key >> sh) < P are in, those with (key >> sh) == P compete
+    unsigned P = 0;
+    int sh = 20, r = K, cnt_b = 0;
+    knn_level<31, 20, 11>(key, hist, s_wsum, s_found, tid, P, r, cnt_b);
+    if (cnt_b > KNN_CAPB) {                                               // uniform, rare: refine the bin
+        sh = 9;
+        knn_level<20, 9, 11>(key, hist, s_wsum, s_found, tid, P, r, cnt_b);
+        if (cnt_b > KNN_CAPB) {
+            sh = 0;
+            knn_level<9, 0, 9>(key, hist, s_wsum, s_found, tid, P, r, cnt_b);
+        }
+    }
+    const int nA = K - r;
+
+    // ---- compaction (order irrelevant) and the r winners of B
+#pragma unroll
+    for (int t = 0; t < KNN_PPT; ++t) {
+        const unsigned pre = key[t] >> sh;
+        const unsigned long long e = ((unsigned long long)key[t] << 32) | (unsigned)(t * 256 + tid);
+        if (pre < P) selA[atomicAdd(&s_cnt[0], 1)] = e;
+        else if (pre == P && cnt_b <= KNN_CAPB) selB[atomicAdd(&s_cnt[1], 1)] = e;
+    }
+    __syncthreads();
+    if (cnt_b <= KNN_CAPB) {
+        if (tid < cnt_b) {
+            const unsigned long long e = selB[tid];
+            int rank = 0;
+            for (int j = 0; j < cnt_b; ++j) rank += selB[j] < e ? 1 : 0;
+            if (rank < r) selA[nA + rank] = e;
+        }
+    } else {
+        // all 31 bits resolved (sh == 0): the B keys equal P.  Index order = (t, tid) order.
+        int base = 0;
+#pragma unroll 1
+        for (int t = 0; t < KNN_PPT && base < r; ++t) {
+            const bool tie = key[t] == P;
+            const unsigned long long bal = __ballot(tie);
+            if (lane == 0) s_wsum[w] = __popcll(bal);
+            __syncthreads();
+            int off = base, row = 0;
+            for (int k = 0; k < 4; ++k) { off += k < w ? s_wsum[k] : 0; row += s_wsum[k]; }
+            const int rank = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (tie && rank < r) selA[nA + rank] = ((unsigned long long)key[t] << 32) | (unsigned)(t * 256 + tid);
+            base += row;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---- bitonic sort of the K winners, one per thread (padding sorts last)
+    unsigned long long v = tid < K ? selA[tid] : ~0ull;
+    __syncthreads();                                                      // selA is reused as the exchange buffer
+#pragma unroll
+    for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            unsigned long long o;
+            if (stride >= 64) {
+                selA[tid] = v;
+                __syncthreads();
+                o = selA[tid ^ stride];
+                __syncthreads();
+            } else
+                o = knn_exchange(v, stride);
+            const bool keep_min = ((tid & stride) == 0) == ((tid & size) == 0);
+            const bool o_less = o < v;
+            v = (o_less == keep_min) ? o : v;
+        }
+    }
+
+    // ---- outputs
+    if (tid < K) {
+        const int i = (int)(v & 0xffffffffu);
+        dists[ob + tid] = __uint_as_float((unsigned)(v >> 32));
+        idx[ob + tid] = i;
+        if (nn) {
+            float x = rp[3 * i], y = rp[3 * i + 1], z = rp[3 * i + 2];
+            if (patch_scale != 0.f) {
+                // grouped_xyz -= centre (compress.py:72); x_patches * (N/N0)^(1/3) (compress.py:108)
+                x = __fmul_rn(__fsub_rn(x, qx), patch_scale);
+                y = __fmul_rn(__fsub_rn(y, qy), patch_scale);
+                z = __fmul_rn(__fsub_rn(z, qz), patch_scale);
+            }
+            nn[(ob + tid) * 3] = x; nn[(ob + tid) * 3 + 1] = y; nn[(ob + tid) * 3 + 2] = z;
+        }
+    }
+}
+
 extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, int K, float *dists, int64_t *idx,
                         float *nn, float patch_scale, void *stream)
 {
@@ -164,8 +341,12 @@ extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, i
     size_t shmem = (size_t)Kp * 8 + (size_t)N * 4 + (256 + 4 + 3 + 1) * 4;
     PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(knn_kernel, dim3(M, B), dim3(256), shmem, (hipStream_t)stream, q, M, ref, N, K, Kp, dists, idx, nn,
-                       patch_scale);
+    if (N <= 256 * KNN_PPT && K <= 256)
+        hipLaunchKernelGGL(knn_fast_kernel, dim3(M, B), dim3(256), 0, (hipStream_t)stream, q, M, ref, N, K, dists, idx, nn,
+                           patch_scale);
+    else
+        hipLaunchKernelGGL(knn_kernel, dim3(M, B), dim3(256), shmem, (hipStream_t)stream, q, M, ref, N, K, Kp, dists, idx, nn,
+                           patch_scale);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

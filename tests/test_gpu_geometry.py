@@ -83,6 +83,30 @@ def test_knn_vs_oracle(N, M, K):
         assert np.array_equal(r.knn[b].cpu().numpy(), ref[b][i])
 
 
+def test_knn_near_equidistant_and_massively_tied_clouds():
+    """The fast kNN kernel narrows the K-th distance by histogram levels (11 + 11 + 9 key bits) only as far as
+    needed.  A jittered shell around the query puts every distance into one 1/8-octave bin and forces the deeper
+    levels; a cloud with 1500 copies of one point leaves more exact ties at the K-th distance than the tie buffer
+    holds and forces the ordered lowest-index pass.  A far-away query stays on the one-level path.  All must equal
+    the oracle's (distance, index) order."""
+    rng = np.random.default_rng(8)
+    N, K = 4096, 200
+    dirs = rng.normal(size=(N, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    shell = (0.5 + 0.3 * dirs * (1.0 + rng.integers(-30, 31, size=(N, 1)) * 2.0 ** -23)).astype(np.float32)
+    tied = rng.random((N, 3)).astype(np.float32)
+    tied[rng.choice(N, size=1500, replace=False)] = np.float32([0.25, 0.5, 0.75])
+    tied[rng.choice(N, size=50, replace=False)] = np.float32([0.26, 0.5, 0.75])       # 50 nearer ones: r < ties
+    ref = np.stack([shell, tied])
+    q = np.stack([np.array([[0.5, 0.5, 0.5], [2.0, -1.0, 0.25], [0.5, 0.5, 0.8]], dtype=np.float32),
+                  np.array([[0.26, 0.5, 0.75], [0.25, 0.5, 0.75], [0.9, 0.1, 0.2]], dtype=np.float32)])
+    r = ops.knn_points(dev(q), dev(ref), K)
+    for b in range(2):
+        d, i = cport.knn(q[b], ref[b], K)
+        assert np.array_equal(r.idx[b].cpu().numpy(), i)
+        assert np.array_equal(r.dists[b].cpu().numpy(), d)
+        assert np.array_equal(r.knn[b].cpu().numpy(), ref[b][i])
+
+
 def test_knn_patches_fused_centre_and_scale():
     pc = cloud_synth.cad_cloud(3, 8192)
     c = pc[:64] + np.float32(0.001)
