@@ -170,9 +170,33 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
 #define KNN_BINS 2048
 #define KNN_CAPB 256
 
-__device__ __forceinline__ unsigned long long knn_exchange(unsigned long long v, int stride)
+template <int X>
+__device__ __forceinline__ unsigned knn_xor_lane(unsigned v)             // value of lane (lane ^ X), X < 64
 {
-    const unsigned lo = __shfl_xor((unsigned)v, stride), hi = __shfl_xor((unsigned)(v >> 32), stride);
+    if (X == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    if (X == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    if (X == 3) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);       // quad_perm [3,2,1,0]
+    if (X == 7) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);      // row_half_mirror
+    if (X == 15) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);     // row_mirror
+    if (X < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (X << 10) | 0x1F);        // bitmask mode: lane ^ X within 32
+    return (unsigned)__shfl_xor((int)v, X);
+}
+
+__device__ __forceinline__ unsigned long long knn_exchange(unsigned long long v, int x)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    switch (x) {                                                          // x is a compile-time constant after unrolling
+    case 1: lo = knn_xor_lane<1>(lo); hi = knn_xor_lane<1>(hi); break;
+    case 2: lo = knn_xor_lane<2>(lo); hi = knn_xor_lane<2>(hi); break;
+    case 3: lo = knn_xor_lane<3>(lo); hi = knn_xor_lane<3>(hi); break;
+    case 4: lo = knn_xor_lane<4>(lo); hi = knn_xor_lane<4>(hi); break;
+    case 7: lo = knn_xor_lane<7>(lo); hi = knn_xor_lane<7>(hi); break;
+    case 8: lo = knn_xor_lane<8>(lo); hi = knn_xor_lane<8>(hi); break;
+    case 15: lo = knn_xor_lane<15>(lo); hi = knn_xor_lane<15>(hi); break;
+    case 16: lo = knn_xor_lane<16>(lo); hi = knn_xor_lane<16>(hi); break;
+    case 31: lo = knn_xor_lane<31>(lo); hi = knn_xor_lane<31>(hi); break;
+    default: lo = __shfl_xor(lo, x); hi = __shfl_xor(hi, x); break;
+    }
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -253,13 +277,31 @@ __global__ __launch_bounds__(256, 4) void knn_fast_kernel(const float *__restric
     }
     const int nA = K - r;
 
-    // ---- compaction (order irrelevant) and the r winners of B
+    // ---- compaction (order irrelevant) without per-element atomics: count, one packed wave scan and one atomic per
+    // wave for the bases, then plain stores.  (A in the low half of the packed counters, B in the high half.)
+    const bool use_b = cnt_b <= KNN_CAPB;
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < KNN_PPT; ++t) {
+        const unsigned pre = key[t] >> sh;
+        cnt += (pre < P ? 1 : 0) + (pre == P ? 0x10000 : 0);
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    int base = 0;
+    if (lane == 63) base = atomicAdd(&s_cnt[0], incl);
+    base = __shfl(base, 63) + incl - cnt;
+    int posA = base & 0xFFFF, posB = base >> 16;
 #pragma unroll
     for (int t = 0; t < KNN_PPT; ++t) {
         const unsigned pre = key[t] >> sh;
         const unsigned long long e = ((unsigned long long)key[t] << 32) | (unsigned)(t * 256 + tid);
-        if (pre < P) selA[atomicAdd(&s_cnt[0], 1)] = e;
-        else if (pre == P && cnt_b <= KNN_CAPB) selB[atomicAdd(&s_cnt[1], 1)] = e;
+        if (pre < P) selA[posA++] = e;
+        else if (pre == P && use_b) selB[posB++] = e;
     }
     __syncthreads();
     if (cnt_b <= KNN_CAPB) {
@@ -288,24 +330,28 @@ __global__ __launch_bounds__(256, 4) void knn_fast_kernel(const float *__restric
     }
     __syncthreads();
 
-    // ---- bitonic sort of the K winners, one per thread (padding sorts last)
+    // ---- bitonic sort of the K winners, one per thread (padding sorts last).  Merge of two sorted runs of
+    // size/2: first compare i with its mirror i ^ (size-1), then with i ^ stride for stride = size/4 .. 1; the lower
+    // lane keeps the smaller key.  Partners inside a wave come by DPP (xor 1, 2, 3, 7, 15), ds_swizzle (xor 4, 8,
+    // 16, 31) or ds_bpermute (xor 32, 63); the three cross-wave steps go through LDS.
     unsigned long long v = tid < K ? selA[tid] : ~0ull;
     __syncthreads();                                                      // selA is reused as the exchange buffer
 #pragma unroll
     for (int size = 2; size <= 256; size <<= 1) {
 #pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int step = 0, stride = size >> 1; stride > 0; ++step, stride >>= 1) {
+            const int x = step == 0 ? size - 1 : stride;                  // partner = tid ^ x
             unsigned long long o;
-            if (stride >= 64) {
+            if (x >= 64) {
                 selA[tid] = v;
                 __syncthreads();
-                o = selA[tid ^ stride];
+                o = selA[tid ^ x];
                 __syncthreads();
             } else
-                o = knn_exchange(v, stride);
-            const bool keep_min = ((tid & stride) == 0) == ((tid & size) == 0);
+                o = knn_exchange(v, x);
+            const bool lower = (tid & (step == 0 ? size >> 1 : stride)) == 0;
             const bool o_less = o < v;
-            v = (o_less == keep_min) ? o : v;
+            v = (o_less == lower) ? o : v;
         }
     }
 
