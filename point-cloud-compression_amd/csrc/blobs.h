@@ -24,12 +24,15 @@
 #define ENC_PN_W2 (ENC_PN_W1 + 8 * 16 * 256)   // KT=16, MT=32
 #define ENC_PN_W3 (ENC_PN_W2 + 16 * 32 * 256)  // KT=32, MT=1
 // PointNet fragments again, in the order pn_forward_kernel consumes them (one pass = 744 fragments,
-// padded to ENC_PN_STREAM_CHUNKS chunks of 16): L0 [kt][mt], L1 [kt][mt], then for each pair of
+// padded to ENC_PN_STREAM_CHUNKS chunks of WS_CHUNK): L0 [kt][mt], L1 [kt][mt], then for each pair of
 // layer-2 output tiles mp: L2 [kt][2mp..2mp+1] followed by L3 k-tiles 2mp, 2mp+1.
+#ifndef WS_CHUNK
+#define WS_CHUNK 8                        // fragments (KiB) per LDS-ring chunk of the PointNet stream (mfma_chain.h: WStreamT)
+#endif
 #define ENC_PN_STREAM (ENC_PN_W3 + 32 * 1 * 256)
 #define ENC_PN_STREAM_FRAGS 744
-#define ENC_PN_STREAM_CHUNKS 48
-#define ENC_BLOB_FLOATS (ENC_PN_STREAM + ENC_PN_STREAM_CHUNKS * 16 * 256)
+#define ENC_PN_STREAM_CHUNKS (2 * ((ENC_PN_STREAM_FRAGS + 2 * WS_CHUNK - 1) / (2 * WS_CHUNK)))      // even
+#define ENC_BLOB_FLOATS (ENC_PN_STREAM + ENC_PN_STREAM_CHUNKS * WS_CHUNK * 256)
 
 // ---- AE decoder: inv_pool 16->256->1024->k*128 (AE.py:19-26) + inv_mlp 144->128->64->32->3 (AE.py:27)
 #define DEC_H_B1 0                             // [256]
@@ -47,12 +50,15 @@
 #define DEC_G_B (DEC_M_W3 + 2 * 1 * 256)       // [k*128] bias of inv_pool.4, rows permuted to p*128+c
 // followed by one weight stream per point p (what the workgroup of point p consumes, in order):
 // 512 inv_pool.4 fragments (rows permuted to o' = p*128 + c, [kt=64][8 m-tiles]), then the 114 inv_mlp
-// fragments (L0 [9][8], L1 [8][4], L2 [4][2], L3 [2][1]; the same for every p), padded to 40 chunks.
+// fragments (L0 [9][8], L1 [8][4], L2 [4][2], L3 [2][1]; the same for every p), padded to DEC_STREAM_CHUNKS chunks of DEC_WS_CHUNK.
 #define DEC_STREAM_GEMM_FRAGS 512
 #define DEC_STREAM_FRAGS 626
-#define DEC_STREAM_CHUNKS 40
+#ifndef DEC_WS_CHUNK
+#define DEC_WS_CHUNK 8                    // the decoder's ring: one k-tile (8 m-tiles) per chunk
+#endif
+#define DEC_STREAM_CHUNKS (2 * ((DEC_STREAM_FRAGS + 2 * DEC_WS_CHUNK - 1) / (2 * DEC_WS_CHUNK)))
 #define DEC_G_W(k) (DEC_G_B + (k) * 128)
-#define DEC_BLOB_FLOATS(k) (DEC_G_W(k) + (size_t)(k) * DEC_STREAM_CHUNKS * 16 * 256)
+#define DEC_BLOB_FLOATS(k) (DEC_G_W(k) + (size_t)(k) * DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 256)
 
 // ---- ConditionalProbabilityModel (AE.py:87-123): PointNet 3->64->128->256, MLP 259->512->512->d*L
 #define PRB_P_B0 0                             // [64]

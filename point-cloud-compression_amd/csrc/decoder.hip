@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     const int g = lane >> 4, n = lane & 15;
     const int p = blockIdx.y;
     const int tile0 = blockIdx.x * 8 + 2 * w;
-    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * WS_CHUNK * 64];      // 32 KiB ring: 2 k-tiles x 8 m-tiles per chunk
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * DEC_WS_CHUNK * 64];      // ring: one k-tile (8 m-tiles) per chunk
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const WStream ws{blob + DEC_G_W(k) + (size_t)p * DEC_STREAM_CHUNKS * 16 * 256, swt, DEC_STREAM_CHUNKS, lane, wu, false};
+    const WStreamT<DEC_WS_CHUNK> ws{blob + DEC_G_W(k) + (size_t)p * DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 256, swt, DEC_STREAM_CHUNKS, lane, wu, false};
     ws.prologue();
 
     f32x4 acc[2][8];
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     b_cur[0] = h2p[((size_t)0 * ntiles + t0) * 64 + lane];
     b_cur[1] = h2p[((size_t)0 * ntiles + t1) * 64 + lane];
 #pragma unroll 1
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < 64 / (DEC_WS_CHUNK / 8); ++c) {
         ws.boundary(c);
-        const f32x4 *buf = swt + (c & 1) * WS_CHUNK * 64 + lane;
+        const f32x4 *buf = swt + (c & 1) * DEC_WS_CHUNK * 64 + lane;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kt = 2 * c + h;
+        for (int h = 0; h < DEC_WS_CHUNK / 8; ++h) {
+            const int kt = (DEC_WS_CHUNK / 8) * c + h;
             const int kn = kt + 1 < 64 ? kt + 1 : 63;
             b_nxt[0] = h2p[((size_t)kn * ntiles + t0) * 64 + lane];
             b_nxt[1] = h2p[((size_t)kn * ntiles + t1) * 64 + lane];

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
                                                             float half_spread, float *__restrict__ latent_raw,
                                                             float *__restrict__ latent, float *__restrict__ latent_q)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * WS_CHUNK * 64];      // 32 KiB weight ring
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * WS_CHUNK * 64];      // weight ring: 2 chunks of WS_CHUNK KiB
     __shared__ float smax[4][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
     const float *xp = x + P * (size_t)K * 3;
     const int ntiles = K >> 4;
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    WStream ws{blob + ENC_PN_STREAM, swt, ENC_PN_STREAM_CHUNKS, lane, wu, true};
+    WStreamT<WS_CHUNK> ws{blob + ENC_PN_STREAM, swt, ENC_PN_STREAM_CHUNKS, lane, wu, true};
     ws.prologue();
 
     f32x4 run;                                            // running max, channel 4g+r
@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
                 for (int m = 0; m < 2; ++m) a2[nt][m] = relu4(a2[nt][m]);
             dense_acc_stream<2, 1, NT>(ws, f, a2, a3);     // last layer has no ReLU (AE.py:17 relu=[T,T,T,F])
         }
-        ws.boundary(ENC_PN_STREAM_CHUNKS - 1);             // padding chunk: keeps the ring parity; prefetches chunk 0
+        if ((ENC_PN_STREAM_FRAGS + WS_CHUNK - 1) / WS_CHUNK < ENC_PN_STREAM_CHUNKS)
+            ws.boundary(ENC_PN_STREAM_CHUNKS - 1);         // padding chunk: keeps the ring parity; prefetches chunk 0
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             if (valid[nt])

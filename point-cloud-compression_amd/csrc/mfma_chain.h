@@ -109,22 +109,23 @@ __device__ __forceinline__ void max16_of_8_transposed_tiles(const f32x4 (&t)[8],
 // Weight stream through LDS.  When every wave of a workgroup consumes the SAME fragment sequence
 // (PointNet: each wave runs the whole layer stack on its own 16 points), the sequence is packed on
 // the host in consumption order and streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4, one
-// 1 KiB fragment per wave-instruction, no VGPRs), one 16-fragment chunk ahead of the MFMAs:
+// 1 KiB fragment per wave-instruction, no VGPRs), one CH-fragment chunk ahead of the MFMAs (CH = 8 measured
+// best on MI355X: 16 costs 1 %, 32 costs 3 %, 4 equals 8):
 //   * L2 -> CU traffic drops by the number of waves sharing the stream,
 //   * MFMAs read fragments with short, uniform LDS latency instead of exposed L2 latency.
 // Protocol per chunk c (all waves in lock step, ONE barrier per chunk):
 //   s_waitcnt vmcnt(0)   own DMA of chunk c has landed
 //   __syncthreads()      everyone's has, and everyone finished reading chunk c-1's buffer
-//   issue DMA of chunk c+1 into that buffer; run the 64 MFMAs of chunk c.
+//   issue DMA of chunk c+1 into that buffer; run the MFMAs of chunk c.
 // The fragment counter is a plain int that constant-folds after full unrolling, so the chunk hook
 // costs nothing between boundaries.
 // ------------------------------------------------------------------------------------------
-#define WS_CHUNK 16                       // fragments (KiB) per chunk
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
-struct WStream {
-    const float *g;                       // global stream, NCH * WS_CHUNK fragments, wave-uniform
-    f32x4 *lds;                           // [2][WS_CHUNK][64]
+template <int CH>
+struct WStreamT {
+    const float *g;                       // global stream, NCH * CH fragments, wave-uniform
+    f32x4 *lds;                           // [2][CH][64]
     int nch;                              // chunks per pass (even)
     int lane, wave;
     bool wrap;                            // several passes over the same stream
@@ -135,10 +136,10 @@ struct WStream {
         // wave-uniform fragment base (scalar registers) + lane*16 (one VGPR shared by every DMA).
         const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
-        for (int q = 0; q < WS_CHUNK / 4; ++q) {
-            const int fr = wave * (WS_CHUNK / 4) + q;                // wave is scalar (readfirstlane)
-            const char *src = (const char *)g + ((size_t)c * WS_CHUNK + fr) * 1024;
-            f32x4 *dst = lds + (buf * WS_CHUNK + fr) * 64;          // wave-uniform; hardware adds lane*16
+        for (int q = 0; q < CH / 4; ++q) {
+            const int fr = wave * (CH / 4) + q;                // wave is scalar (readfirstlane)
+            const char *src = (const char *)g + ((size_t)c * CH + fr) * 1024;
+            f32x4 *dst = lds + (buf * CH + fr) * 64;          // wave-uniform; hardware adds lane*16
             __builtin_amdgcn_global_load_lds((const void *)(src + voff), (lds_u32 *)(uintptr_t)dst, 16, 0, 0);
         }
     }
@@ -152,16 +153,16 @@ struct WStream {
     }
     __device__ __forceinline__ f32x4 get(int f) const         // fragment f of the current pass
     {
-        if ((f % WS_CHUNK) == 0) boundary(f / WS_CHUNK);
-        return lds[(((f / WS_CHUNK) & 1) * WS_CHUNK + (f % WS_CHUNK)) * 64 + lane];
+        if ((f % CH) == 0) boundary(f / CH);
+        return lds[(((f / CH) & 1) * CH + (f % CH)) * 64 + lane];
     }
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 // dense_acc fed from a WStream: fragments are taken in stream order (kt-major, m inner), `f` is the
 // running fragment index of the pass.
-template <int KT, int MT, int NT, bool SWAP = false>
-__device__ __forceinline__ void dense_acc_stream(const WStream &ws, int &f, const f32x4 (&in)[NT][KT], f32x4 (&acc)[NT][MT])
+template <int KT, int MT, int NT, bool SWAP = false, class WS>
+__device__ __forceinline__ void dense_acc_stream(const WS &ws, int &f, const f32x4 (&in)[NT][KT], f32x4 (&acc)[NT][MT])
 {
     constexpr int MG = MT >= 4 ? 4 : MT;
     static_assert(MT % MG == 0, "MT must be a multiple of the m-group");

@@ -128,7 +128,7 @@ extern "C" int pccx_pack_ae_decoder(const float *ip_w0, const float *ip_b0, cons
     for (int p = 0; p < k; ++p)
         for (int c = 0; c < 128; ++c) blob[DEC_G_B + p * 128 + c] = ip_b2[(size_t)c * k + p];
     // Per-point weight stream (blobs.h): [p][ 64 kt x 8 m-tiles | inv_mlp fragments | pad ].
-    const size_t stride = (size_t)DEC_STREAM_CHUNKS * 16;          // fragments per point
+    const size_t stride = (size_t)DEC_STREAM_CHUNKS * DEC_WS_CHUNK; // fragments per point
     pack_dense(ip_w2, 1024, 64, k * 8, blob + DEC_G_W(k),
                [k](int row) -> long { return (long)(row & 127) * k + (row >> 7); }, Ident{1024},
                [=](int kt, int mt) -> size_t { return (size_t)(mt >> 3) * stride + (size_t)kt * 8 + (mt & 7); });
