@@ -189,6 +189,20 @@ PCCX_API int pccx_ae_decode(const float *latent_q, int P, int d, int k, const fl
                             const float *nrm_center, const float *nrm_longest, int S, double margin,
                             float *pc_out, void *stream);
 
+/* EXPERIMENTAL, opt-in: the same synthesis transform with the K = 1024 Linear evaluated as
+ * fp32 products of three bf16 pieces per operand on the bf16 matrix cores (six v_mfma_f32_16x16x32_bf16 passes,
+ * fp32 accumulate; error at the level of an fp32 summation reorder, not bit-identical to pccx_ae_decode).
+ * b3_blob: pccx_dec_b3_blob_floats(k) floats on the device, filled once from the packed decoder blob (already on
+ * the device) by pccx_pack_ae_decoder_b3.  workspace: pccx_ae_decode_b3_workspace_floats(P).  Replaces the same
+ * reference lines as pccx_ae_decode (AE.py:48-53, decompress.py:97-116). */
+PCCX_API size_t pccx_dec_b3_blob_floats(int k);
+PCCX_API int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream);
+PCCX_API size_t pccx_ae_decode_b3_workspace_floats(int P);
+PCCX_API int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, const float *dec_blob,
+                               const float *b3_blob, float *workspace, float *patches_out, float scale,
+                               const float *centres, const float *nrm_center, const float *nrm_longest,
+                               int S, double margin, float *pc_out, void *stream);
+
 /* AE.ConditionalProbabilityModel.forward (AE.py:107-123) + pn_kit.pmf_to_cdf (pn_kit.py:452-461)
  * + torchac's float-CDF -> 16-bit conversion.  centres: (B,S,3), S % 16 == 0.  Any of the outputs
  * may be NULL: pmf (B,S,d,L) f32; cdf (B,S,d,L+1) f32; cdf_int (B,S,d,L+1) int32 holding uint16. */

@@ -46,9 +46,69 @@ __global__ __launch_bounds__(256, 2) void dec_head_kernel(const float *__restric
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- experimental bf16x3 operands: x = hi + mid + lo exactly, each a bf16 (round to nearest even)
+__device__ __forceinline__ unsigned b3_rne(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void b3_split(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = b3_rne(x);
+    const float r1 = __fsub_rn(x, __uint_as_float(h << 16));
+    m = b3_rne(r1);
+    l = b3_rne(__fsub_rn(r1, __uint_as_float(m << 16)));
+}
+
+// Pairs of fp32 fragments (k-tiles 2t and 2t+1 of the 16x16x4 chain layout) -> the three bf16 planes of one K=32 operand
+// fragment of v_mfma_f32_16x16x32_bf16.  Lane-local: lane (x, kg) holds channels 16*kt + 4*kg + r of both k-tiles, which
+// are k-slots 8*kg + j of the bf16 operand.  src index = outer*src_outer + ((2t + h)*W + j)*64 + lane,
+// dst index = outer*dst_outer + ((t*W + j)*3 + plane)*64 + lane (units: 16-byte vectors).
+__global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__ src, uint4 *__restrict__ dst, int n_outer, int T, int W,
+                                                       size_t src_outer, size_t dst_outer)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (size_t)n_outer * T * W) return;
+    const int j = (int)(item % W), t = (int)((item / W) % T);
+    const size_t o = item / ((size_t)W * T);
+    const f32x4 v0 = src[o * src_outer + ((size_t)(2 * t) * W + j) * 64 + lane];
+    const f32x4 v1 = src[o * src_outer + ((size_t)(2 * t + 1) * W + j) * 64 + lane];
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b3_split(v0[r], h[r], m[r], l[r]); b3_split(v1[r], h[4 + r], m[4 + r], l[4 + r]); }
+    uint4 *d = dst + o * dst_outer + ((size_t)t * W + j) * 3 * 64 + lane;
+    d[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    d[64] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+    d[128] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// copies the 114 fp32 inv_mlp fragments of every point's fp32 stream behind the bf16 GEMM planes of its b3 stream
+__global__ void b3_copy_tail_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int k, size_t src_outer, size_t dst_outer)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)k * 114 * 64) return;
+    const size_t p = i / (114 * 64), e = i % (114 * 64);
+    dst[p * dst_outer + (size_t)DEC_B3_GEMM_FRAGS * 64 + e] = src[p * src_outer + (size_t)DEC_STREAM_GEMM_FRAGS * 64 + e];
+}
+
+__device__ __forceinline__ uint4 b3_load_async(const uint4 *p)    // placed exactly here; completion is covered by the ring's s_waitcnt
+{
+    uint4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // grid: x = patch block (8 n-tiles = 128 patches), y = point p.  4 waves, wave w owns n-tiles 2w, 2w+1.
+// B3 = false: exact fp32 MFMA GEMM (the product path).  B3 = true (experimental, opt-in): the K = 1024 GEMM runs as six
+// v_mfma_f32_16x16x32_bf16 passes over pre-split operands (blob3 / h2p hold bf16 planes); the inv_mlp tail is unchanged.
+template <bool B3>
 __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restrict__ h2p, const float *__restrict__ latent_q,
                                                           int P, int d, int k, int ntiles, const float *__restrict__ blob,
+                                                          const float *__restrict__ blob3,
                                                           float *__restrict__ patches_out, float inv_scale_div,
                                                           const float *__restrict__ centres, const float *__restrict__ nrm_center,
                                                           const float *__restrict__ nrm_longest, int S, float one_minus_margin,
@@ -58,9 +118,13 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     const int g = lane >> 4, n = lane & 15;
     const int p = blockIdx.y;
     const int tile0 = blockIdx.x * 8 + 2 * w;
-    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * DEC_WS_CHUNK * 64];      // ring: one k-tile (8 m-tiles) per chunk
+    constexpr int CH = B3 ? DEC_B3_CHUNK : DEC_WS_CHUNK;
+    constexpr int NB = B3 ? 4 : 2;                                        // ring depth: B3 chunks are short, their DMA needs 3 chunks of lead
+    __shared__ __attribute__((aligned(16))) f32x4 swt[NB * CH * 64];     // ring: one k-tile (8 m-tiles) per chunk; B3: 4 m-tiles x 3 planes
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const WStreamT<DEC_WS_CHUNK> ws{blob + DEC_G_W(k) + (size_t)p * DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 256, swt, DEC_STREAM_CHUNKS, lane, wu, false};
+    const WStreamT<CH, NB> ws{B3 ? blob3 + (size_t)p * DEC_B3_STREAM_CHUNKS * DEC_B3_CHUNK * 256
+                             : blob + DEC_G_W(k) + (size_t)p * DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 256,
+                          swt, B3 ? DEC_B3_STREAM_CHUNKS : DEC_STREAM_CHUNKS, lane, wu, false};
     ws.prologue();
 
     f32x4 acc[2][8];
@@ -70,36 +134,94 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
         acc[0][mt] = b; acc[1][mt] = b;
     }
     const int t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
-    // ---- GEMM over K = 1024 (64 k-tiles).  A (weights of point p, shared by the 4 waves) comes through
-    // the LDS ring one chunk (2 k-tiles) ahead; B (this wave's 2 patch tiles) is prefetched one k-tile
-    // ahead from global.
-    f32x4 b_cur[2], b_nxt[2];
-    b_cur[0] = h2p[((size_t)0 * ntiles + t0) * 64 + lane];
-    b_cur[1] = h2p[((size_t)0 * ntiles + t1) * 64 + lane];
+    if constexpr (!B3) {
+        // ---- GEMM over K = 1024 (64 k-tiles).  A (weights of point p, shared by the 4 waves) comes through
+        // the LDS ring one chunk (2 k-tiles) ahead; B (this wave's 2 patch tiles) is prefetched one k-tile
+        // ahead from global.
+        f32x4 b_cur[2], b_nxt[2];
+        b_cur[0] = h2p[((size_t)0 * ntiles + t0) * 64 + lane];
+        b_cur[1] = h2p[((size_t)0 * ntiles + t1) * 64 + lane];
 #pragma unroll 1
-    for (int c = 0; c < 64 / (DEC_WS_CHUNK / 8); ++c) {
-        ws.boundary(c);
-        const f32x4 *buf = swt + (c & 1) * DEC_WS_CHUNK * 64 + lane;
+        for (int c = 0; c < 64 / (DEC_WS_CHUNK / 8); ++c) {
+            ws.boundary(c);
+            const f32x4 *buf = swt + (c & 1) * DEC_WS_CHUNK * 64 + lane;
 #pragma unroll
-        for (int h = 0; h < DEC_WS_CHUNK / 8; ++h) {
-            const int kt = (DEC_WS_CHUNK / 8) * c + h;
-            const int kn = kt + 1 < 64 ? kt + 1 : 63;
-            b_nxt[0] = h2p[((size_t)kn * ntiles + t0) * 64 + lane];
-            b_nxt[1] = h2p[((size_t)kn * ntiles + t1) * 64 + lane];
-            f32x4 a[8];
+            for (int h = 0; h < DEC_WS_CHUNK / 8; ++h) {
+                const int kt = (DEC_WS_CHUNK / 8) * c + h;
+                const int kn = kt + 1 < 64 ? kt + 1 : 63;
+                b_nxt[0] = h2p[((size_t)kn * ntiles + t0) * 64 + lane];
+                b_nxt[1] = h2p[((size_t)kn * ntiles + t1) * 64 + lane];
+                f32x4 a[8];
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) a[mt] = buf[(h * 8 + mt) * 64];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int mt = 0; mt < 8; ++mt) a[mt] = buf[(h * 8 + mt) * 64];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    acc[0][mt] = mfma16(a[mt][r], b_cur[0][r], acc[0][mt]);
-                    acc[1][mt] = mfma16(a[mt][r], b_cur[1][r], acc[1][mt]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+                    for (int mt = 0; mt < 8; ++mt) {
+                        acc[0][mt] = mfma16(a[mt][r], b_cur[0][r], acc[0][mt]);
+                        acc[1][mt] = mfma16(a[mt][r], b_cur[1][r], acc[1][mt]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+            }
         }
+    } else {
+        // ---- GEMM over K = 1024 as 32 k-steps of 32.  A planes come through the 4-deep LDS ring (chunk = 4 m-tiles x 3
+        // planes, DMA three chunks ahead); the B planes of this wave's two patch tiles sit in three rotating register sets,
+        // loaded two k-steps ahead by asm loads whose completion rides on the ring's waits.  VMEM issue order per wave:
+        //   boundary(2t):   DMA(2t+3) [3 loads], B(t+2) [6 loads]        boundary(2t+1): DMA(2t+4) [3 loads]
+        // so boundary(2t) needs all but its 12 youngest loads (DMA(2t) was issued at boundary(2t-3), B(t) at 2t-4) and
+        // boundary(2t+1) all but its 18 youngest; loads complete in order.
+        const uint4 *h3 = (const uint4 *)h2p;
+        uint4 bs[3][2][3];
+        auto load_b = [&](uint4 (&dst)[2][3], int t) {
+            const int tc = t < 32 ? t : 31;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) dst[nt][pl] = b3_load_async(h3 + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+        };
+        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c = 2 * t + half;
+                if (half == 0) {
+                    if (first) ws.boundary(c); else ws.template boundary_keep<12>(c);
+                    load_b(bload, t + 2);
+                } else
+                    ws.template boundary_keep<18>(c);
+                const f32x4 *buf = ws.chunk(c);
+                bf16x8 a[4][3];
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+                // six products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        load_b(bs[0], 0);
+        load_b(bs[1], 1);
+        kstep(0, bs[0], bs[2], true);                     // boundary(0) waits for everything issued so far
+        kstep(1, bs[1], bs[0], false);
+#pragma unroll 1
+        for (int t = 2; t < 32; t += 3) {                 // t = 2, 5, ..., 29: three k-steps per trip, static register sets
+            kstep(t, bs[2], bs[1], false);
+            kstep(t + 1, bs[0], bs[2], false);
+            kstep(t + 2, bs[1], bs[0], false);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads
     }
     // ---- inv_mlp on registers: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent
     f32x4 in[2][9];
@@ -117,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(blob + DEC_M_B0 + 16 * mt + 4 * g);
-    int f = DEC_STREAM_GEMM_FRAGS;                    // the inv_mlp fragments follow in the same LDS ring
+    int f = B3 ? DEC_B3_GEMM_FRAGS : DEC_STREAM_GEMM_FRAGS;   // the inv_mlp fragments follow in the same LDS ring
     dense_acc_stream<9, 8, 2>(ws, f, in, m0);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -200,8 +322,60 @@ extern "C" int pccx_ae_decode(const float *latent_q, int P, int d, int k, const 
     hipLaunchKernelGGL(dec_head_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, latent_q, P, d, ntiles, dec_blob,
                        (f32x4 *)workspace);
     PCCX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_main_kernel, dim3((ntiles + 7) / 8, k), dim3(256), 0, st, (const f32x4 *)workspace, latent_q, P, d, k,
-                       ntiles, dec_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,
+    hipLaunchKernelGGL(dec_main_kernel<false>, dim3((ntiles + 7) / 8, k), dim3(256), 0, st, (const f32x4 *)workspace, latent_q, P, d,
+                       k, ntiles, dec_blob, (const float *)nullptr, patches_out, scale, centres, nrm_center, nrm_longest,
+                       S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- experimental bf16x3 decoder GEMM (opt-in) ---------------------------------------
+extern "C" size_t pccx_dec_b3_blob_floats(int k) { return DEC_B3_BLOB_FLOATS(k > 0 ? k : 0); }
+
+extern "C" int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream)
+{
+    PCCX_CHECK_ARG(dec_blob_dev && b3_blob_dev && k >= 1, "pccx_pack_ae_decoder_b3: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    PCCX_CHECK_HIP(hipMemsetAsync(b3_blob_dev, 0, sizeof(float) * DEC_B3_BLOB_FLOATS(k), st));
+    const size_t so = (size_t)DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 64, dst_o = (size_t)DEC_B3_STREAM_CHUNKS * DEC_B3_CHUNK * 64;
+    const f32x4 *src = (const f32x4 *)(dec_blob_dev + DEC_G_W(k));
+    const size_t items = (size_t)k * 32 * 8;
+    hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, src, (uint4 *)b3_blob_dev, k, 32, 8, so, dst_o);
+    PCCX_CHECK_LAUNCH();
+    const size_t n = (size_t)k * 114 * 64;
+    hipLaunchKernelGGL(b3_copy_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (f32x4 *)b3_blob_dev, k, so, dst_o);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" size_t pccx_ae_decode_b3_workspace_floats(int P)
+{
+    const size_t ntiles = ((size_t)(P > 0 ? P : 0) + 15) / 16;
+    return (size_t)(64 + 96) * ntiles * 64 * 4;              // fp32 fragments of dec_head + their three bf16 planes
+}
+
+extern "C" int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, const float *dec_blob, const float *b3_blob,
+                                 float *workspace, float *patches_out, float scale, const float *centres, const float *nrm_center,
+                                 const float *nrm_longest, int S, double margin, float *pc_out, void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(latent_q && dec_blob && b3_blob && workspace, "pccx_ae_decode_b3: null pointer");
+    PCCX_CHECK_ARG(patches_out || pc_out, "pccx_ae_decode_b3: need patches_out and/or pc_out");
+    PCCX_CHECK_ARG(P >= 0 && d >= 1 && d <= 16 && k >= 1 && k <= 65535, "pccx_ae_decode_b3: unsupported P=%d d=%d k=%d", P, d, k);
+    PCCX_CHECK_ARG(!pc_out || (centres && nrm_center && nrm_longest && S >= 1 && scale != 0.f),
+                   "pccx_ae_decode_b3: pc_out needs centres, center, longest, S >= 1 and scale != 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (P + 15) / 16;
+    f32x4 *h2p = (f32x4 *)workspace;
+    uint4 *h3 = (uint4 *)(workspace + (size_t)64 * ntiles * 64 * 4);
+    hipLaunchKernelGGL(dec_head_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, latent_q, P, d, ntiles, dec_blob, h2p);
+    PCCX_CHECK_LAUNCH();
+    const size_t items = (size_t)32 * ntiles;
+    hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)h2p, h3, 1, 32, ntiles,
+                       (size_t)0, (size_t)0);
+    PCCX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dec_main_kernel<true>, dim3((ntiles + 7) / 8, k), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
+                       ntiles, dec_blob, b3_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,
                        (float)(1.0 - margin), pc_out);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;

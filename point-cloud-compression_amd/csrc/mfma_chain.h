@@ -122,17 +122,19 @@ __device__ __forceinline__ void max16_of_8_transposed_tiles(const f32x4 (&t)[8],
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
-template <int CH>
+// NB buffers of CH fragments: the DMA of chunk c + NB - 1 is issued at the boundary of chunk c into the buffer chunk c - 1
+// has just vacated (NB = 2: one chunk ahead).
+template <int CH, int NB = 2>
 struct WStreamT {
     const float *g;                       // global stream, NCH * CH fragments, wave-uniform
-    f32x4 *lds;                           // [2][CH][64]
-    int nch;                              // chunks per pass (even)
+    f32x4 *lds;                           // [NB][CH][64]
+    int nch;                              // chunks per pass (a multiple of NB when wrap)
     int lane, wave;
     bool wrap;                            // several passes over the same stream
 
     __device__ __forceinline__ void issue(int c, int buf) const
     {
-        // 4 waves x 4 fragments: wave w moves fragments 4w .. 4w+3 of the chunk.  Source address =
+        // 4 waves x CH/4 fragments: wave w moves fragments (CH/4)w .. of the chunk.  Source address =
         // wave-uniform fragment base (scalar registers) + lane*16 (one VGPR shared by every DMA).
         const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
@@ -143,18 +145,37 @@ struct WStreamT {
             __builtin_amdgcn_global_load_lds((const void *)(src + voff), (lds_u32 *)(uintptr_t)dst, 16, 0, 0);
         }
     }
-    __device__ __forceinline__ void prologue() const { issue(0, 0); }
+    __device__ __forceinline__ void prologue() const
+    {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) issue(i, i);
+    }
+    __device__ __forceinline__ void issue_ahead(int c) const
+    {
+        const int n = c + NB - 1;
+        if (n < nch) issue(n, n % NB);
+        else if (wrap) issue(n - nch, n % NB);      // next pass starts over
+    }
     __device__ __forceinline__ void boundary(int c) const     // before the first read of chunk c
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (c + 1 < nch) issue(c + 1, (c + 1) & 1);
-        else if (wrap) issue(0, (c + 1) & 1);       // next pass starts over (nch is even)
+        issue_ahead(c);
     }
+    // boundary that may leave the wave's N most recent VMEM loads in flight: the caller guarantees that the DMA of
+    // chunk c was issued before them (in-order completion)
+    template <int N>
+    __device__ __forceinline__ void boundary_keep(int c) const
+    {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        __syncthreads();
+        issue_ahead(c);
+    }
+    __device__ __forceinline__ const f32x4 *chunk(int c) const { return lds + (c % NB) * CH * 64 + lane; }
     __device__ __forceinline__ f32x4 get(int f) const         // fragment f of the current pass
     {
         if ((f % CH) == 0) boundary(f / CH);
-        return lds[(((f / CH) & 1) * CH + (f % CH)) * 64 + lane];
+        return lds[(((f / CH) % NB) * CH + (f % CH)) * 64 + lane];
     }
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };

@@ -51,8 +51,9 @@ class Compressed:
 
 
 class Codec:
-    def __init__(self, ae, prob, K=256, ALPHA=2, N0=1024, octree_mode="reference", margin=0.01):
+    def __init__(self, ae, prob, K=256, ALPHA=2, N0=1024, octree_mode="reference", margin=0.01, decoder_matmul="f32"):
         self.ae, self.prob = ae, prob
+        self.decoder_matmul = decoder_matmul                 # "bf16x3": EXPERIMENTAL opt-in (models.AE.decode)
         self.K, self.ALPHA, self.N0 = K, ALPHA, N0
         self.k = K // ALPHA                                  # compress.py:46
         self.octree_mode = octree_mode
@@ -109,7 +110,8 @@ class Codec:
         scale = float((N / self.N0) ** (1 / 3))
         with stage("ae_decode"):
             return self.ae.decode(q.view(B * S, d), rec.view(B * S, 3), comp.c[:, :3].contiguous(),
-                                  comp.c[:, 3].contiguous(), S=S, scale=scale, margin=self.margin)
+                                  comp.c[:, 3].contiguous(), S=S, scale=scale, margin=self.margin,
+                                  matmul=self.decoder_matmul)
 
 
 def d1_psnr(orig, recon):

@@ -116,6 +116,7 @@ class AE(nn.Module):
                      w("inv_mlp.mlp_Modules.2.0.weight"), sd["inv_mlp.mlp_Modules.2.0.bias"],
                      w("inv_mlp.mlp_Modules.3.0.weight"), sd["inv_mlp.mlp_Modules.3.0.bias"]], [self.k, self.d])
         self._enc_blob, self._dec_blob = enc.to(device), dec.to(device)
+        self._dec_b3 = None
         return self
 
     def _blobs(self, device):
@@ -138,16 +139,33 @@ class AE(nn.Module):
                       outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
         return tuple(outs)
 
-    def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01):
+    def _b3_blob(self, device):
+        """EXPERIMENTAL: bf16x3 planes of the decoder's big Linear, built on the device from the packed fp32 blob."""
+        _, dec = self._blobs(device)
+        if getattr(self, "_dec_b3", None) is None or self._dec_b3.device != dec.device:
+            self._dec_b3 = torch.empty(_lib.load().pccx_dec_b3_blob_floats(self.k), device=dec.device, dtype=torch.float32)
+            _lib.call("pccx_pack_ae_decoder_b3", dec.data_ptr(), self.k, self._dec_b3.data_ptr(), _stream())
+        return self._dec_b3
+
+    def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01, matmul="f32"):
         """latent_q (BS,d) -> decoded patches (BS,k,3) (AE.py:48-53).  With centres/center/longest/S/scale
-        it returns instead the reassembled, denormalised cloud (B,S*k,3) of decompress.py:104-116."""
+        it returns instead the reassembled, denormalised cloud (B,S*k,3) of decompress.py:104-116.
+        matmul="bf16x3" (EXPERIMENTAL, opt-in) evaluates the 1024 -> k*128 Linear as fp32 products of three bf16
+        pieces per operand on the bf16 matrix cores: fp32-level error, not bit-identical to the default."""
         q = _f32c(latent_q, "AE.decode")
         P = q.shape[0]
         _, dec = self._blobs(q.device)
-        ws = workspace("dec_h2", _lib.load().pccx_ae_decode_workspace_floats(P), q.device)
+        if matmul == "bf16x3":
+            fn, extra = "pccx_ae_decode_b3", (self._b3_blob(q.device).data_ptr(),)
+            ws = workspace("dec_h2_b3", _lib.load().pccx_ae_decode_b3_workspace_floats(P), q.device)
+        elif matmul == "f32":
+            fn, extra = "pccx_ae_decode", ()
+            ws = workspace("dec_h2", _lib.load().pccx_ae_decode_workspace_floats(P), q.device)
+        else:
+            raise ValueError(f"matmul={matmul!r}: expected 'f32' or 'bf16x3'")
         if centres is None:
             out = torch.empty(P, self.k, 3, device=q.device, dtype=torch.float32)
-            _lib.call("pccx_ae_decode", q.data_ptr(), P, self.d, self.k, dec.data_ptr(), ws.data_ptr(), out.data_ptr(),
+            _lib.call(fn, q.data_ptr(), P, self.d, self.k, dec.data_ptr(), *extra, ws.data_ptr(), out.data_ptr(),
                       0.0, None, None, None, 1, float(margin), None, _stream())
             return out
         B = P // S
@@ -155,7 +173,7 @@ class AE(nn.Module):
         center = _f32c(center.reshape(B, 3), "AE.decode.center")
         longest = _f32c(longest.reshape(B), "AE.decode.longest")
         pc = torch.empty(B, S * self.k, 3, device=q.device, dtype=torch.float32)
-        _lib.call("pccx_ae_decode", q.data_ptr(), P, self.d, self.k, dec.data_ptr(), ws.data_ptr(), None, float(scale),
+        _lib.call(fn, q.data_ptr(), P, self.d, self.k, dec.data_ptr(), *extra, ws.data_ptr(), None, float(scale),
                   centres.data_ptr(), center.data_ptr(), longest.data_ptr(), int(S), float(margin), pc.data_ptr(), _stream())
         return pc
 

@@ -267,3 +267,32 @@ def test_range_coder_other_alphabets_and_ragged_lengths(L, nsym):
         want = cport.range_encode(cdf[b].astype(np.int32), sym[b].astype(np.int16))
         assert bytes(by[b, :int(nb[b])].cpu().numpy()) == want, f"stream {b}"
         assert np.array_equal(cport.range_decode(cdf[b].astype(np.int32), want), sym[b])
+
+
+def test_decoder_bf16x3_experimental_matches_fp32_path(nets):
+    """EXPERIMENTAL opt-in: the decoder's 1024 -> k*128 Linear as fp32 products of three bf16 pieces per operand on
+    the bf16 matrix cores.  Not bit-identical to the fp32 MFMA path; the bar is the same as any fp32 summation
+    reorder: raw patches within 2e-6 absolute of the default path (values are O(0.1)) and within the decoder
+    golden tolerance of the oracle."""
+    ae, _, oae, _ = nets
+    rng = np.random.default_rng(21)
+    for P in (1, 37, 300):
+        lq = rng.integers(-3, 4, size=(P, d)).astype(np.float32)
+        a = ae.decode(torch.from_numpy(lq).cuda()).cpu().numpy()
+        b = ae.decode(torch.from_numpy(lq).cuda(), matmul="bf16x3").cpu().numpy()
+        assert np.isfinite(b).all()
+        assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max()), (P, np.abs(a - b).max(), np.abs(a).max())
+        with torch.no_grad():
+            want = oae.decode(torch.from_numpy(lq)).numpy() if hasattr(oae, "decode") else None
+        if want is not None:
+            np.testing.assert_allclose(b, want.reshape(b.shape), rtol=1e-4, atol=2e-5)
+    # the reassembled cloud path
+    B, S = 2, 64
+    lq = rng.integers(-3, 4, size=(B * S, d)).astype(np.float32)
+    centres = rng.random((B, S, 3)).astype(np.float32)
+    center = rng.random((B, 3)).astype(np.float32)
+    longest = (rng.random(B) + 0.5).astype(np.float32)
+    args = [torch.from_numpy(x).cuda() for x in (lq, centres, center, longest)]
+    p0 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0).cpu().numpy()
+    p1 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0, matmul="bf16x3").cpu().numpy()
+    assert np.abs(p0 - p1).max() <= 4e-6 * max(1.0, np.abs(p0).max())
