@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256, 2) void dec_head_kernel(const float *__restric
     }
 }
 
+#define DEC_GROUP 64                       // patch blocks per group of the block order (dec_main_kernel)
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- experimental bf16x3 operands: x = hi + mid + lo exactly, each a bf16 (round to nearest even)
@@ -116,8 +118,15 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
-    const int p = blockIdx.y;
-    const int tile0 = blockIdx.x * 8 + 2 * w;
+    // Block order: groups of DEC_GROUP patch blocks (128 patches each) outermost, then the point p, then the block inside
+    // the group.  Consecutive workgroups share point p's weight stream (L2), and a group's activation fragments
+    // (DEC_GROUP x 8 tiles, 32-48 MB) stay in the Infinity Cache while all k points sweep over them, instead of the whole
+    // activation array being re-streamed from HBM once per point.
+    const int nblk = (ntiles + 7) / 8;
+    const int grp = blockIdx.x / (DEC_GROUP * k), rem = blockIdx.x % (DEC_GROUP * k);
+    const int p = rem / DEC_GROUP, blk = grp * DEC_GROUP + rem % DEC_GROUP;
+    if (blk >= nblk) return;                                  // whole workgroup (before any barrier)
+    const int tile0 = blk * 8 + 2 * w;
     constexpr int CH = B3 ? DEC_B3_CHUNK : DEC_WS_CHUNK;
     constexpr int NB = B3 ? 4 : 2;                                        // ring depth: B3 chunks are short, their DMA needs 3 chunks of lead
     __shared__ __attribute__((aligned(16))) f32x4 swt[NB * CH * 64];     // ring: one k-tile (8 m-tiles) per chunk; B3: 4 m-tiles x 3 planes
@@ -300,6 +309,12 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     }
 }
 
+static unsigned dec_grid(int ntiles, int k)
+{
+    const int nblk = (ntiles + 7) / 8, groups = (nblk + DEC_GROUP - 1) / DEC_GROUP;
+    return (unsigned)groups * DEC_GROUP * (unsigned)k;
+}
+
 extern "C" size_t pccx_ae_decode_workspace_floats(int P)
 {
     const size_t ntiles = ((size_t)(P > 0 ? P : 0) + 15) / 16;
@@ -322,7 +337,7 @@ extern "C" int pccx_ae_decode(const float *latent_q, int P, int d, int k, const 
     hipLaunchKernelGGL(dec_head_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, latent_q, P, d, ntiles, dec_blob,
                        (f32x4 *)workspace);
     PCCX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_main_kernel<false>, dim3((ntiles + 7) / 8, k), dim3(256), 0, st, (const f32x4 *)workspace, latent_q, P, d,
+    hipLaunchKernelGGL(dec_main_kernel<false>, dim3(dec_grid(ntiles, k)), dim3(256), 0, st, (const f32x4 *)workspace, latent_q, P, d,
                        k, ntiles, dec_blob, (const float *)nullptr, patches_out, scale, centres, nrm_center, nrm_longest,
                        S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
     PCCX_CHECK_LAUNCH();
@@ -374,7 +389,7 @@ extern "C" int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, con
     hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)h2p, h3, 1, 32, ntiles,
                        (size_t)0, (size_t)0);
     PCCX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_main_kernel<true>, dim3((ntiles + 7) / 8, k), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
+    hipLaunchKernelGGL(dec_main_kernel<true>, dim3(dec_grid(ntiles, k)), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
                        ntiles, dec_blob, b3_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,
                        (float)(1.0 - margin), pc_out);
     PCCX_CHECK_LAUNCH();
