@@ -189,7 +189,7 @@ PCCX_API int pccx_ae_decode(const float *latent_q, int P, int d, int k, const fl
                             const float *nrm_center, const float *nrm_longest, int S, double margin,
                             float *pc_out, void *stream);
 
-/* EXPERIMENTAL, opt-in: the same synthesis transform with the K = 1024 Linear evaluated as
+/* EXPERIMENTAL, opt-in: the same synthesis transform with the K = 1024 Linear and inv_mlp evaluated as
  * fp32 products of three bf16 pieces per operand on the bf16 matrix cores (six v_mfma_f32_16x16x32_bf16 passes,
  * fp32 accumulate; error at the level of an fp32 summation reorder, not bit-identical to pccx_ae_decode).
  * b3_blob: pccx_dec_b3_blob_floats(k) floats on the device, filled once from the packed decoder blob (already on

@@ -63,10 +63,12 @@
 // ---- experimental: decoder GEMM as fp32 products of three bf16 pieces per operand (decoder.hip, dec_main_kernel<true>).
 // Per point p: [32 k-steps of 32][8 m-tiles][3 planes hi/mid/lo] bf16 A fragments of v_mfma_f32_16x16x32_bf16
 // (1 KiB each: lane (m = lane%16, kg = lane/16) holds 8 bf16 of k-slots 8*kg + j <-> channel 32t + 16*(j>>2) + 4*kg + (j&3),
-// the order in which two fp32 C tiles concatenate), then the 114 fp32 inv_mlp fragments, padded to chunks of 12.
+// the order in which two fp32 C tiles concatenate), then the inv_mlp layers in the same form (L0 [5][8][3] with the odd ninth
+// k-tile zero-padded, L1 [4][4][3], L2 [2][2][3], L3 [1][1][3] = 183 fragments), padded to chunks of 12.
 #define DEC_B3_CHUNK 12
 #define DEC_B3_GEMM_FRAGS (32 * 8 * 3)
-#define DEC_B3_STREAM_FRAGS (DEC_B3_GEMM_FRAGS + 114)
+#define DEC_B3_TAIL_FRAGS (120 + 48 + 12 + 3)
+#define DEC_B3_STREAM_FRAGS (DEC_B3_GEMM_FRAGS + DEC_B3_TAIL_FRAGS)
 #define DEC_B3_STREAM_CHUNKS (2 * ((DEC_B3_STREAM_FRAGS + 2 * DEC_B3_CHUNK - 1) / (2 * DEC_B3_CHUNK)))
 #define DEC_B3_BLOB_FLOATS(k) ((size_t)(k) * DEC_B3_STREAM_CHUNKS * DEC_B3_CHUNK * 256)
 

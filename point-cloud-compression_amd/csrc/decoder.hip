@@ -69,16 +69,17 @@ __device__ __forceinline__ void b3_split(float x, unsigned &h, unsigned &m, unsi
 // fragment of v_mfma_f32_16x16x32_bf16.  Lane-local: lane (x, kg) holds channels 16*kt + 4*kg + r of both k-tiles, which
 // are k-slots 8*kg + j of the bf16 operand.  src index = outer*src_outer + ((2t + h)*W + j)*64 + lane,
 // dst index = outer*dst_outer + ((t*W + j)*3 + plane)*64 + lane (units: 16-byte vectors).
-__global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__ src, uint4 *__restrict__ dst, int n_outer, int T, int W,
+__global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__ src, uint4 *__restrict__ dst, int n_outer, int KT16, int W,
                                                        size_t src_outer, size_t dst_outer)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, T = (KT16 + 1) / 2;     // an odd last k-tile pairs with zeros
     const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (size_t)n_outer * T * W) return;
     const int j = (int)(item % W), t = (int)((item / W) % T);
     const size_t o = item / ((size_t)W * T);
     const f32x4 v0 = src[o * src_outer + ((size_t)(2 * t) * W + j) * 64 + lane];
-    const f32x4 v1 = src[o * src_outer + ((size_t)(2 * t + 1) * W + j) * 64 + lane];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v1 = 2 * t + 1 < KT16 ? src[o * src_outer + ((size_t)(2 * t + 1) * W + j) * 64 + lane] : zero;
     unsigned h[8], m[8], l[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { b3_split(v0[r], h[r], m[r], l[r]); b3_split(v1[r], h[4 + r], m[4 + r], l[4 + r]); }
@@ -88,13 +89,66 @@ __global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__
     d[128] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
-// copies the 114 fp32 inv_mlp fragments of every point's fp32 stream behind the bf16 GEMM planes of its b3 stream
-__global__ void b3_copy_tail_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int k, size_t src_outer, size_t dst_outer)
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// In-register split of two fp32 C tiles (8 values per lane = one K=32 B operand) into the three bf16 planes:
+// v_cvt_pk_bf16_f32 (round to nearest even), widen back, exact residual, twice.
+__device__ __forceinline__ void b3_split8(const f32x4 &v0, const f32x4 &v1, bf16x8 (&pl)[3])
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)k * 114 * 64) return;
-    const size_t p = i / (114 * 64), e = i % (114 * 64);
-    dst[p * dst_outer + (size_t)DEC_B3_GEMM_FRAGS * 64 + e] = src[p * src_outer + (size_t)DEC_STREAM_GEMM_FRAGS * 64 + e];
+    unsigned w[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2v x = q < 2 ? f32x2v{v0[2 * q], v0[2 * q + 1]} : f32x2v{v1[2 * q - 4], v1[2 * q - 3]};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const bf16x2 h = __builtin_convertvector(x, bf16x2);
+            w[p][q] = __builtin_bit_cast(unsigned, h);
+            if (p < 2) x = x - __builtin_convertvector(h, f32x2v);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pl[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+}
+
+// dense layer of the chain on bf16x3 operands: in[nt][kt][plane] are K=32 B operands, the weight blocks ([kt][mt][plane],
+// three 1 KiB A fragments each) come from the LDS ring in stream order; six products per block, two blocks in flight.
+template <int KT, int MT, int NT, class WS>
+__device__ __forceinline__ void dense_b3_stream(const WS &ws, int &f, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    bf16x8 cur[MG][3], nxt[MG][3];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * m + p));
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * ((gi + 1) * MG + m) + p));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
+    }
+    f += 3 * KT * MT;
 }
 
 __device__ __forceinline__ uint4 b3_load_async(const uint4 *p)    // placed exactly here; completion is covered by the ring's s_waitcnt
@@ -232,52 +286,104 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads
     }
-    // ---- inv_mlp on registers: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent
-    f32x4 in[2][9];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) in[nt][mt] = relu4(acc[nt][mt]);
-        const int patch = (tile0 + nt) * 16 + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            in[nt][8][r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
-    }
-    f32x4 m0[2][8];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(blob + DEC_M_B0 + 16 * mt + 4 * g);
-    int f = B3 ? DEC_B3_GEMM_FRAGS : DEC_STREAM_GEMM_FRAGS;   // the inv_mlp fragments follow in the same LDS ring
-    dense_acc_stream<9, 8, 2>(ws, f, in, m0);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = relu4(m0[nt][mt]);
-    f32x4 m1[2][4];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(blob + DEC_M_B1 + 16 * mt + 4 * g);
-    dense_acc_stream<8, 4, 2>(ws, f, m0, m1);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = relu4(m1[nt][mt]);
-    f32x4 m2[2][2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(blob + DEC_M_B2 + 16 * mt + 4 * g);
-    dense_acc_stream<4, 2, 2>(ws, f, m1, m2);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = relu4(m2[nt][mt]);
     f32x4 m3[2][1];
+    if constexpr (!B3) {
+        // ---- inv_mlp on registers: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent
+        f32x4 in[2][9];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(blob + DEC_M_B3 + 4 * g);
-    dense_acc_stream<2, 1, 2>(ws, f, m2, m3);          // last layer: no ReLU (AE.py:27)
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) in[nt][mt] = relu4(acc[nt][mt]);
+            const int patch = (tile0 + nt) * 16 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                in[nt][8][r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
+        }
+        f32x4 m0[2][8];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(blob + DEC_M_B0 + 16 * mt + 4 * g);
+        int f = B3 ? DEC_B3_GEMM_FRAGS : DEC_STREAM_GEMM_FRAGS;   // the inv_mlp fragments follow in the same LDS ring
+        dense_acc_stream<9, 8, 2>(ws, f, in, m0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = relu4(m0[nt][mt]);
+        f32x4 m1[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(blob + DEC_M_B1 + 16 * mt + 4 * g);
+        dense_acc_stream<8, 4, 2>(ws, f, m0, m1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = relu4(m1[nt][mt]);
+        f32x4 m2[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(blob + DEC_M_B2 + 16 * mt + 4 * g);
+        dense_acc_stream<4, 2, 2>(ws, f, m1, m2);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = relu4(m2[nt][mt]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(blob + DEC_M_B3 + 4 * g);
+        dense_acc_stream<2, 1, 2>(ws, f, m2, m3);          // last layer: no ReLU (AE.py:27)
+    } else {
+        // ---- inv_mlp as a bf16x3 chain: every layer's input is split in registers (relu, then three bf16 planes per pair
+        // of 16-channel tiles); the ninth input tile (the latent) pairs with zeros.
+        int f = DEC_B3_GEMM_FRAGS;
+        bf16x8 i0[2][5][3];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b3_split8(relu4(acc[nt][2 * t]), relu4(acc[nt][2 * t + 1]), i0[nt][t]);
+            const int patch = (tile0 + nt) * 16 + n;
+            f32x4 lat;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lat[r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
+            b3_split8(lat, zero, i0[nt][4]);
+        }
+        f32x4 m0[2][8];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(blob + DEC_M_B0 + 16 * mt + 4 * g);
+        dense_b3_stream<5, 8, 2>(ws, f, i0, m0);
+        bf16x8 i1[2][4][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b3_split8(relu4(m0[nt][2 * t]), relu4(m0[nt][2 * t + 1]), i1[nt][t]);
+        f32x4 m1[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(blob + DEC_M_B1 + 16 * mt + 4 * g);
+        dense_b3_stream<4, 4, 2>(ws, f, i1, m1);
+        bf16x8 i2[2][2][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b3_split8(relu4(m1[nt][2 * t]), relu4(m1[nt][2 * t + 1]), i2[nt][t]);
+        f32x4 m2[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(blob + DEC_M_B2 + 16 * mt + 4 * g);
+        dense_b3_stream<2, 2, 2>(ws, f, i2, m2);
+        bf16x8 i3[2][1][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b3_split8(relu4(m2[nt][0]), relu4(m2[nt][1]), i3[nt][0]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(blob + DEC_M_B3 + 4 * g);
+        dense_b3_stream<1, 1, 2>(ws, f, i3, m3);          // last layer: no ReLU (AE.py:27)
+    }
     ws.drain();
 
     // ---- epilogue: rows 0..2 of the last tile (g == 0, r = 0..2) are x,y,z of (patch, point p)
@@ -354,12 +460,18 @@ extern "C" int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *
     PCCX_CHECK_HIP(hipMemsetAsync(b3_blob_dev, 0, sizeof(float) * DEC_B3_BLOB_FLOATS(k), st));
     const size_t so = (size_t)DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 64, dst_o = (size_t)DEC_B3_STREAM_CHUNKS * DEC_B3_CHUNK * 64;
     const f32x4 *src = (const f32x4 *)(dec_blob_dev + DEC_G_W(k));
-    const size_t items = (size_t)k * 32 * 8;
-    hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, src, (uint4 *)b3_blob_dev, k, 32, 8, so, dst_o);
-    PCCX_CHECK_LAUNCH();
-    const size_t n = (size_t)k * 114 * 64;
-    hipLaunchKernelGGL(b3_copy_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (f32x4 *)b3_blob_dev, k, so, dst_o);
-    PCCX_CHECK_LAUNCH();
+    // GEMM: [64 kt16][8 mt] fp32 fragments -> [32][8][3]; then the four inv_mlp layers ([kt16][mt] each, kt-major) likewise
+    const int KT16[5] = {64, 9, 8, 4, 2}, MTL[5] = {8, 8, 4, 2, 1};
+    size_t s_off = 0, d_off = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int T = (KT16[l] + 1) / 2;
+        const size_t items = (size_t)k * T * MTL[l];
+        hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, src + s_off * 64,
+                           (uint4 *)b3_blob_dev + d_off * 64, k, KT16[l], MTL[l], so, dst_o);
+        PCCX_CHECK_LAUNCH();
+        s_off += (size_t)KT16[l] * MTL[l];
+        d_off += (size_t)T * MTL[l] * 3;
+    }
     return PCCX_OK;
 }
 
@@ -386,7 +498,7 @@ extern "C" int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, con
     hipLaunchKernelGGL(dec_head_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, latent_q, P, d, ntiles, dec_blob, h2p);
     PCCX_CHECK_LAUNCH();
     const size_t items = (size_t)32 * ntiles;
-    hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)h2p, h3, 1, 32, ntiles,
+    hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)h2p, h3, 1, 64, ntiles,
                        (size_t)0, (size_t)0);
     PCCX_CHECK_LAUNCH();
     hipLaunchKernelGGL(dec_main_kernel<true>, dim3(dec_grid(ntiles, k)), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
