@@ -195,6 +195,11 @@ PCCX_API int pccx_ae_decode(const float *latent_q, int P, int d, int k, const fl
  * b3_blob: pccx_dec_b3_blob_floats(k) floats on the device, filled once from the packed decoder blob (already on
  * the device) by pccx_pack_ae_decoder_b3.  workspace: pccx_ae_decode_b3_workspace_floats(P).  Replaces the same
  * reference lines as pccx_ae_decode (AE.py:48-53, decompress.py:97-116). */
+PCCX_API size_t pccx_sa_b3_blob_floats(void);
+PCCX_API int pccx_pack_sa_b3(const float *enc_blob_dev, float *sa_b3_blob_dev, void *stream);
+/* pccx_sa_forward (pn_kit.py:164-211) with conv1 / conv2 on bf16x3 operands; same EXPERIMENTAL status. */
+PCCX_API int pccx_sa_forward_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
+                                float *feat, void *stream);
 PCCX_API size_t pccx_dec_b3_blob_floats(int k);
 PCCX_API int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream);
 PCCX_API size_t pccx_ae_decode_b3_workspace_floats(int P);

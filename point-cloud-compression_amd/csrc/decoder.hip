@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256, 2) void dec_head_kernel(const float *__restric
 
 #define DEC_GROUP 64                       // patch blocks per group of the block order (dec_main_kernel)
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- experimental bf16x3 operands: x = hi + mid + lo exactly, each a bf16 (round to nearest even)
 __device__ __forceinline__ unsigned b3_rne(float x)
@@ -87,28 +86,6 @@ __global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__
     d[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
     d[64] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
     d[128] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-}
-
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// In-register split of two fp32 C tiles (8 values per lane = one K=32 B operand) into the three bf16 planes:
-// v_cvt_pk_bf16_f32 (round to nearest even), widen back, exact residual, twice.
-__device__ __forceinline__ void b3_split8(const f32x4 &v0, const f32x4 &v1, bf16x8 (&pl)[3])
-{
-    unsigned w[3][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x2v x = q < 2 ? f32x2v{v0[2 * q], v0[2 * q + 1]} : f32x2v{v1[2 * q - 4], v1[2 * q - 3]};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const bf16x2 h = __builtin_convertvector(x, bf16x2);
-            w[p][q] = __builtin_bit_cast(unsigned, h);
-            if (p < 2) x = x - __builtin_convertvector(h, f32x2v);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) pl[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
 }
 
 // dense layer of the chain on bf16x3 operands: in[nt][kt][plane] are K=32 B operands, the weight blocks ([kt][mt][plane],
@@ -472,6 +449,22 @@ extern "C" int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *
         s_off += (size_t)KT16[l] * MTL[l];
         d_off += (size_t)T * MTL[l] * 3;
     }
+    return PCCX_OK;
+}
+
+// SetAbstraction conv1 / conv2 weight planes (encoder.hip: sa_forward_kernel<true>): [1 x 4 x 3][2 x 8 x 3] fragments
+extern "C" size_t pccx_sa_b3_blob_floats(void) { return (size_t)(1 * 4 * 3 + 2 * 8 * 3) * 256; }
+
+extern "C" int pccx_pack_sa_b3(const float *enc_blob_dev, float *sa_b3_blob_dev, void *stream)
+{
+    PCCX_CHECK_ARG(enc_blob_dev && sa_b3_blob_dev, "pccx_pack_sa_b3: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(b3_split_kernel, dim3((1 * 4 + 3) / 4), dim3(256), 0, st, (const f32x4 *)(enc_blob_dev + ENC_SA_W1),
+                       (uint4 *)sa_b3_blob_dev, 1, 2, 4, (size_t)0, (size_t)0);
+    PCCX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(b3_split_kernel, dim3((2 * 8 + 3) / 4), dim3(256), 0, st, (const f32x4 *)(enc_blob_dev + ENC_SA_W2),
+                       (uint4 *)sa_b3_blob_dev + 12 * 64, 1, 4, 8, (size_t)0, (size_t)0);
+    PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
 

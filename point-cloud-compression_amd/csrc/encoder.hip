@@ -30,13 +30,19 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
-__global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restrict__ x, int K, const float *__restrict__ blob,
-                                                         float *__restrict__ feat)
+// B3 (EXPERIMENTAL, opt-in): conv1 and conv2 as fp32 products of three bf16 pieces per operand on the
+// bf16 matrix cores.  blob3 = [conv1: 1 kt32 x 4 mt x 3 planes][conv2: 2 x 8 x 3] fragments (pccx_pack_sa_b3).
+#define SA_W1_FRAGS(b3) ((b3) ? 1 * 4 * 3 : 2 * 4)
+#define SA_W2_FRAGS(b3) ((b3) ? 2 * 8 * 3 : 4 * 8)
+
+template <bool B3>
+__global__ __launch_bounds__(256, B3 ? 2 : 3) void sa_forward_kernel(const float *__restrict__ x, int K, const float *__restrict__ blob,
+                                                                  const float *__restrict__ blob3, float *__restrict__ feat)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f32x4 *sw1 = (f32x4 *)smem;                          // [2*4*64]   8 KiB
-    f32x4 *sw2 = sw1 + 2 * 4 * 64;                       // [4*8*64]  32 KiB
-    float *sb1 = (float *)(sw2 + 4 * 8 * 64);            // [64]
+    f32x4 *sw1 = (f32x4 *)smem;                          // fp32: [2*4*64] 8 KiB;  B3: 12 KiB
+    f32x4 *sw2 = sw1 + SA_W1_FRAGS(B3) * 64;             // fp32: [4*8*64] 32 KiB; B3: 48 KiB
+    float *sb1 = (float *)(sw2 + SA_W2_FRAGS(B3) * 64);  // [64]
     float *sb2 = sb1 + 64;                               // [128]
     float *sx = sb2 + 128;                               // [3K]
     unsigned char *nbr = (unsigned char *)(sx + 3 * K);  // [K][16] (index < K <= 1024 needs 10 bits)
@@ -48,10 +54,10 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
     const float *xp = x + P * (size_t)K * 3;
 
     {   // stage weights + patch
-        const f32x4 *gw1 = (const f32x4 *)(blob + ENC_SA_W1);
-        const f32x4 *gw2 = (const f32x4 *)(blob + ENC_SA_W2);
-        for (int i = tid; i < 2 * 4 * 64; i += 256) sw1[i] = gw1[i];
-        for (int i = tid; i < 4 * 8 * 64; i += 256) sw2[i] = gw2[i];
+        const f32x4 *gw1 = B3 ? (const f32x4 *)blob3 : (const f32x4 *)(blob + ENC_SA_W1);
+        const f32x4 *gw2 = B3 ? (const f32x4 *)blob3 + SA_W1_FRAGS(true) * 64 : (const f32x4 *)(blob + ENC_SA_W2);
+        for (int i = tid; i < SA_W1_FRAGS(B3) * 64; i += 256) sw1[i] = gw1[i];
+        for (int i = tid; i < SA_W2_FRAGS(B3) * 64; i += 256) sw2[i] = gw2[i];
         if (tid < 64) sb1[tid] = blob[ENC_SA_B1 + tid];
         if (tid < 128) sb2[tid] = blob[ENC_SA_B2 + tid];
         for (int i = tid; i < 3 * K; i += 256) sx[i] = xp[i];
@@ -140,11 +146,6 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
         f32x4 a1[2][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) a1[0][mt] = a1[1][mt] = *(const f32x4 *)(sb1 + 16 * mt + 4 * g);
-        dense_acc<2, 4, 2, 4>(sw1, lane, h0, a1);                                    // conv1
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = relu4(a1[nt][mt]);
         // conv2 transposed (points x channels): bias of channel 16*mt + n in every register
         f32x4 a2[2][8];
 #pragma unroll
@@ -153,7 +154,25 @@ __global__ __launch_bounds__(256, 3) void sa_forward_kernel(const float *__restr
             f32x4 b4 = {bv, bv, bv, bv};
             a2[0][mt] = b4; a2[1][mt] = b4;
         }
-        dense_acc<4, 8, 2, 8, true>(sw2, lane, a1, a2);                              // conv2
+        if constexpr (!B3) {
+            dense_acc<2, 4, 2, 4>(sw1, lane, h0, a1);                                // conv1
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a1[nt][mt] = relu4(a1[nt][mt]);
+            dense_acc<4, 8, 2, 8, true>(sw2, lane, a1, a2);                          // conv2
+        } else {
+            bf16x8 i1[2][1][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b3_split8(h0[nt][0], h0[nt][1], i1[nt][0]);
+            dense_b3<1, 4, 2>(sw1, lane, i1, a1);                                    // conv1
+            bf16x8 i2[2][2][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) b3_split8(relu4(a1[nt][2 * t]), relu4(a1[nt][2 * t + 1]), i2[nt][t]);
+            dense_b3<2, 8, 2, true>(sw2, lane, i2, a2);                              // conv2
+        }
         // relu then max over the 16 neighbours (pn_kit.py:204-207) == max then relu
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -277,12 +296,19 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
     }
 }
 
-static int launch_sa(const float *patches, int P, int K, const float *enc_blob, float *feat, hipStream_t st)
+static int launch_sa(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob, float *feat, hipStream_t st)
 {
-    const size_t sa_lds = (size_t)(2 * 4 * 64 + 4 * 8 * 64) * 16 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32;
-    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(sa_forward_kernel, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, feat);
+    const bool b3 = sa_b3_blob != nullptr;
+    const size_t sa_lds = (size_t)(SA_W1_FRAGS(b3) + SA_W2_FRAGS(b3)) * 64 * 16 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32;
+    if (b3) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(sa_forward_kernel<true>, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, sa_b3_blob, feat);
+    } else {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(sa_forward_kernel<false>, dim3(P), dim3(256), sa_lds, st, patches, K, enc_blob, (const float *)nullptr, feat);
+    }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
@@ -313,7 +339,17 @@ extern "C" int pccx_sa_forward(const float *patches, int P, int K, const float *
     PCCX_CHECK_ARG(patches && enc_blob && feat, "pccx_sa_forward: null pointer");
     CHECK_PK("pccx_sa_forward");
     if (P == 0) return PCCX_OK;
-    return launch_sa(patches, P, K, enc_blob, feat, (hipStream_t)stream);
+    return launch_sa(patches, P, K, enc_blob, nullptr, feat, (hipStream_t)stream);
+}
+
+// EXPERIMENTAL, opt-in: see sa_forward_kernel<true>
+extern "C" int pccx_sa_forward_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob, float *feat,
+                                  void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(patches && enc_blob && sa_b3_blob && feat, "pccx_sa_forward_b3: null pointer");
+    CHECK_PK("pccx_sa_forward_b3");
+    return launch_sa(patches, P, K, enc_blob, sa_b3_blob, feat, (hipStream_t)stream);
 }
 
 extern "C" int pccx_pn_forward(const float *patches, const float *feat, int P, int K, const float *enc_blob, int d, int L,
@@ -335,7 +371,7 @@ extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *e
     CHECK_PK("pccx_ae_encode");
     PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode: unsupported d=%d L=%d", d, L);
     if (P == 0) return PCCX_OK;
-    int rc = launch_sa(patches, P, K, enc_blob, feat_ws, (hipStream_t)stream);
+    int rc = launch_sa(patches, P, K, enc_blob, nullptr, feat_ws, (hipStream_t)stream);
     if (rc != PCCX_OK) return rc;
     return launch_pn(patches, feat_ws, P, K, enc_blob, d, L, latent_raw, latent, latent_q, (hipStream_t)stream);
 }

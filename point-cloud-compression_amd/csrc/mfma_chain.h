@@ -106,6 +106,74 @@ __device__ __forceinline__ void max16_of_8_transposed_tiles(const f32x4 (&t)[8],
 }
 
 // ------------------------------------------------------------------------------------------
+// EXPERIMENTAL bf16x3 operands: fp32 products formed on the bf16 matrix cores from three bf16
+// pieces per operand (x = hi + mid + lo exactly), the six products of weight i + j <= 4 accumulated in fp32.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// In-register split of two fp32 C tiles (8 values per lane = one K=32 B operand) into the three bf16 planes:
+// v_cvt_pk_bf16_f32 (round to nearest even), widen back, exact residual, twice.
+__device__ __forceinline__ void b3_split8(const f32x4 &v0, const f32x4 &v1, bf16x8 (&pl)[3])
+{
+    unsigned w[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2v x = q < 2 ? f32x2v{v0[2 * q], v0[2 * q + 1]} : f32x2v{v1[2 * q - 4], v1[2 * q - 3]};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const bf16x2 h = __builtin_convertvector(x, bf16x2);
+            w[p][q] = __builtin_bit_cast(unsigned, h);
+            if (p < 2) x = x - __builtin_convertvector(h, f32x2v);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pl[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+}
+
+// dense layer on bf16x3 operands with the weight blocks RESIDENT in LDS as [kt][mt][plane] fragments (K = 32 per kt).
+// SWAP exchanges the MFMA operands (the lane maps of 16x16x32 mirror each other like those of 16x16x4): the tile comes out
+// transposed, D[point][channel].
+template <int KT, int MT, int NT, bool SWAP = false>
+__device__ __forceinline__ void dense_b3(const f32x4 *w, int lane, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    bf16x8 cur[MG][3], nxt[MG][3];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[m][p] = __builtin_bit_cast(bf16x8, w[(size_t)(m * 3 + p) * 64 + lane]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = __builtin_bit_cast(bf16x8, w[(size_t)(((gi + 1) * MG + m) * 3 + p) * 64 + lane]);
+        }
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(in[nt][kt][PB[q]], cur[m][PA[q]], acc[nt][m0 + m], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Weight stream through LDS.  When every wave of a workgroup consumes the SAME fragment sequence
 // (PointNet: each wave runs the whole layer stack on its own 16 points), the sequence is packed on
 // the host in consumption order and streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4, one

@@ -296,3 +296,25 @@ def test_decoder_bf16x3_experimental_matches_fp32_path(nets):
     p0 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0).cpu().numpy()
     p1 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0, matmul="bf16x3").cpu().numpy()
     assert np.abs(p0 - p1).max() <= 4e-6 * max(1.0, np.abs(p0).max())
+
+
+def test_sa_bf16x3_experimental_matches_fp32_path(nets):
+    """EXPERIMENTAL opt-in: SetAbstraction conv1 / conv2 as bf16x3-split fp32 products.  Feature map within 1e-6 of the
+    exact-fp32 kernel (features are O(0.1)), latents within 2e-6, symbols equal except at a rounding boundary."""
+    from pccx import _lib
+    ae = nets[0]
+    patches = synth.patch_batch(K)
+    x = torch.from_numpy(patches).cuda().contiguous()
+    P = x.shape[0]
+    enc, _ = ae._blobs(x.device)
+    f0 = torch.empty(P * 8 * K * 16, device="cuda")
+    f1 = torch.empty_like(f0)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("pccx_sa_forward", x.data_ptr(), P, K, enc.data_ptr(), f0.data_ptr(), st)
+    _lib.call("pccx_sa_forward_b3", x.data_ptr(), P, K, enc.data_ptr(), ae._sa_b3_blob(x.device).data_ptr(), f1.data_ptr(), st)
+    a, b = f0.cpu().numpy(), f1.cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max()), (np.abs(a - b).max(), np.abs(a).max())
+    _, lat0, q0 = ae.encode(x)
+    _, lat1, q1 = ae.encode(x, sa_matmul="bf16x3")
+    assert np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max() <= 2e-6
+    _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
