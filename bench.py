@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="clouds per GPU per step")
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
     ap.add_argument("--sa-matmul", default="f32", choices=["f32", "bf16x3"], help="EXPERIMENTAL, as --decoder-matmul, for SetAbstraction")
+    ap.add_argument("--pn-matmul", default="f32", choices=["f32", "bf16x3"], help="EXPERIMENTAL, as --decoder-matmul, for PointNet")
     ap.add_argument("--decoder-matmul", default="f32", choices=["f32", "bf16x3"],
                     help="bf16x3 = EXPERIMENTAL: the decoder's big Linear as fp32 products of three bf16 pieces per operand on the "
                          "bf16 matrix cores (fp32-level error, not bit-identical); the default f32 is the measured configuration")
@@ -211,7 +212,7 @@ def main():
     prob.load_state_dict(seeded_state_dict(prob, PROB_SEED, gain=PROB_GAIN))
     ae.pack(dev)
     prob.pack(dev)
-    cd = codec.Codec(ae, prob, K=K_PATCH, ALPHA=ALPHA, N0=N0, octree_mode=args.octree_mode, decoder_matmul=args.decoder_matmul, sa_matmul=args.sa_matmul)
+    cd = codec.Codec(ae, prob, K=K_PATCH, ALPHA=ALPHA, N0=N0, octree_mode=args.octree_mode, decoder_matmul=args.decoder_matmul, sa_matmul=args.sa_matmul, pn_matmul=args.pn_matmul)
 
     B = args.batch
     # shard by file: global cloud i -> rank i % world; 32 distinct shapes per rank, tiled
@@ -274,14 +275,14 @@ def main():
             "value": world * B * N_POINTS * args.steps / dt, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.decoder_matmul == args.sa_matmul == "f32" else
+            "dtype": "f32" if args.decoder_matmul == args.sa_matmul == args.pn_matmul == "f32" else
                      "f32 (EXPERIMENTAL: bf16x3-split operands, fp32 accumulate, in: %s)" % "+".join(
-                         n for n, v in (("decoder", args.decoder_matmul), ("sa", args.sa_matmul)) if v != "f32"),
+                         n for n, v in (("decoder", args.decoder_matmul), ("sa", args.sa_matmul), ("pn", args.pn_matmul)) if v != "f32"),
             "data": "synthetic",
             "config": {"workload": "IPDAE K=256 d=16 L=7, 8192-pt CAD-like synthetic clouds (configs[1])",
                        "clouds_per_gpu_per_step": B, "points_per_cloud": N_POINTS, "patches_per_cloud": S_PATCH,
                        "octree_mode": args.octree_mode, "sharding": f"file-sharded x{world}", "weights": "seeded random",
-                       "pcie_inclusive": bool(args.pcie), "decoder_matmul": args.decoder_matmul, "sa_matmul": args.sa_matmul},
+                       "pcie_inclusive": bool(args.pcie), "decoder_matmul": args.decoder_matmul, "sa_matmul": args.sa_matmul, "pn_matmul": args.pn_matmul},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS, "traffic": measured_traffic(dom, B),
                          "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P},

@@ -200,6 +200,12 @@ PCCX_API int pccx_pack_sa_b3(const float *enc_blob_dev, float *sa_b3_blob_dev, v
 /* pccx_sa_forward (pn_kit.py:164-211) with conv1 / conv2 on bf16x3 operands; same EXPERIMENTAL status. */
 PCCX_API int pccx_sa_forward_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
                                 float *feat, void *stream);
+PCCX_API size_t pccx_pn_b3_blob_floats(void);
+PCCX_API int pccx_pack_pn_b3(const float *enc_blob_dev, float *pn_b3_blob_dev, void *stream);
+/* pccx_pn_forward (pn_kit.py:124-144, AE.py:43-45) on bf16x3 operands; same EXPERIMENTAL status. */
+PCCX_API int pccx_pn_forward_b3(const float *patches, const float *feat, int P, int K, const float *enc_blob,
+                                const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
+                                float *latent_q, void *stream);
 PCCX_API size_t pccx_dec_b3_blob_floats(int k);
 PCCX_API int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream);
 PCCX_API size_t pccx_ae_decode_b3_workspace_floats(int P);

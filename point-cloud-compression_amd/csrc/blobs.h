@@ -34,6 +34,14 @@
 #define ENC_PN_STREAM_CHUNKS (2 * ((ENC_PN_STREAM_FRAGS + 2 * WS_CHUNK - 1) / (2 * WS_CHUNK)))      // even
 #define ENC_BLOB_FLOATS (ENC_PN_STREAM + ENC_PN_STREAM_CHUNKS * WS_CHUNK * 256)
 
+// EXPERIMENTAL PointNet weight stream on bf16x3 operands (encoder.hip: pn_forward_b3_kernel): L0 [5][8][3], L1 [4][16][3],
+// then per half h of layer 2's outputs: L2 [8][16][3] and L3 [8][1][3] fragments, [kt32][mt][plane] each (pccx_pack_pn_b3),
+// padded to chunks of 24.
+#define PN_B3_CHUNK 24
+#define PN_B3_STREAM_FRAGS (120 + 192 + 768 + 48)
+#define PN_B3_STREAM_CHUNKS (2 * ((PN_B3_STREAM_FRAGS + 2 * PN_B3_CHUNK - 1) / (2 * PN_B3_CHUNK)))
+#define PN_B3_BLOB_FLOATS ((size_t)PN_B3_STREAM_CHUNKS * PN_B3_CHUNK * 256)
+
 // ---- AE decoder: inv_pool 16->256->1024->k*128 (AE.py:19-26) + inv_mlp 144->128->64->32->3 (AE.py:27)
 #define DEC_H_B1 0                             // [256]
 #define DEC_H_B2 (DEC_H_B1 + 256)              // [1024]

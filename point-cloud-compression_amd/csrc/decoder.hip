@@ -69,16 +69,17 @@ __device__ __forceinline__ void b3_split(float x, unsigned &h, unsigned &m, unsi
 // are k-slots 8*kg + j of the bf16 operand.  src index = outer*src_outer + ((2t + h)*W + j)*64 + lane,
 // dst index = outer*dst_outer + ((t*W + j)*3 + plane)*64 + lane (units: 16-byte vectors).
 __global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__ src, uint4 *__restrict__ dst, int n_outer, int KT16, int W,
-                                                       size_t src_outer, size_t dst_outer)
+                                                       size_t src_outer, size_t dst_outer, int src_w)
 {
+    // src_w: fragments per k-tile row of the SOURCE array (>= W: a column range of a wider layer can be taken)
     const int lane = threadIdx.x & 63, T = (KT16 + 1) / 2;     // an odd last k-tile pairs with zeros
     const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (size_t)n_outer * T * W) return;
     const int j = (int)(item % W), t = (int)((item / W) % T);
     const size_t o = item / ((size_t)W * T);
-    const f32x4 v0 = src[o * src_outer + ((size_t)(2 * t) * W + j) * 64 + lane];
+    const f32x4 v0 = src[o * src_outer + ((size_t)(2 * t) * src_w + j) * 64 + lane];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 v1 = 2 * t + 1 < KT16 ? src[o * src_outer + ((size_t)(2 * t + 1) * W + j) * 64 + lane] : zero;
+    const f32x4 v1 = 2 * t + 1 < KT16 ? src[o * src_outer + ((size_t)(2 * t + 1) * src_w + j) * 64 + lane] : zero;
     unsigned h[8], m[8], l[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { b3_split(v0[r], h[r], m[r], l[r]); b3_split(v1[r], h[4 + r], m[4 + r], l[4 + r]); }
@@ -86,46 +87,6 @@ __global__ __launch_bounds__(256) void b3_split_kernel(const f32x4 *__restrict__
     d[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
     d[64] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
     d[128] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-}
-
-// dense layer of the chain on bf16x3 operands: in[nt][kt][plane] are K=32 B operands, the weight blocks ([kt][mt][plane],
-// three 1 KiB A fragments each) come from the LDS ring in stream order; six products per block, two blocks in flight.
-template <int KT, int MT, int NT, class WS>
-__device__ __forceinline__ void dense_b3_stream(const WS &ws, int &f, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
-{
-    constexpr int MG = MT >= 2 ? 2 : 1;
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
-    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
-    constexpr int NG = KT * (MT / MG);
-    bf16x8 cur[MG][3], nxt[MG][3];
-#pragma unroll
-    for (int m = 0; m < MG; ++m)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) cur[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * m + p));
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
-        if (gi + 1 < NG) {
-#pragma unroll
-            for (int m = 0; m < MG; ++m)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) nxt[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * ((gi + 1) * MG + m) + p));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int m = 0; m < MG; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt][m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MG; ++m)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
-    }
-    f += 3 * KT * MT;
 }
 
 __device__ __forceinline__ uint4 b3_load_async(const uint4 *p)    // placed exactly here; completion is covered by the ring's s_waitcnt
@@ -444,7 +405,7 @@ extern "C" int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *
         const int T = (KT16[l] + 1) / 2;
         const size_t items = (size_t)k * T * MTL[l];
         hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, src + s_off * 64,
-                           (uint4 *)b3_blob_dev + d_off * 64, k, KT16[l], MTL[l], so, dst_o);
+                           (uint4 *)b3_blob_dev + d_off * 64, k, KT16[l], MTL[l], so, dst_o, MTL[l]);
         PCCX_CHECK_LAUNCH();
         s_off += (size_t)KT16[l] * MTL[l];
         d_off += (size_t)T * MTL[l] * 3;
@@ -460,11 +421,40 @@ extern "C" int pccx_pack_sa_b3(const float *enc_blob_dev, float *sa_b3_blob_dev,
     PCCX_CHECK_ARG(enc_blob_dev && sa_b3_blob_dev, "pccx_pack_sa_b3: null pointer");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(b3_split_kernel, dim3((1 * 4 + 3) / 4), dim3(256), 0, st, (const f32x4 *)(enc_blob_dev + ENC_SA_W1),
-                       (uint4 *)sa_b3_blob_dev, 1, 2, 4, (size_t)0, (size_t)0);
+                       (uint4 *)sa_b3_blob_dev, 1, 2, 4, (size_t)0, (size_t)0, 4);
     PCCX_CHECK_LAUNCH();
     hipLaunchKernelGGL(b3_split_kernel, dim3((2 * 8 + 3) / 4), dim3(256), 0, st, (const f32x4 *)(enc_blob_dev + ENC_SA_W2),
-                       (uint4 *)sa_b3_blob_dev + 12 * 64, 1, 4, 8, (size_t)0, (size_t)0);
+                       (uint4 *)sa_b3_blob_dev + 12 * 64, 1, 4, 8, (size_t)0, (size_t)0, 8);
     PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// PointNet weight stream (encoder.hip: pn_forward_b3_kernel): the four layers' [kt16][mt] fp32 fragments -> [kt32][mt][plane]
+extern "C" size_t pccx_pn_b3_blob_floats(void) { return PN_B3_BLOB_FLOATS; }
+
+extern "C" int pccx_pack_pn_b3(const float *enc_blob_dev, float *pn_b3_blob_dev, void *stream)
+{
+    PCCX_CHECK_ARG(enc_blob_dev && pn_b3_blob_dev, "pccx_pack_pn_b3: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    PCCX_CHECK_HIP(hipMemsetAsync(pn_b3_blob_dev, 0, sizeof(float) * PN_B3_BLOB_FLOATS, st));
+    // stream order: L0 [5][8], L1 [4][16], then for each half h of layer 2's output tiles: L2 [8][16 tiles 16h..] and the
+    // eight k-steps 8h.. of layer 3 that consume them
+    struct Seg { size_t src; int kt16, w, src_w; };
+    const Seg segs[6] = {{ENC_PN_W0, 9, 8, 8},
+                         {ENC_PN_W1, 8, 16, 16},
+                         {ENC_PN_W2, 16, 16, 32},
+                         {ENC_PN_W3, 16, 1, 1},
+                         {ENC_PN_W2 + (size_t)16 * 256, 16, 16, 32},
+                         {ENC_PN_W3 + (size_t)16 * 256, 16, 1, 1}};
+    size_t d_off = 0;
+    for (int l = 0; l < 6; ++l) {
+        const int T = (segs[l].kt16 + 1) / 2;
+        const size_t items = (size_t)T * segs[l].w;
+        hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)(enc_blob_dev + segs[l].src),
+                           (uint4 *)pn_b3_blob_dev + d_off * 64, 1, segs[l].kt16, segs[l].w, (size_t)0, (size_t)0, segs[l].src_w);
+        PCCX_CHECK_LAUNCH();
+        d_off += (size_t)T * segs[l].w * 3;
+    }
     return PCCX_OK;
 }
 
@@ -492,7 +482,7 @@ extern "C" int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, con
     PCCX_CHECK_LAUNCH();
     const size_t items = (size_t)32 * ntiles;
     hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)h2p, h3, 1, 64, ntiles,
-                       (size_t)0, (size_t)0);
+                       (size_t)0, (size_t)0, ntiles);
     PCCX_CHECK_LAUNCH();
     hipLaunchKernelGGL(dec_main_kernel<true>, dim3(dec_grid(ntiles, k)), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
                        ntiles, dec_blob, b3_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,

@@ -296,6 +296,109 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// EXPERIMENTAL (opt-in): PointNet + quantiser on bf16x3 operands.  Workgroup = one patch, EIGHT
+// waves, ONE 16-point tile per wave per pass (the bf16 planes of two tiles of the 256-channel activation do not fit the
+// register file), so the weight stream is shared by 128 points per pass as in the fp32 kernel.  Layer 2 runs k-outer in
+// two halves of 16 output tiles (64 accumulator VGPRs): each pair of input tiles is split into its three planes once per
+// half, and layer 3 consumes the half's accumulators pair by pair.  Epilogue as pn_forward_kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void pn_forward_b3_kernel(const float *__restrict__ x, const float *__restrict__ feat, int K,
+                                                               const float *__restrict__ blob, const float *__restrict__ blob3, int d,
+                                                               float spread, float half_spread, float *__restrict__ latent_raw,
+                                                               float *__restrict__ latent, float *__restrict__ latent_q)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * PN_B3_CHUNK * 64];   // 48 KiB weight ring
+    __shared__ float smax[8][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const size_t P = blockIdx.x;
+    const float *xp = x + P * (size_t)K * 3;
+    const int ntiles = K >> 4;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    WStreamT<PN_B3_CHUNK, 2, 8> ws{blob3, swt, PN_B3_STREAM_CHUNKS, lane, wu, true};
+    ws.prologue();
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 run;                                            // running max, channel 4g+r
+    run[0] = run[1] = run[2] = run[3] = -INFINITY;
+    const int passes = (ntiles + 7) / 8;                  // identical for all waves: barriers inside
+    for (int it = 0; it < passes; ++it) {
+        const int tile = it * 8 + w;
+        const bool valid = tile < ntiles;
+        const int p = (valid ? tile : 0) * 16 + n;
+        blob = opaque_uniform(blob);                      // keep bias and DMA addressing inside the pass (no LICM)
+        ws.g = opaque_uniform(blob3);
+        int f = 0;                                        // fragment cursor of this pass (constant-folds)
+        f32x4 a0[1][8];
+        {
+            f32x4 in[9];
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) in[kt] = *(const f32x4 *)(feat + ((P * 8 + kt) * (size_t)K + p) * 16 + 4 * g);
+            in[8][0] = g == 0 ? xp[3 * p] : 0.f;          // channels 128,129,130 = x,y,z (g == 0, r = 0..2)
+            in[8][1] = g == 0 ? xp[3 * p + 1] : 0.f;
+            in[8][2] = g == 0 ? xp[3 * p + 2] : 0.f;
+            in[8][3] = 0.f;
+            bf16x8 i0[1][5][3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b3_split8(in[2 * t], in[2 * t + 1], i0[0][t]);
+            b3_split8(in[8], zero, i0[0][4]);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) a0[0][mt] = *(const f32x4 *)(blob + ENC_PN_B0 + 16 * mt + 4 * g);
+            dense_b3_stream<5, 8, 1>(ws, f, i0, a0);
+        }
+        f32x4 a1[1][16];
+        {
+            bf16x8 i1[1][4][3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b3_split8(relu4(a0[0][2 * t]), relu4(a0[0][2 * t + 1]), i1[0][t]);
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a1[0][mt] = *(const f32x4 *)(blob + ENC_PN_B1 + 16 * mt + 4 * g);
+            dense_b3_stream<4, 16, 1>(ws, f, i1, a1);
+        }
+        f32x4 a3[1][1];
+        a3[0][0] = *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
+#pragma clang loop unroll(full)
+        for (int h = 0; h < 2; ++h) {                     // layer 2 in two halves of 16 output tiles (64 accumulator VGPRs each)
+            f32x4 a2[1][16];
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a2[0][mt] = *(const f32x4 *)(blob + ENC_PN_B2 + 16 * (16 * h + mt) + 4 * g);
+#pragma clang loop unroll(full)
+            for (int kt = 0; kt < 8; ++kt) {              // k-outer: every input pair is split once per half
+                bf16x8 pl[1][1][3];
+                b3_split8(relu4(a1[0][2 * kt]), relu4(a1[0][2 * kt + 1]), pl[0][0]);
+                dense_b3_stream<1, 16, 1>(ws, f, pl, a2);
+            }
+#pragma clang loop unroll(full)
+            for (int kt = 0; kt < 8; ++kt) {              // layer 3 over these 256 channels (no ReLU after it, AE.py:17)
+                bf16x8 pl[1][1][3];
+                b3_split8(relu4(a2[0][2 * kt]), relu4(a2[0][2 * kt + 1]), pl[0][0]);
+                dense_b3_stream<1, 1, 1>(ws, f, pl, a3);
+            }
+        }
+        if ((PN_B3_STREAM_FRAGS + PN_B3_CHUNK - 1) / PN_B3_CHUNK < PN_B3_STREAM_CHUNKS)
+            ws.boundary(PN_B3_STREAM_CHUNKS - 1);          // padding chunk: keeps the ring parity; prefetches chunk 0
+        if (valid)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) run[r] = fmaxf(run[r], row16_max(a3[0][0][r]));
+    }
+    ws.drain();                                            // no DMA may land after the workgroup retires
+    if (n == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smax[w][4 * g + r] = run[r];
+    __syncthreads();
+    if (tid < 16 && tid < d) {
+        float m = smax[0][tid];
+#pragma unroll
+        for (int k8 = 1; k8 < 8; ++k8) m = fmaxf(m, smax[k8][tid]);                                    // torch.max(points, 2)
+        const float s = 1.0f / (1.0f + expf(-m));
+        const float y = __fsub_rn(__fmul_rn(s, spread), half_spread);
+        latent_raw[P * d + tid] = m;
+        latent[P * d + tid] = y;
+        latent_q[P * d + tid] = rintf(y);
+    }
+}
+
 static int launch_sa(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob, float *feat, hipStream_t st)
 {
     const bool b3 = sa_b3_blob != nullptr;
@@ -361,6 +464,22 @@ extern "C" int pccx_pn_forward(const float *patches, const float *feat, int P, i
     PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_pn_forward: unsupported d=%d L=%d", d, L);
     if (P == 0) return PCCX_OK;
     return launch_pn(patches, feat, P, K, enc_blob, d, L, latent_raw, latent, latent_q, (hipStream_t)stream);
+}
+
+// EXPERIMENTAL, opt-in: see pn_forward_b3_kernel
+extern "C" int pccx_pn_forward_b3(const float *patches, const float *feat, int P, int K, const float *enc_blob, const float *pn_b3_blob,
+                                  int d, int L, float *latent_raw, float *latent, float *latent_q, void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(patches && feat && enc_blob && pn_b3_blob && latent_raw && latent && latent_q, "pccx_pn_forward_b3: null pointer");
+    CHECK_PK("pccx_pn_forward_b3");
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_pn_forward_b3: unsupported d=%d L=%d", d, L);
+    const float spread = (float)((double)L - 0.2);
+    const float half = (float)(((double)L - 0.2) / 2);
+    hipLaunchKernelGGL(pn_forward_b3_kernel, dim3(P), dim3(512), 0, (hipStream_t)stream, patches, feat, K, enc_blob, pn_b3_blob, d, spread,
+                       half, latent_raw, latent, latent_q);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
 }
 
 extern "C" int pccx_ae_encode(const float *patches, int P, int K, const float *enc_blob, int d, int L, float *feat_ws,

@@ -192,7 +192,7 @@ typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
 // NB buffers of CH fragments: the DMA of chunk c + NB - 1 is issued at the boundary of chunk c into the buffer chunk c - 1
 // has just vacated (NB = 2: one chunk ahead).
-template <int CH, int NB = 2>
+template <int CH, int NB = 2, int NW = 4>
 struct WStreamT {
     const float *g;                       // global stream, NCH * CH fragments, wave-uniform
     f32x4 *lds;                           // [NB][CH][64]
@@ -202,12 +202,13 @@ struct WStreamT {
 
     __device__ __forceinline__ void issue(int c, int buf) const
     {
-        // 4 waves x CH/4 fragments: wave w moves fragments (CH/4)w .. of the chunk.  Source address =
+        // NW waves x CH/NW fragments: wave w moves fragments (CH/NW)w .. of the chunk.  Source address =
         // wave-uniform fragment base (scalar registers) + lane*16 (one VGPR shared by every DMA).
+        static_assert(CH % NW == 0, "chunk must divide over the waves");
         const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
-        for (int q = 0; q < CH / 4; ++q) {
-            const int fr = wave * (CH / 4) + q;                // wave is scalar (readfirstlane)
+        for (int q = 0; q < CH / NW; ++q) {
+            const int fr = wave * (CH / NW) + q;               // wave is scalar (readfirstlane)
             const char *src = (const char *)g + ((size_t)c * CH + fr) * 1024;
             f32x4 *dst = lds + (buf * CH + fr) * 64;          // wave-uniform; hardware adds lane*16
             __builtin_amdgcn_global_load_lds((const void *)(src + voff), (lds_u32 *)(uintptr_t)dst, 16, 0, 0);
@@ -308,3 +309,44 @@ __device__ __forceinline__ float row16_max(float v)
     v = fmaxf(v, __int_as_float(t));
     return v;
 }
+
+// dense layer of the chain on bf16x3 operands: in[nt][kt][plane] are K=32 B operands, the weight blocks ([kt][mt][plane],
+// three 1 KiB A fragments each) come from the LDS ring in stream order; six products per block, two blocks in flight.
+template <int KT, int MT, int NT, class WS>
+__device__ __forceinline__ void dense_b3_stream(const WS &ws, int &f, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    bf16x8 cur[MG][3], nxt[MG][3];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * m + p));
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * ((gi + 1) * MG + m) + p));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
+    }
+    f += 3 * KT * MT;
+}
+

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "pccx_sa_b3_blob_floats": [],
     "pccx_pack_sa_b3": [_P, _P, _P],
     "pccx_sa_forward_b3": [_P, C.c_int, C.c_int, _P, _P, _P, _P],
+    "pccx_pn_b3_blob_floats": [],
+    "pccx_pack_pn_b3": [_P, _P, _P],
+    "pccx_pn_forward_b3": [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P],
     "pccx_dec_b3_blob_floats": [C.c_int],
     "pccx_pack_ae_decoder_b3": [_P, C.c_int, _P, _P],
     "pccx_ae_decode_b3_workspace_floats": [C.c_int],
@@ -74,7 +77,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
-             "pccx_packed_linear_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t,
+             "pccx_packed_linear_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t, "pccx_pn_b3_blob_floats": C.c_size_t,
              "pccx_ae_decode_b3_workspace_floats": C.c_size_t}
 
 _lib = None

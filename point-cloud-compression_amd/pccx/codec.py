@@ -52,10 +52,10 @@ class Compressed:
 
 class Codec:
     def __init__(self, ae, prob, K=256, ALPHA=2, N0=1024, octree_mode="reference", margin=0.01, decoder_matmul="f32",
-                 sa_matmul="f32"):
+                 sa_matmul="f32", pn_matmul="f32"):
         self.ae, self.prob = ae, prob
         self.decoder_matmul = decoder_matmul                 # "bf16x3": EXPERIMENTAL opt-in (models.AE.decode)
-        self.sa_matmul = sa_matmul                           # "bf16x3": EXPERIMENTAL opt-in (models.AE.encode)
+        self.sa_matmul, self.pn_matmul = sa_matmul, pn_matmul  # "bf16x3": EXPERIMENTAL opt-in (models.AE.encode)
         self.K, self.ALPHA, self.N0 = K, ALPHA, N0
         self.k = K // ALPHA                                  # compress.py:46
         self.octree_mode = octree_mode
@@ -86,7 +86,7 @@ class Codec:
         with stage("knn_patches"):
             nn = ops.knn_points(rec, pcn, self.K, patch_scale=scale)                 # compress.py:105-108
         patches = nn.knn.view(B * S, self.K, 3)
-        raw, latent, q = self.ae.encode(patches, sa_matmul=self.sa_matmul)                                     # compress.py:113-127
+        raw, latent, q = self.ae.encode(patches, sa_matmul=self.sa_matmul, pn_matmul=self.pn_matmul)                                     # compress.py:113-127
         with stage("prob"):
             cdf_int = self.prob.run(rec, ("cdf_int",))["cdf_int"]                    # compress.py:131-134
         with stage("range_encode"):

@@ -116,7 +116,7 @@ class AE(nn.Module):
                      w("inv_mlp.mlp_Modules.2.0.weight"), sd["inv_mlp.mlp_Modules.2.0.bias"],
                      w("inv_mlp.mlp_Modules.3.0.weight"), sd["inv_mlp.mlp_Modules.3.0.bias"]], [self.k, self.d])
         self._enc_blob, self._dec_blob = enc.to(device), dec.to(device)
-        self._dec_b3 = self._sa_b3 = None
+        self._dec_b3 = self._sa_b3 = self._pn_b3 = None
         return self
 
     def _blobs(self, device):
@@ -132,10 +132,18 @@ class AE(nn.Module):
             _lib.call("pccx_pack_sa_b3", enc.data_ptr(), self._sa_b3.data_ptr(), _stream())
         return self._sa_b3
 
-    def encode(self, patches, sa_matmul="f32"):
+    def _pn_b3_blob(self, device):
+        """EXPERIMENTAL: bf16x3 planes of the PointNet weight stream, built on the device."""
+        enc, _ = self._blobs(device)
+        if getattr(self, "_pn_b3", None) is None or self._pn_b3.device != enc.device:
+            self._pn_b3 = torch.empty(_lib.load().pccx_pn_b3_blob_floats(), device=enc.device, dtype=torch.float32)
+            _lib.call("pccx_pack_pn_b3", enc.data_ptr(), self._pn_b3.data_ptr(), _stream())
+        return self._pn_b3
+
+    def encode(self, patches, sa_matmul="f32", pn_matmul="f32"):
         """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
         = ae.sa + ae.pn + sigmoid spread + round (compress.py:113-127, AE.py:37-45).
-        sa_matmul="bf16x3" (EXPERIMENTAL, opt-in): SetAbstraction conv1 / conv2 as fp32 products of three bf16 pieces per
+        sa_matmul / pn_matmul = "bf16x3" (EXPERIMENTAL, opt-in): SetAbstraction conv1 / conv2, the PointNet chain as fp32 products of three bf16 pieces per
         operand on the bf16 matrix cores (fp32-level error; a latent within ~1e-6 of a rounding boundary may flip)."""
         x = _f32c(patches, "AE.encode")
         P, K, _ = x.shape
@@ -151,8 +159,14 @@ class AE(nn.Module):
             else:
                 raise ValueError(f"sa_matmul={sa_matmul!r}: expected 'f32' or 'bf16x3'")
         with stage("pn_forward"):
-            _lib.call("pccx_pn_forward", x.data_ptr(), ws.data_ptr(), P, K, enc.data_ptr(), self.d, self.L,
-                      outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+            if pn_matmul == "bf16x3":
+                _lib.call("pccx_pn_forward_b3", x.data_ptr(), ws.data_ptr(), P, K, enc.data_ptr(), self._pn_b3_blob(x.device).data_ptr(),
+                          self.d, self.L, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+            elif pn_matmul == "f32":
+                _lib.call("pccx_pn_forward", x.data_ptr(), ws.data_ptr(), P, K, enc.data_ptr(), self.d, self.L,
+                          outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+            else:
+                raise ValueError(f"pn_matmul={pn_matmul!r}: expected 'f32' or 'bf16x3'")
         return tuple(outs)
 
     def _b3_blob(self, device):
