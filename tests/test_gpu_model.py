@@ -341,3 +341,22 @@ def test_pointnet_bf16x3_experimental_matches_fp32_path(nets):
     # all three experimental stages together
     raw2, lat2, q2 = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3")
     assert np.abs(lat0.cpu().numpy() - lat2.cpu().numpy()).max() <= 5e-6
+
+
+@pytest.mark.parametrize("Kx,kx,P", [(64, 32, 5), (512, 256, 3), (16, 8, 2)])
+def test_bf16x3_experimental_other_patch_sizes(Kx, kx, P):
+    """The experimental bf16x3 kernels at other patch sizes (K = 16: one tile, seven of PointNet's eight waves idle;
+    K = 512: four passes; other k for the decoder's per-point streams): same agreement with the exact-fp32 kernels."""
+    ae = models.AE(Kx, kx, d, L)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    ae.pack("cuda")
+    rng = np.random.default_rng(Kx + P)
+    x = torch.from_numpy((rng.random((P, Kx, 3)).astype(np.float32) - 0.5)).cuda()
+    raw0, lat0, q0 = ae.encode(x)
+    raw1, lat1, q1 = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3")
+    assert np.abs(raw0.cpu().numpy() - raw1.cpu().numpy()).max() <= 2e-5 * max(1.0, float(raw0.abs().max()))
+    assert np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max() <= 5e-6
+    _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
+    a = ae.decode(q0).cpu().numpy()
+    b = ae.decode(q0, matmul="bf16x3").cpu().numpy()
+    assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max())
