@@ -10,6 +10,7 @@
 //                     accumulators feed inv_mlp directly from registers (n index = patch).  The
 //                     (BS,16384) activation of the reference never exists in memory.
 // MFMA-bound; weights (64 MiB) and activations stream from L2 / Infinity Cache as 1 KiB fragments.
+// dec_main_kernel<true> is the EXPERIMENTAL, opt-in bf16x3 variant; <false> is the product.
 #include <math.h>
 
 #include "blobs.h"

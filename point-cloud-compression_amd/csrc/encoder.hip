@@ -8,6 +8,9 @@
 // workgroup per patch.  The GEMM-shaped layers run on the fp32 matrix cores
 // (v_mfma_f32_16x16x4_f32, exact fp32) as register-resident chains (mfma_chain.h).
 // MFMA-bound: 5.42 GFLOP (SA) + 6.19 GFLOP (PointNet) per 8192-point cloud.
+//
+// sa_forward_kernel<true> and pn_forward_b3_kernel are EXPERIMENTAL, opt-in variants that form the
+// same fp32 products from three bf16 pieces per operand on the bf16 matrix cores; the exact-fp32 kernels are the product.
 #include <math.h>
 
 #include "blobs.h"
