@@ -94,4 +94,10 @@
 #define PRB_M_W0 (PRB_P_W2 + 8 * 16 * 256)     // KT=17 (256 features, then xyz), MT=32
 #define PRB_M_W1 (PRB_M_W0 + 17 * 32 * 256)    // KT=32, MT=32
 #define PRB_M_W2 (PRB_M_W1 + 32 * 32 * 256)    // KT=32, MT=8
-#define PRB_BLOB_FLOATS (PRB_M_W2 + 32 * 8 * 256)
+// model_mlp fragments again, in the order prob_forward_kernel consumes them (LDS ring, mfma_chain.h: WStreamT<8, 4>):
+// W0 [17 kt][32 mt], then for each pair of layer-1 output tiles mp: W1 [32 kt][2mp..2mp+1] and W2 k-tiles 2mp, 2mp+1 [8 mt].
+#define PRB_WS_CHUNK 8
+#define PRB_STREAM (PRB_M_W2 + 32 * 8 * 256)
+#define PRB_STREAM_FRAGS (17 * 32 + 16 * (32 * 2 + 2 * 8))
+#define PRB_STREAM_CHUNKS (4 * ((PRB_STREAM_FRAGS + 4 * PRB_WS_CHUNK - 1) / (4 * PRB_WS_CHUNK)))      // multiple of the ring depth
+#define PRB_BLOB_FLOATS (PRB_STREAM + (size_t)PRB_STREAM_CHUNKS * PRB_WS_CHUNK * 256)

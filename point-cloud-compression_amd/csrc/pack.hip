@@ -161,5 +161,19 @@ extern "C" int pccx_pack_prob(const float *p_w0, const float *p_b0, const float 
                [](int ch) -> long { return ch < 256 ? 3 + ch : (ch < 259 ? ch - 256 : -1); });
     pack_dense(m_w1, 512, 32, 32, blob + PRB_M_W1, Ident{512}, Ident{512});
     pack_dense(m_w2, 512, 32, 8, blob + PRB_M_W2, Ident{d * L}, Ident{512});
+    {   // consumption-order stream of model_mlp for the LDS ring
+        float *st = blob + PRB_STREAM;
+        int f = 0;
+        auto put = [&](size_t base, int MT, int kt, int mt) {
+            memcpy(st + (size_t)f * 256, blob + base + ((size_t)kt * MT + mt) * 256, 256 * sizeof(float));
+            ++f;
+        };
+        for (int kt = 0; kt < 17; ++kt) for (int mt = 0; mt < 32; ++mt) put(PRB_M_W0, 32, kt, mt);
+        for (int mp = 0; mp < 16; ++mp) {
+            for (int kt = 0; kt < 32; ++kt) for (int m = 0; m < 2; ++m) put(PRB_M_W1, 32, kt, 2 * mp + m);
+            for (int k2 = 0; k2 < 2; ++k2) for (int mt = 0; mt < 8; ++mt) put(PRB_M_W2, 8, 2 * mp + k2, mt);
+        }
+        if (f != PRB_STREAM_FRAGS) { pccx_set_error("pccx_pack_prob: stream has %d fragments", f); return PCCX_ERR_ARG; }
+    }
     return PCCX_OK;
 }

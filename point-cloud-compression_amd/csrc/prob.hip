@@ -13,10 +13,11 @@
 #include "common.h"
 #include "mfma_chain.h"
 
-__global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__restrict__ centres, int S, int d, int L,
+__global__ __launch_bounds__(256, 2) void prob_forward_kernel(const float *__restrict__ centres, int S, int d, int L,
                                                               const float *__restrict__ blob, float *__restrict__ pmf,
                                                               float *__restrict__ cdf, int32_t *__restrict__ cdf_int)
 {
+    __shared__ __attribute__((aligned(16))) f32x4 swt[4 * PRB_WS_CHUNK * 64];   // 32 KiB weight ring, four chunks deep
     __shared__ __attribute__((aligned(16))) float sfeat[256];
     __shared__ float smax[4][256];
     __shared__ __attribute__((aligned(16))) float slog[4][16][128];
@@ -25,6 +26,9 @@ __global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__res
     const size_t b = blockIdx.x;
     const float *cp = centres + b * (size_t)S * 3;
     const int ntiles = S >> 4;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    WStreamT<PRB_WS_CHUNK, 4, 4> ws{blob + PRB_STREAM, swt, PRB_STREAM_CHUNKS, lane, wu, true};
+    ws.prologue();                                        // the first chunks of model_mlp arrive while model_pn runs
 
     // ---- pass 1: model_pn (AE.py:96,112)
     f32x4 run[16];
@@ -72,13 +76,17 @@ __global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__res
     const int Lp = L + 1;
     for (int tile0 = 0; tile0 < ntiles; tile0 += 4) {
         const int tile = tile0 + w;
-        if (tile < ntiles) {
+        {
+            // All four waves walk the same weight sequence on their own tile (an idle wave of the last round walks it on a
+            // clamped tile and discards the result: the ring's barriers need every wave), streamed L2 -> LDS three chunks ahead.
             const float *bl = opaque_uniform(blob);
-            const int c = tile * 16 + n;
+            ws.g = bl + PRB_STREAM;
+            const int c = (tile < ntiles ? tile : ntiles - 1) * 16 + n;
+            int f = 0;
             f32x4 a0[1][32];
 #pragma unroll
             for (int mt = 0; mt < 32; ++mt) a0[0][mt] = *(const f32x4 *)(bl + PRB_M_B0 + 16 * mt + 4 * g);
-#pragma unroll 1
+#pragma unroll
             for (int kt = 0; kt < 17; ++kt) {
                 f32x4 in[1][1];
                 if (kt < 16) {
@@ -89,25 +97,26 @@ __global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__res
                     in[0][0][2] = g == 0 ? cp[3 * c + 2] : 0.f;
                     in[0][0][3] = 0.f;
                 }
-                dense_acc<1, 32, 1, 32>(opaque_uniform((const f32x4 *)(bl + PRB_M_W0)) + (size_t)kt * 32 * 64, lane, in, a0);
+                dense_acc_stream<1, 32, 1>(ws, f, in, a0);
             }
 #pragma unroll
             for (int mt = 0; mt < 32; ++mt) a0[0][mt] = relu4(a0[0][mt]);
             f32x4 a2[1][8];
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) a2[0][mt] = *(const f32x4 *)(bl + PRB_M_B2 + 16 * mt + 4 * g);
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int mp = 0; mp < 16; ++mp) {
                 f32x4 a1[1][2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) a1[0][m] = *(const f32x4 *)(bl + PRB_M_B1 + 16 * (2 * mp + m) + 4 * g);
-                dense_acc<32, 2, 1, 32>((const f32x4 *)(bl + PRB_M_W1), lane, a0, a1, 0, 2 * mp);
+                dense_acc_stream<32, 2, 1>(ws, f, a0, a1);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) a1[0][m] = relu4(a1[0][m]);
-                dense_acc<2, 8, 1, 8>((const f32x4 *)(bl + PRB_M_W2), lane, a1, a2, 2 * mp, 0);
+                dense_acc_stream<2, 8, 1>(ws, f, a1, a2);
             }
+            if (tile < ntiles)
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) *(f32x4 *)(&slog[w][n][16 * mt + 4 * g]) = a2[0][mt];
+                for (int mt = 0; mt < 8; ++mt) *(f32x4 *)(&slog[w][n][16 * mt + 4 * g]) = a2[0][mt];
         }
         __syncthreads();
         // one thread per (centre, latent dim): the wave's own tile, 16 centres x 16 dims
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void prob_forward_kernel(const float *__res
         }
         __syncthreads();
     }
+    ws.drain();                                           // no DMA may land after the workgroup retires
 }
 
 extern "C" int pccx_prob_forward(const float *centres, int B, int S, int d, int L, const float *prob_blob, float *pmf,
