@@ -3,15 +3,26 @@
 
 A "step" is one pass of the hot path over one batch of synthetic clouds: the loop bodies of
 compress.py:90-152 and decompress.py:80-116 for ``--batch`` clouds of 8192 points (IPDAE K=256,
-configs[1]), inputs already resident in HBM when the timed region starts.  Multi-GPU: clouds are
-sharded by file across ranks (one process per GPU, no data-path collective; the only collective
-is the MAX of the wall time), so scaling is weak.
+configs[1]).  Multi-GPU: clouds are sharded by file across ranks (one process per GPU, no data-path
+collective; the collectives are the MAX of the wall time and one all-gather of a six-number summary per
+rank), so scaling is weak.  ``python bench.py --gpus N`` without a torchrun environment starts the N rank
+processes itself (pccx/launch.py) before anything touches a GPU.
+
+The timed WINDOW is the reference's (``"window": "host-to-host"``): compress starts with the cloud in device
+memory (compress.py:82-85 moves it before start_time) and ends with the bytes of the three files on the host
+(compress.py:139-152); decompress starts from those host bytes (decompress.py:77-82) and ends with the
+reconstructed XYZ on the host (decompress.py:110-116).  Copies run on the step's own stream into pinned
+double buffers while the other stream computes the next step.  The HBM-resident rate (no copies) is reported
+beside it as ``value_resident``; its single-stream leg is also where the per-stage HIP-event times and the
+roofline of the dominant kernel are taken (events on overlapped streams would time each other's kernels).
 
 Prints ONE JSON line on rank 0.  Besides the driver's contract it carries
-  roofline     -- the dominant kernel: algorithmic FLOPs per launch / its HIP-event duration,
-                  against the fp32 matrix-core peak (MI355X_MICROARCH.md: 157.3 TFLOP/s);
-  cpu_baseline -- the CPU restatement of the reference loop (oracle/ref_pipeline.py), timed on
-                  this node's host cores on a bounded sample, rank 0 at N=1 only.
+  roofline     -- the dominant kernel: algorithmic FLOPs per launch / its HIP-event duration against the
+                  matrix-core peak of the arithmetic used (MI355X_MICROARCH.md: fp32 matrix 157.3 TFLOP/s;
+                  bf16 dense 16x that, / 6 products for the three-way split = 419.5 fp32-equivalent);
+  f32          -- the same step with every product formed by the exact-fp32 MFMA (its own value + roofline);
+  cpu_baseline -- the CPU restatement of the reference loop (oracle/ref_pipeline.py), timed on this node's host
+                  cores on a bounded sample, with its bpp / D1-PSNR and a 1-thread figure, rank 0 at N=1 only.
 """
 import argparse
 import json
@@ -23,38 +34,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "point-cloud-compression_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 N_POINTS, K_PATCH, ALPHA, N0, D_LAT, L_LEV = 8192, 256, 2, 1024, 16, 7
 S_PATCH = N_POINTS * ALPHA // K_PATCH
 AE_SEED, PROB_SEED = 11, 12
 AE_LAST_GAIN = {"pn.mlp_Modules.3.0": 40.0}
 PROB_GAIN = 2.0
-F32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F32_MATRIX_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_DENSE_PEAK_TFLOPS = 16 * F32_MATRIX_PEAK_TFLOPS  # same table: the f32 MFMA runs at 1/16 of BF16 (~2.5 PF dense)
+B3_PRODUCTS = 6                                     # bf16 MFMA products per fp32 product in the three-way split
 
 # algorithmic FLOPs per PATCH (2*MACs), from the layer shapes of AE.py:16-27
 FLOP_SA = K_PATCH * 16 * (3 * 32 + 32 * 64 + 64 * 128) * 2
 FLOP_PN = K_PATCH * (131 * 128 + 128 * 256 + 256 * 512 + 512 * D_LAT) * 2
 K_SMALL = K_PATCH // ALPHA
 FLOP_DEC = (D_LAT * 256 + 256 * 1024 + 1024 * K_SMALL * 128) * 2 + K_SMALL * (144 * 128 + 128 * 64 + 64 * 32 + 32 * 3) * 2
-STAGE_FLOP = {"sa_forward": FLOP_SA, "pn_forward": FLOP_PN, "ae_decode": FLOP_DEC}
-STAGE_KERNEL = {"sa_forward": "sa_forward_kernel", "pn_forward": "pn_forward_kernel", "ae_decode": "dec_main_kernel"}
+STAGE_FLOP = {"sa_forward": FLOP_SA, "pn_forward": FLOP_PN, "ae_decode": FLOP_DEC, "sa_pn_forward": FLOP_SA + FLOP_PN}
+STAGE_KERNEL = {"sa_forward": "sa_forward_kernel", "pn_forward": "pn_forward_kernel", "ae_decode": "dec_main_kernel",
+                "sa_pn_forward": "sa_pn_forward_kernel"}
 
 
-def measured_traffic(stage, batch):
-    """HBM bytes per launch of the stage's kernel from the committed PMC passes (profiles/round1_traffic.json,
-    collected at --batch 256 with rocprofv3 --pmc in separate runs); None when not applicable."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))["kernels"][STAGE_KERNEL[stage]]
-        return int(t["hbm_bytes_per_launch"] * batch / 256)
-    except (OSError, KeyError, ValueError):
-        return None
+def committed_traffic(stage, batch):
+    """HBM bytes per launch of the stage's kernel, NOT measured in this run: read from the newest committed rocprofv3
+    --pmc pass (profiles/round*_traffic.json, separate passes, gfx950 corrections applied) and scaled linearly from the
+    batch that pass ran at.  Returns (bytes or None, source)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            t = j["kernels"][STAGE_KERNEL[stage]]
+            return int(t["hbm_bytes_per_launch"] * batch / j.get("batch", 256)), "scaled from committed PMC pass " + os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def seeded_state_dict(module, seed, gain=1.0, last_gain=None):
     """Same deterministic fill as oracle.ref_model.seeded_state_dict (kept local: the product side
     of bench.py must not import the oracle)."""
+    import numpy as np
+    import torch
     rng = np.random.default_rng(seed)
     sd = {}
     cur = module.state_dict()
@@ -95,32 +113,346 @@ def host_cores():
 
 
 def cpu_baseline(max_clouds, budget_s):
-    """Reference-structured CPU loop (oracle) on a bounded sample of the same workload."""
+    """Reference-structured CPU loop (oracle) on a bounded sample of the same workload: all host cores for ~2/3 of the
+    budget (the reported value, with bpp and D1-PSNR of those clouds), then one thread for the rest."""
+    import numpy as np
+    import torch
     from oracle import ref_model, ref_pipeline
     from pccx import synth
-    torch.set_num_threads(host_cores())
     ae = ref_model.AE(K_PATCH, K_SMALL, D_LAT, L_LEV).eval()
     ae.load_state_dict(ref_model.seeded_state_dict(ae, AE_SEED, last_gain=AE_LAST_GAIN))
     prob = ref_model.ConditionalProbabilityModel(L_LEV, D_LAT).eval()
     prob.load_state_dict(ref_model.seeded_state_dict(prob, PROB_SEED, gain=PROB_GAIN))
-    ref_pipeline.compress_one(synth.cad_cloud(11, N_POINTS), ae, prob, 0)          # warm-up, discarded
-    tot, n, t_start = 0.0, 0, time.time()
-    while n < max_clouds and (n < 4 or time.time() - t_start < budget_s):
-        pc = synth.cad_cloud(11 + n, N_POINTS)
-        o, tc = ref_pipeline.compress_one(pc, ae, prob, (n * 97) % N_POINTS)
-        _, td = ref_pipeline.decompress_one(o["s"], o["p"], o["c"], ae, prob)
-        tot += tc + td
-        n += 1
-    return {"value": n * N_POINTS / tot, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} synthetic 8192-pt clouds, compress+decompress windows of compress.py:85-154 / "
-                      f"decompress.py:77-118, CPU restatement of the reference loop (torch CPU fp32 + C oracle)",
-            "ms_per_cloud": 1e3 * tot / n}
+
+    def leg(threads, max_n, min_n, budget):
+        torch.set_num_threads(threads)
+        ref_pipeline.compress_one(synth.cad_cloud(11, N_POINTS), ae, prob, 0)          # warm-up, discarded
+        tot, n, bits, psnr, t_start = 0.0, 0, 0, 0.0, time.time()
+        while n < max_n and (n < min_n or time.time() - t_start < budget):
+            pc = synth.cad_cloud(11 + n, N_POINTS)
+            o, tc = ref_pipeline.compress_one(pc, ae, prob, (n * 97) % N_POINTS)
+            rec, td = ref_pipeline.decompress_one(o["s"], o["p"], o["c"], ae, prob)
+            tot += tc + td
+            bits += 8 * (len(o["s"]) + len(o["p"]) + len(o["c"]))                      # eval.py:189
+            psnr += ref_pipeline.d1_psnr(pc, rec)                                      # outside the timed windows
+            n += 1
+        return n, tot, bits / (n * N_POINTS), psnr / n
+
+    cores = host_cores()
+    n, tot, bpp, psnr = leg(cores, max_clouds, 4, budget_s * 2 / 3)
+    n1, tot1, _, _ = leg(1, max(2, max_clouds // 4), 2, budget_s / 3)
+    return {"value": n * N_POINTS / tot, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 8192-pt clouds (the first {n} of the GPU leg's seeds), compress+decompress windows of "
+                      f"compress.py:85-154 / decompress.py:77-118, CPU restatement of the reference loop (torch CPU fp32 + C oracle)",
+            "ms_per_cloud": 1e3 * tot / n, "bpp": bpp, "d1_psnr_db": psnr,
+            "one_thread": {"value": n1 * N_POINTS / tot1, "unit": "points/s", "cores": 1, "sample": f"{n1} clouds", "ms_per_cloud": 1e3 * tot1 / n1}}
 
 
-def bench_pppe_train(args, world, rank, dev, cdev):
-    """Secondary workload: one optimisation step of the pppe fast path per "step" (forward in train mode,
-    Chamfer rate-distortion loss as the script builds it, backward, clip, Adam; data-parallel gradient all-reduce when N > 1)."""
-    import torch.distributed as dist
+# =====================================================================================================================
+# distributed plumbing
+# =====================================================================================================================
+class Ranks:
+    def __init__(self, args):
+        import torch
+        from pccx import launch
+        self.rank, self.local, self.world = launch.rank_env()
+        self.backend = args.dist_backend
+        if self.backend == "gloo":
+            self.local = self.local % max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
+        self.gpu = args.workload != "launch-check"
+        if self.gpu:
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device("cuda", self.local)
+        else:
+            self.dev = torch.device("cpu")
+        self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where the tiny collectives live
+        if self.world > 1:
+            launch.init_process_group(self.backend, self.dev if self.backend == "nccl" else None)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max_seconds(self, dt):
+        from pccx import dist as pdist
+        return pdist.max_over_ranks(dt, self.cdev) if self.world > 1 else dt
+
+    def summaries(self, local_vec):
+        """RCCL all_gather of the dist.SUMMARY_FIELDS vector (bits, points, psnr_sum, chamfer_sum, files, seconds)."""
+        from pccx import dist as pdist
+        return pdist.reduce_summaries(pdist.gather_summaries(local_vec, self.cdev))
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def timed(rk, fn, steps, sync):
+    """EXACTLY ``steps`` calls of fn between barrier + synchronize on both sides; MAX over ranks."""
+    rk.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    sync()
+    rk.barrier()
+    return rk.max_seconds(time.perf_counter() - t0)
+
+
+# =====================================================================================================================
+# workloads
+# =====================================================================================================================
+def bench_launch_check(args, rk):
+    """No GPU: proves the self-launch (rank environment, rendezvous on 127.0.0.1, one JSON line from rank 0) and the
+    summary all-gather; used by tests/test_sharding_gloo.py on CPU."""
+    local = [1000.0 * (rk.rank + 1), 8192.0 * (rk.rank + 1), 30.0 + rk.rank, 1e-4 * (rk.rank + 1), float(rk.rank + 1), 0.5 + rk.rank]
+    dt = timed(rk, lambda i: None, args.steps, lambda: None)
+    s = rk.summaries(local)
+    if rk.rank == 0:
+        print(json.dumps({"metric": "launch-check", "value": float(s["files"]), "unit": "files", "n_gpus": rk.world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "launch-check (no GPU work)", "dist_backend": rk.backend}, "summary": s}), flush=True)
+
+
+def build_codec(rk, matmul, octree_mode):
+    from pccx import codec, models
+    ae = models.AE(K_PATCH, K_SMALL, D_LAT, L_LEV)
+    ae.load_state_dict(seeded_state_dict(ae, AE_SEED, last_gain=AE_LAST_GAIN))
+    prob = models.ConditionalProbabilityModel(L_LEV, D_LAT)
+    prob.load_state_dict(seeded_state_dict(prob, PROB_SEED, gain=PROB_GAIN))
+    ae.pack(rk.dev)
+    prob.pack(rk.dev)
+    return codec.Codec(ae, prob, K=K_PATCH, ALPHA=ALPHA, N0=N0, octree_mode=octree_mode, matmul=matmul), ae, prob
+
+
+def roofline_of(stages, steps, P, matmul, batch):
+    """Dominant transform kernel of a resident leg: algorithmic FLOPs per launch / mean HIP-event duration of its launches."""
+    per_step_ms = {k: v[0] * v[1] / steps for k, v in stages.items()}
+    dom = max((k for k in STAGE_FLOP if k in stages), key=lambda k: per_step_ms[k])
+    dur_ms = stages[dom][0]
+    achieved = STAGE_FLOP[dom] * P / (dur_ms * 1e-3) / 1e12
+    if matmul == "bf16x3":
+        peak = BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS
+        note = ("fp32-equivalent TFLOP/s: each fp32 product = %d bf16 MFMA products (three-way split), so peak = bf16 dense "
+                "%.0f / %d; the same fraction as real bf16 FLOP/s (%.0f) over %.0f" %
+                (B3_PRODUCTS, BF16_DENSE_PEAK_TFLOPS, B3_PRODUCTS, achieved * B3_PRODUCTS, BF16_DENSE_PEAK_TFLOPS))
+    else:
+        peak, note = F32_MATRIX_PEAK_TFLOPS, "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) against the fp32 matrix peak"
+    traffic, src = committed_traffic(dom, batch)
+    rf = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+          "traffic": traffic, "traffic_source": src, "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P,
+          "arithmetic": matmul, "note": note, "window": "resident leg (single stream; HIP events per stage)"}
+    tfl = {k: STAGE_FLOP[k] * P / (stages[k][0] * 1e-3) / 1e12 for k in STAGE_FLOP if k in stages}
+    return rf, per_step_ms, tfl
+
+
+def bench_ipdae(args, rk):
+    import numpy as np
+    import torch
+    from pccx import codec, ops, synth
+
+    dev, B = rk.dev, args.batch
+    # shard by file: global cloud i -> rank i % world (SURVEY 8e); 32 distinct shapes per rank, tiled to the batch
+    base = np.stack([synth.cad_cloud(11 + rk.rank + rk.world * i, N_POINTS) for i in range(min(B, 32))])
+    clouds = torch.from_numpy(np.concatenate([base] * ((B + base.shape[0] - 1) // base.shape[0]))[:B]).to(dev)
+    starts = torch.from_numpy((np.arange(B) * 97 + rk.rank) % N_POINTS).to(dev)
+    P = B * S_PATCH
+    sync = torch.cuda.synchronize
+    modes = [args.matmul] + [m for m in ("f32", "bf16x3") if m != args.matmul and not args.one_mode]
+    res_by_mode = {}
+    for mode in modes:
+        cd, _, _ = build_codec(rk, mode, args.octree_mode)
+        S = S_PATCH
+
+        # ---- resident leg: one stream, everything stays in HBM, per-stage events -------------------------------
+        def step_resident(i):
+            comp = cd.compress(clouds, starts)
+            return comp, cd.decompress(comp, S=S)
+        for _ in range(args.warmup):
+            comp, out = step_resident(0)
+        sync()
+        timer = ops.StageTimer()
+        ops.set_timer(timer)
+        keep = {}
+        dt_res = timed(rk, lambda i: keep.__setitem__("r", step_resident(i)), args.steps, sync)
+        ops.set_timer(None)
+        comp, out = keep["r"]
+        stages = {k: (ms / n, n) for k, (ms, n) in timer.totals_ms().items()}
+        r = {"dt_res": dt_res, "stages": stages, "bits": float(comp.bits().sum()), "psnr_sum": float(codec.d1_psnr(clouds, out).sum()),
+             "chamfer_sum": float(codec.normalized_chamfer(clouds, out).sum())}
+
+        # ---- host-to-host leg (the reference's window): two streams, pinned double buffers ---------------------
+        if mode == args.matmul:
+            probe = cd.compress(clouds[:1], starts[:1])
+            row = probe.packed.numel()                                            # bytes per cloud of the packed streams
+            s_stride, p_cap = probe.s_bytes.shape[1], probe.p_bytes.shape[1]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            pin_comp = [torch.empty(row * B, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            pin_out = [torch.empty(B, N_POINTS, 3, dtype=torch.float32).pin_memory() for _ in range(2)]
+
+            def step_host(i):
+                j = i % 2
+                with torch.cuda.stream(streams[j]):                               # slot j's buffers: stream order protects reuse
+                    c = cd.compress(clouds, starts)
+                    pin_comp[j].copy_(c.packed, non_blocking=True)                # the three files' bytes on the host (ONE D2H)
+                    up = pin_comp[j].to(dev, non_blocking=True)                   # decompress starts from the host bytes
+                    c2 = codec.Compressed.from_packed(up, B, s_stride, p_cap, N_POINTS)
+                    o = cd.decompress(c2, S=S)
+                    pin_out[j].copy_(o, non_blocking=True)                        # reconstructed XYZ on the host
+            for s_ in streams:
+                s_.wait_stream(torch.cuda.current_stream())
+            for i in range(max(args.warmup, 2)):
+                step_host(i)
+            sync()
+            r["dt_host"] = timed(rk, step_host, args.steps, sync)
+            last = (args.steps - 1) % 2
+            r["host_equals_resident"] = bool(torch.equal(pin_out[last], out.cpu()))
+            hc = codec.Compressed.from_packed(pin_comp[last], B, s_stride, p_cap, N_POINTS)
+            r["host_bytes_equal_resident"] = bool(torch.equal(hc.s_nbytes, comp.s_nbytes.cpu()) and torch.equal(hc.p_nbytes, comp.p_nbytes.cpu()))
+            r["d2h_bytes_per_step"] = row * B + B * N_POINTS * 12
+            del streams, pin_comp, pin_out
+        res_by_mode[mode] = r
+        del cd
+        torch.cuda.empty_cache()
+
+    main = res_by_mode[args.matmul]
+    pts = B * N_POINTS * args.steps
+    summ = rk.summaries([main["bits"], B * N_POINTS, main["psnr_sum"], main["chamfer_sum"], B, main["dt_host"]])
+    if rk.rank == 0:
+        rf, per_step_ms, tfl = roofline_of(main["stages"], args.steps, P, args.matmul, B)
+        dtype = "f32" if args.matmul == "f32" else "f32 (operands split into three bf16 pieces, six bf16-MFMA products per fp32 product, fp32 accumulate)"
+        res = {
+            "metric": "points/sec compress+decompress (ModelNet40-shaped 8192 K=256)",
+            "value": rk.world * pts / main["dt_host"], "unit": "points/s",
+            "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * main["dt_host"] / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "window": "host-to-host: cloud in HBM -> .s/.p/.c bytes on the host (compress.py:85-154) -> XYZ on the host "
+                      "(decompress.py:77-118); copies overlapped on two streams",
+            "value_resident": rk.world * pts / main["dt_res"], "ms_per_step_resident": 1e3 * main["dt_res"] / args.steps,
+            "host_window_checks": {k: main[k] for k in ("host_equals_resident", "host_bytes_equal_resident", "d2h_bytes_per_step")},
+            "config": {"workload": "IPDAE K=256 d=16 L=7, 8192-pt CAD-like synthetic clouds (configs[1])",
+                       "clouds_per_gpu_per_step": B, "distinct_clouds_per_gpu": int(base.shape[0]), "points_per_cloud": N_POINTS,
+                       "patches_per_cloud": S_PATCH, "octree_mode": args.octree_mode, "sharding": f"file-sharded x{rk.world}",
+                       "weights": "seeded random", "matmul": args.matmul},
+            "roofline": rf,
+            "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
+            "mfma_stage_tflops": tfl,
+            "bpp": summ["bpp"], "d1_psnr_db": summ["d1_psnr_db"], "chamfer": summ["chamfer"], "summary_files": summ["files"],
+        }
+        for mode, r in res_by_mode.items():
+            if mode == args.matmul:
+                continue
+            rf2, ps2, tfl2 = roofline_of(r["stages"], args.steps, P, mode, B)
+            res["f32" if mode == "f32" else mode] = {
+                "value_resident": rk.world * pts / r["dt_res"], "ms_per_step_resident": 1e3 * r["dt_res"] / args.steps,
+                "dtype": mode, "roofline": rf2, "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(ps2.items(), key=lambda kv: -kv[1])},
+                "bpp": r["bits"] / (B * N_POINTS), "d1_psnr_db": r["psnr_sum"] / B}
+        res["cpu_baseline"] = None
+        print("[bench] gpu legs done: %.3e points/s host-to-host (%.2f ms/step), %.3e resident; dominant %s %.1f TFLOP/s (%.2f of %s peak)" %
+              (res["value"], res["ms_per_step"], res["value_resident"], rf["kernel"], rf["achieved"], rf["frac"], args.matmul),
+              file=sys.stderr, flush=True)
+        if rk.world == 1 and args.cpu_clouds > 0:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.cpu_clouds, args.cpu_budget)
+                res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            except Exception as e:   # the GPU line must survive a broken host toolchain
+                res["cpu_baseline_error"] = repr(e)
+        print(json.dumps(res), flush=True)
+
+
+def bench_s3dis(args, rk):
+    """configs[3]: room-scale clouds (0.5-1 M points, synth.room_cloud(100+i)) cut into 8192-point Morton blocks that shard
+    across ranks like files (large.py); a step = compress + decompress of every block of every room owned by this rank,
+    reassembled with the inverse permutation.  Total work is fixed, so scaling is strong."""
+    import torch
+    from pccx import codec, large, synth
+    cd, _, _ = build_codec(rk, args.matmul, "reference")
+    rooms = [torch.from_numpy(synth.room_cloud(100 + i)).to(rk.dev) for i in range(args.rooms)]
+    n_pts = sum(int(r.shape[0]) for r in rooms)
+    keep = {}
+
+    def step(i):
+        bits = psnr = 0.0
+        for ri, pc in enumerate(rooms):
+            parts, nb, order, n_last = large.compress_large(cd, pc, seed=11, rank=rk.rank, world=rk.world, batch=args.batch)
+            out = large.decompress_large(cd, parts, nb, order, pc.shape[0])
+            keep[ri] = (parts, out, nb)
+    for _ in range(args.warmup):
+        step(0)
+    dt = timed(rk, step, args.steps, torch.cuda.synchronize)
+    bits = sum(float(c.bits().sum()) for parts, _, _ in keep.values() for _, c in parts)
+    # D1 per room needs the whole reconstruction; with world > 1 every rank holds its own blocks' rows only, so
+    # the PSNR here is the block-level mean over this rank's blocks (gathered as sums)
+    psnr_sum = blocks = 0.0
+    for ri, pc in enumerate(rooms):
+        parts, out, nb = keep[ri]
+        blk, order, _ = large.split_blocks(pc)
+        for ids, c in parts:
+            rec = cd.decompress(c)
+            psnr_sum += float(codec.d1_psnr(blk[ids], rec).sum())
+            blocks += len(ids)
+    summ = rk.summaries([bits, float(n_pts) / rk.world, psnr_sum, 0.0, blocks, dt])
+    if rk.rank == 0:
+        print(json.dumps({
+            "metric": "points/sec compress+decompress, room-scale clouds in 8192-pt Morton blocks", "value": n_pts * args.steps / dt,
+            "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split)",
+            "data": "synthetic", "window": "resident (block partition by torch.sort of Morton keys inside the step)",
+            "config": {"workload": f"S3DIS-like rooms (configs[3]): {args.rooms} rooms, {n_pts} points, IPDAE K=256 per 8192-pt block",
+                       "sharding": f"block-sharded x{rk.world}", "matmul": args.matmul},
+            "roofline": None, "cpu_baseline": None, "bpp": bits * rk.world / n_pts if rk.world == 1 else summ["bpp"],
+            "d1_psnr_db_blockwise": summ["d1_psnr_db"], "blocks": int(summ["files"])}), flush=True)
+
+
+def bench_pppf(args, rk):
+    """configs[2]: PPPF_AE (PointNet++ encoder + FoldingNet decoder, PPPF_AE.py:114-150) forward on K=512-point patches of
+    2048-pt clouds (S = N*ALPHA/K = 8 patches per cloud), the model call of the reference's patch loop."""
+    import numpy as np
+    import torch
+    from pccx import families, ops, synth
+    Kp, N = 512, 2048
+    S = N * ALPHA // Kp
+    model = families.PPPF_AE(K=Kp, k=Kp // ALPHA, d=16, L=7)
+    model.load_state_dict(seeded_state_dict(model, 21))
+    for k_, v in model.state_dict().items():
+        if k_.endswith("running_var"):
+            v.fill_(1.0)
+    model.pack(rk.dev)
+    B = args.batch
+    clouds = torch.from_numpy(np.stack([synth.cad_cloud(300 + rk.rank + rk.world * i, N) for i in range(min(B, 32))])).to(rk.dev)
+    clouds = clouds.repeat((B + clouds.shape[0] - 1) // clouds.shape[0], 1, 1)[:B].contiguous()
+    cent = ops.index_points(clouds, ops.farthest_point_sample_batch(clouds, S, torch.zeros(B, dtype=torch.int32)))
+    patches = ops.knn_points(cent, clouds, Kp, patch_scale=float((N / N0) ** (1 / 3))).knn.view(B * S, Kp, 3).contiguous()
+    keep = {}
+    for _ in range(args.warmup):
+        model(patches)
+    timer = ops.StageTimer()
+    dt = timed(rk, lambda i: keep.__setitem__("o", model(patches)), args.steps, torch.cuda.synchronize)
+    flop = families.pppf_flops_per_patch(model) if hasattr(families, "pppf_flops_per_patch") else None
+    if rk.rank == 0:
+        rf = None
+        if flop:
+            ach = flop * B * S * args.steps / dt / 1e12
+            rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": ach / F32_MATRIX_PEAK_TFLOPS, "traffic": None, "flop_per_patch": flop,
+                  "note": "whole-forward wall time, not a single kernel: layer-by-layer generic kernels (csrc/linear.hip)"}
+        print(json.dumps({
+            "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
+            "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud",
+                       "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
+            "roofline": rf, "cpu_baseline": None}), flush=True)
+
+
+def bench_pppe_train(args, rk):
+    """configs[4]: one optimisation step of the pppe fast path per "step" (forward in train mode, Chamfer rate-distortion
+    loss as the script builds it, backward, clip, Adam; data-parallel gradient all-reduce over RCCL when N > 1)."""
+    import numpy as np
+    import torch
     from pccx import families, synth, train
     Bt = 4                                                   # train_pppe_pcd_ae.py: batch_size 4
     model = families.PointCloudAE(64, 16, N_POINTS)
@@ -128,38 +460,33 @@ def bench_pppe_train(args, world, rank, dev, cdev):
     for k, v in model.state_dict().items():                  # sane BatchNorm statistics
         if k.endswith("running_var"):
             v.fill_(1.0)
-    model = model.to(dev)
+    model = model.to(rk.dev)
     opt = train.Adam(model.parameters(), lr=1e-3)
-    x = torch.from_numpy(np.stack([synth.cad_cloud(900 + rank * Bt + i, N_POINTS) for i in range(Bt)])).to(dev)
-    rng = np.random.default_rng(rank)
+    x = torch.from_numpy(np.stack([synth.cad_cloud(900 + rk.rank * Bt + i, N_POINTS) for i in range(Bt)])).to(rk.dev)
+    rng = np.random.default_rng(rk.rank)
     starts = [[rng.integers(0, N_POINTS, Bt), rng.integers(0, N_POINTS, Bt)], rng.integers(0, 512, Bt), rng.integers(0, 128, Bt)]
+    keep = {}
+    kw = dict(lam=1e-3, data_parallel=rk.world > 1)
+    if args.autocast:
+        kw["autocast"] = True
     for _ in range(args.warmup):
-        out = train.train_step(model, opt, x, starts, lam=1e-3, data_parallel=world > 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = train.train_step(model, opt, x, starts, lam=1e-3, data_parallel=world > 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    if rank == 0:
+        train.train_step(model, opt, x, starts, **kw)
+    dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), args.steps, torch.cuda.synchronize)
+    if rk.rank == 0:
+        flop = train.step_flops(model, Bt) if hasattr(train, "step_flops") else None
+        rf = None
+        if flop:
+            ach = flop * args.steps / dt / 1e12
+            rf = {"kernel": "training step (forward + backward GEMMs)", "bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": ach / F32_MATRIX_PEAK_TFLOPS, "traffic": None, "flop_per_step": flop,
+                  "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): small, launch-bound layers"}
         print(json.dumps({
-            "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": world * Bt * args.steps / dt,
-            "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU, fp32",
-                       "parallelism": f"dp{world}", "weights": "seeded random"},
-            "roofline": None, "cpu_baseline": None, "loss": out[0],
-            "note": "secondary, correctness-first path: unfused layers, weights re-packed every step"}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": rk.world * Bt * args.steps / dt,
+            "unit": "clouds/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if args.autocast else "f32", "data": "synthetic",
+            "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
+                       "parallelism": f"dp{rk.world}", "weights": "seeded random"},
+            "roofline": rf, "cpu_baseline": None, "loss": keep["o"][0]}), flush=True)
 
 
 def main():
@@ -169,139 +496,43 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="clouds per GPU per step")
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
-    ap.add_argument("--sa-matmul", default="f32", choices=["f32", "bf16x3"], help="EXPERIMENTAL, as --decoder-matmul, for SetAbstraction")
-    ap.add_argument("--pn-matmul", default="f32", choices=["f32", "bf16x3"], help="EXPERIMENTAL, as --decoder-matmul, for PointNet")
-    ap.add_argument("--decoder-matmul", default="f32", choices=["f32", "bf16x3"],
-                    help="bf16x3 = EXPERIMENTAL: the decoder's big Linear as fp32 products of three bf16 pieces per operand on the "
-                         "bf16 matrix cores (fp32-level error, not bit-identical); the default f32 is the measured configuration")
+    ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3"],
+                    help="how the three transforms form their fp32 products (pccx.DEFAULT_MATMUL when omitted); the other mode is "
+                         "measured beside it (resident leg) unless --one-mode")
+    ap.add_argument("--one-mode", action="store_true", help="skip the second arithmetic mode")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="max clouds in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
-    ap.add_argument("--workload", default="ipdae", choices=["ipdae", "pppe-train"],
-                    help="ipdae = the headline compress+decompress path (default); pppe-train = the training step of "
-                         "configs[4] (train_pppe_pcd_ae.py:184-226, batch 4 x 8192 per GPU), a secondary measurement")
-    ap.add_argument("--pcie", action="store_true",
-                    help="also move the clouds host->device and the streams / reconstruction device->host inside the "
-                         "timed region (the PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the baseline sample (2/3 all cores, 1/3 one thread)")
+    ap.add_argument("--workload", default="ipdae", choices=["ipdae", "s3dis", "pppf", "pppe-train", "launch-check"],
+                    help="ipdae = the headline compress+decompress path (default); s3dis = configs[3] room-scale clouds in Morton "
+                         "blocks; pppf = configs[2] PPPF_AE forward; pppe-train = the training step of configs[4]; "
+                         "launch-check = no GPU work, exercises the N-rank launch and the summary all-gather")
+    ap.add_argument("--rooms", type=int, default=8, help="s3dis: number of rooms")
+    ap.add_argument("--autocast", action="store_true", help="pppe-train: the bf16 autocast branch of train_pppe_pcd_ae.py:193-217")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU")
+                    help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU / on CPU")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.dist_backend == "gloo":
-        local = local % max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the tiny collectives live
-    if world > 1:
-        import torch.distributed as dist
+    from pccx import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun_or_us():
+        # start the N rank processes ourselves, BEFORE this process touches a GPU (device_count() does not initialise HIP)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (use --dist-backend gloo to rehearse the N>1 path)")
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
-    from pccx import codec, models, ops, synth
-
-    if args.workload == "pppe-train":
-        return bench_pppe_train(args, world, rank, dev, cdev)
-
-    ae = models.AE(K_PATCH, K_SMALL, D_LAT, L_LEV)
-    ae.load_state_dict(seeded_state_dict(ae, AE_SEED, last_gain=AE_LAST_GAIN))
-    prob = models.ConditionalProbabilityModel(L_LEV, D_LAT)
-    prob.load_state_dict(seeded_state_dict(prob, PROB_SEED, gain=PROB_GAIN))
-    ae.pack(dev)
-    prob.pack(dev)
-    cd = codec.Codec(ae, prob, K=K_PATCH, ALPHA=ALPHA, N0=N0, octree_mode=args.octree_mode, decoder_matmul=args.decoder_matmul, sa_matmul=args.sa_matmul, pn_matmul=args.pn_matmul)
-
-    B = args.batch
-    # shard by file: global cloud i -> rank i % world; 32 distinct shapes per rank, tiled
-    base = np.stack([synth.cad_cloud(11 + rank + world * i, N_POINTS) for i in range(min(B, 32))])
-    clouds = torch.from_numpy(np.concatenate([base] * ((B + base.shape[0] - 1) // base.shape[0]))[:B]).to(dev)
-    starts = torch.from_numpy((np.arange(B) * 97 + rank) % N_POINTS).to(dev)
-
-    host_clouds = clouds.cpu().pin_memory() if args.pcie else None
-
-    def step():
-        if args.pcie:
-            x = host_clouds.to(dev, non_blocking=True)
-            comp = cd.compress(x, starts)
-            comp.to_host()                                   # .s.bin / .p.bin / .c.bin bytes to the host
-            out = cd.decompress(comp)
-            out.cpu()                                        # reconstructed XYZ to the host
-            return comp, out
-        comp = cd.compress(clouds, starts)
-        return comp, cd.decompress(comp)
-
-    for _ in range(args.warmup):
-        comp, out = step()
-    torch.cuda.synchronize()
-    timer = ops.StageTimer()
-    ops.set_timer(timer)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        comp, out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ops.set_timer(None)
-    if world > 1:
-        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-
-    stages = {k: (ms / n, n) for k, (ms, n) in timer.totals_ms().items()}
-    bpp = float(comp.bpp().mean())
-    psnr = float(codec.d1_psnr(clouds, out).mean())
-    if world > 1:
-        # the only data-path-adjacent exchange: tiny per-rank quality summaries
-        summ = torch.tensor([bpp, psnr], device=cdev, dtype=torch.float64)
-        gathered = [torch.zeros_like(summ) for _ in range(world)]
-        dist.all_gather(gathered, summ)
-        bpp, psnr = [float(x) for x in torch.stack(gathered).mean(0)]
-
-    if rank == 0:
-        P = B * S_PATCH
-        per_step_ms = {k: v[0] * v[1] / args.steps for k, v in stages.items()}
-        dom = max(STAGE_FLOP, key=lambda k: per_step_ms.get(k, 0.0))
-        dur_ms = stages[dom][0]
-        achieved = STAGE_FLOP[dom] * P / (dur_ms * 1e-3) / 1e12
-        res = {
-            "metric": "points/sec compress+decompress (ModelNet40-shaped 8192 K=256)",
-            "value": world * B * N_POINTS * args.steps / dt, "unit": "points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.decoder_matmul == args.sa_matmul == args.pn_matmul == "f32" else
-                     "f32 (EXPERIMENTAL: bf16x3-split operands, fp32 accumulate, in: %s)" % "+".join(
-                         n for n, v in (("decoder", args.decoder_matmul), ("sa", args.sa_matmul), ("pn", args.pn_matmul)) if v != "f32"),
-            "data": "synthetic",
-            "config": {"workload": "IPDAE K=256 d=16 L=7, 8192-pt CAD-like synthetic clouds (configs[1])",
-                       "clouds_per_gpu_per_step": B, "points_per_cloud": N_POINTS, "patches_per_cloud": S_PATCH,
-                       "octree_mode": args.octree_mode, "sharding": f"file-sharded x{world}", "weights": "seeded random",
-                       "pcie_inclusive": bool(args.pcie), "decoder_matmul": args.decoder_matmul, "sa_matmul": args.sa_matmul, "pn_matmul": args.pn_matmul},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS, "traffic": measured_traffic(dom, B),
-                         "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P},
-            "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
-            "mfma_stage_tflops": {k: STAGE_FLOP[k] * P / (stages[k][0] * 1e-3) / 1e12 for k in STAGE_FLOP if k in stages},
-            "bpp": bpp, "d1_psnr_db": psnr,
-        }
-        res["cpu_baseline"] = None
-        print("[bench] gpu leg done: %.3e points/s, %.2f ms/step; dominant %s %.1f TFLOP/s" %
-              (res["value"], res["ms_per_step"], dom, achieved), file=sys.stderr, flush=True)
-        if world == 1 and args.cpu_clouds > 0:
-            try:
-                res["cpu_baseline"] = cpu_baseline(args.cpu_clouds, args.cpu_budget)
-                res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
-            except Exception as e:   # the GPU line must survive a broken host toolchain
-                res["cpu_baseline_error"] = repr(e)
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    import pccx
+    if args.matmul is None:
+        args.matmul = pccx.DEFAULT_MATMUL
+    rk = Ranks(args)
+    if rk.world != args.gpus and rk.rank == 0:
+        print(f"[bench] note: WORLD_SIZE={rk.world} from the launcher overrides --gpus {args.gpus}", file=sys.stderr)
+    try:
+        {"ipdae": bench_ipdae, "s3dis": bench_s3dis, "pppf": bench_pppf, "pppe-train": bench_pppe_train,
+         "launch-check": bench_launch_check}[args.workload](args, rk)
+    finally:
+        rk.close()
 
 
 if __name__ == "__main__":

@@ -230,6 +230,11 @@ PCCX_API int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int st
                                const int32_t *nbytes, int B, int nsym, int L, float *latent_q,
                                void *stream);
 
+/* torchac's float -> 16-bit integer CDF conversion (torchac 0.9.3 _convert_to_int_and_normalize with
+ * needs_normalization=True, the first step of encode_float_cdf / decode_float_cdf, compress.py:136, decompress.py:93):
+ * cdf (nrows, Lp) f32 in [0,1] -> cdf_int (nrows, Lp) int32 holding 16-bit values. */
+PCCX_API int pccx_cdf_float_to_int(const float *cdf, int64_t nrows, int Lp, int32_t *cdf_int, void *stream);
+
 /* ---- generic layers for the other model families (PPPF_AE.py, pointnet_sa_module.py,
  *      pppe_pcd_ae.py:556-917): correctness-first building blocks ------------------------------- */
 

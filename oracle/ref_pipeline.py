@@ -99,3 +99,19 @@ def d1_psnr(orig, recon):
     mse = float(np.mean(d2.astype(np.float64)))
     rng = orig.max(0).astype(np.float64) - orig.min(0).astype(np.float64)
     return 10 * np.log10(float((rng ** 2).sum()) / mse) if mse > 0 else float("inf")
+
+
+def calc_uc(input_pc, decomp_pc, region=1024):
+    """eval.calc_uc (eval.py:127-151): the 1024-NN region of point 0 of each cloud (pytorch3d knn_points, centred on
+    the point, :130-136), each region point's distance to its nearest OTHER region point by torch.cdist + topk(k=2,
+    largest=False) (:138-144), and the ratio of the population variances np.var(decomp) / np.var(input) (:146-151).
+    torch.cdist keeps the reference's own call (its default compute mode forms |a|^2 + |b|^2 - 2ab for regions this size)."""
+    def region_dist(pc):
+        pc = torch.from_numpy(np.asarray(pc, dtype=np.float32))
+        point = pc[0]
+        _, _, grouped = ref_model.knn_points(point.view(1, 1, 3), pc.unsqueeze(0), K=region, return_nn=True)
+        reg = (grouped - point.view(1, 1, 1, 3)).view(region, 3)
+        dist = torch.cdist(reg, reg, p=2)
+        values, _ = torch.topk(dist, k=2, largest=False)
+        return values[:, 1].numpy()
+    return float(np.var(region_dist(decomp_pc)) / np.var(region_dist(input_pc)))

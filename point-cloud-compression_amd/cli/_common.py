@@ -27,6 +27,33 @@ def find_checkpoint(folder, prefix):
     return os.path.join(folder, max(steps)[1])
 
 
+def setup_ranks(args):
+    """One process per GPU: under torchrun / pccx.launch (RANK, LOCAL_RANK, WORLD_SIZE in the environment) pin this
+    process to its GPU and join the process group (RCCL); files are then sharded file i -> rank i mod world
+    (dist.shard_indices) and the per-rank summaries all-gathered at the end.  Returns (rank, world)."""
+    from pccx import launch
+    rank, local, world = launch.rank_env()
+    if world > 1:
+        if str(args.device).startswith("cuda"):
+            local = local % max(torch.cuda.device_count(), 1)
+            args.device = f"cuda:{local}"
+            torch.cuda.set_device(local)
+        backend = os.environ.get("PCCX_DIST_BACKEND", "nccl")
+        launch.init_process_group(backend, torch.device(args.device) if backend == "nccl" else None)
+    return rank, world
+
+
+def finish_ranks(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def summary_device(args):
+    return torch.device(args.device) if os.environ.get("PCCX_DIST_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+
+
 def load_models(args, need_gpu=True):
     from pccx import models
     if need_gpu and not torch.cuda.is_available():

@@ -25,9 +25,11 @@ def main():
     print(f"Processing on device (gpu/cpu): {args.device}")
     os.makedirs(args.compressed_path, exist_ok=True)
     files = sorted(glob(args.input_glob, recursive=True))
+    rank, world = _common.setup_ranks(args)
     ae, prob = _common.load_models(args)
     cd = codec.Codec(ae, prob, K=args.K, ALPHA=args.ALPHA, N0=args.N0, octree_mode=args.octree_mode)
-    times, todo = [], list(enumerate(files))
+    mine = set(dist.shard_indices(len(files), rank, world))                                      # file i -> rank i mod world
+    times, todo, bits, points = [], [t for t in enumerate(files) if t[0] in mine], 0, 0
     with torch.no_grad():
         while todo:
             clouds = [(i, f, plyio.read_point_cloud(f)) for i, f in todo[:args.batch]]          # outside the timed window
@@ -47,8 +49,14 @@ def main():
                     with open(os.path.join(args.compressed_path, name + ext), 'wb') as fout:
                         fout.write(data)
             times += [(time.time() - t0) / len(batch)] * len(batch)                              # compress.py:154
-    if times:
-        print(f"Done! Execution time: {round(float(np.mean(times)), 5)}s per point cloud.")
+            bits += sum(8 * (len(s) + len(p) + len(c)) for s, p, c in blobs)
+            points += n0 * len(batch)
+    g = dist.gather_summaries([bits, points, 0.0, 0.0, len(times), float(np.sum(times))], _common.summary_device(args))
+    if rank == 0 and float(g[:, 4].sum()) > 0:
+        tot = g.sum(dim=0)
+        print(f"Done! Execution time: {round(float(tot[5] / tot[4]), 5)}s per point cloud." +
+              (f" ({int(tot[4])} clouds on {world} ranks, {float(tot[0] / tot[1]):.4f} bpp)" if world > 1 else ""))
+    _common.finish_ranks(world)
 
 
 if __name__ == '__main__':

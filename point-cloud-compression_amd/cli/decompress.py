@@ -9,7 +9,8 @@ import numpy as np
 
 import _common  # noqa: F401
 import torch
-from pccx import codec, plyio
+from pccx import codec, dist, ops, plyio
+from pccx._lib import PccxError
 
 parser = argparse.ArgumentParser(prog='decompress.py', description='Deompress Point Clouds Using Trained Model.',
                                  formatter_class=argparse.ArgumentDefaultsHelpFormatter)
@@ -17,7 +18,9 @@ parser.add_argument('compressed_path', help='Comressed .bin files folder.')
 parser.add_argument('decompressed_path', help='Decompressed .ply files folder.')
 parser.add_argument('model_load_folder', help='Directory where to load trained models.')
 _common.add_codec_flags(parser)
-parser.add_argument('--S', type=int, default=64, help="Patches per cloud (only used with --octree-mode full).")
+parser.add_argument('--S', type=int, default=None,
+                    help="Patches per cloud with --octree-mode full (default: the number of centres each .s.bin holds; "
+                         "'reference' mode is octree_np.decode as written, always 64).")
 parser.add_argument('--bin-ply-suffix', action='store_true',
                     help="Write <name>.bin.ply (what eval.py:172 looks for) instead of <name> (decompress.py:121).")
 
@@ -35,6 +38,8 @@ def main():
     print(f"Processing on device (gpu/cpu): {args.device}")
     os.makedirs(args.decompressed_path, exist_ok=True)
     names = sorted(os.path.split(x)[1][:-6] for x in glob(os.path.join(args.compressed_path, '*.s.bin')))
+    rank, world = _common.setup_ranks(args)
+    names = [names[i] for i in dist.shard_indices(len(names), rank, world)]                      # file i -> rank i mod world
     ae, prob = _common.load_models(args)
     cd = codec.Codec(ae, prob, K=args.K, ALPHA=args.ALPHA, N0=args.N0, octree_mode=args.octree_mode)
     times = []
@@ -47,13 +52,29 @@ def main():
             s_b, s_n = _pad([rd(n, '.s.bin') for n in chunk], args.device)
             p_b, p_n = _pad([rd(n, '.p.bin') for n in chunk], args.device)
             c = torch.from_numpy(np.stack([np.frombuffer(rd(n, '.c.bin'), dtype=np.float32) for n in chunk])).to(args.device)
-            comp = codec.Compressed(s_b, s_n, p_b, p_n, c, 0)
-            pc = cd.decompress(comp, S=64 if args.octree_mode == 'reference' else args.S).cpu().numpy()
+            # number of centres each stream holds (decompress.py:85 takes S from the decoded array)
+            _, count = ops.octree_decode(s_b, s_n, args.octree_mode, 64 if args.octree_mode == 'reference' else 1)
+            count = count.cpu().numpy()
+            if (count < 0).any():
+                raise PccxError("corrupt .s.bin stream(s): " + ", ".join(n for n, k_ in zip(chunk, count) if k_ < 0))
+            S_of = np.full(len(chunk), 64) if args.octree_mode == 'reference' else (count if args.S is None else np.full(len(chunk), args.S))
+            if args.octree_mode == 'full' and args.S is not None and (count != args.S).any():
+                raise PccxError(f"--S {args.S} given but the streams hold {sorted(set(count.tolist()))} centres")
+            clouds = [None] * len(chunk)
+            for S in sorted(set(S_of.tolist())):                                                 # one launch sequence per S
+                sel = torch.from_numpy(np.flatnonzero(S_of == S)).to(args.device)
+                comp = codec.Compressed(s_b[sel], s_n[sel], p_b[sel], p_n[sel], c[sel], 0)
+                pc = cd.decompress(comp, S=int(S)).cpu().numpy()
+                for j, cloud in zip(sel.cpu().tolist(), pc):
+                    clouds[j] = cloud
             times += [(time.time() - t0) / len(chunk)] * len(chunk)                              # decompress.py:118
-            for n, cloud in zip(chunk, pc):
+            for n, cloud in zip(chunk, clouds):
                 plyio.save_point_cloud(cloud, os.path.join(args.decompressed_path, n + ('.bin.ply' if args.bin_ply_suffix else '')))
-    if times:
-        print(f"Done! Execution time: {round(float(np.mean(times)), 5)}s per point cloud.")
+    g = dist.gather_summaries([0.0, 0.0, 0.0, 0.0, len(times), float(np.sum(times))], _common.summary_device(args))
+    if rank == 0 and float(g[:, 4].sum()) > 0:
+        tot = g.sum(dim=0)
+        print(f"Done! Execution time: {round(float(tot[5] / tot[4]), 5)}s per point cloud." + (f" ({int(tot[4])} clouds on {world} ranks)" if world > 1 else ""))
+    _common.finish_ranks(world)
 
 
 if __name__ == '__main__':

@@ -11,7 +11,7 @@ import pandas as pd
 
 import _common  # noqa: F401
 import torch
-from pccx import codec, ops, plyio
+from pccx import codec, dist, ops, plyio
 
 parser = argparse.ArgumentParser(prog='eval.py', description='Evaluate point cloud patches',
                                  formatter_class=argparse.ArgumentDefaultsHelpFormatter)
@@ -26,8 +26,8 @@ def calc_uc(input_pc, decomp_pc):
     """eval.py:127-151: variance ratio of nearest-neighbour distances inside the 1024-NN region of point 0."""
     def nn_var(pc):
         K = min(1024, pc.shape[1])
-        region = ops.knn_points(pc[:, :1].contiguous(), pc, K).knn[:, 0]          # (1,K,3)
-        d2 = ops.knn_points(region, region, 2).dists[..., 1]                        # nearest other point
+        region = ops.knn_points(pc[:, :1].contiguous(), pc, K, patch_scale=1.0).knn[:, 0]   # (1,K,3), centred on point 0 (:130-136)
+        d2 = ops.knn_points(region, region, 2).dists[..., 1]                        # nearest other point (:138-144)
         return torch.sqrt(d2).double().var(unbiased=False)
     return float(nn_var(decomp_pc) / nn_var(input_pc))
 
@@ -36,8 +36,9 @@ def main():
     args = parser.parse_args()
     print(f"Processing on device (gpu/cpu): {args.device}")
     files = sorted(glob(args.input_glob, recursive=True))
+    rank, world = _common.setup_ranks(args)
     rows = []
-    for f in files:
+    for f in [files[i] for i in dist.shard_indices(len(files), rank, world)]:                 # file i -> rank i mod world
         name = os.path.split(f)[1]
         cand = [os.path.join(args.decompressed_path, name + '.bin.ply'), os.path.join(args.decompressed_path, name)]
         decomp_f = next((c for c in cand if os.path.exists(c)), None)                # eval.py:172 vs decompress.py:121
@@ -50,6 +51,14 @@ def main():
                          chamfer_distance=float(codec.normalized_chamfer(a, b)[0]), n_points_input=a.shape[1],
                          n_points_output=b.shape[1], bpp=bits / a.shape[1],                 # eval.py:189
                          **{'uniformity coefficient': round(calc_uc(a, b), 3)}))
+    if world > 1:                                            # per-file rows travel to rank 0 (a few hundred bytes per file)
+        import torch.distributed as tdist
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, rows)
+        rows = sorted((r for part in gathered for r in part), key=lambda r: r["filename"])
+        _common.finish_ranks(world)
+        if rank != 0:
+            return
     df = pd.DataFrame(rows, columns=['filename', 'p2pointPSNR', 'p2planePSNR', 'chamfer_distance', 'n_points_input',
                                      'n_points_output', 'bpp', 'uniformity coefficient'])
     if len(df):

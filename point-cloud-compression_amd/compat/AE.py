@@ -7,13 +7,16 @@ from pccx import ops
 from pccx.models import AE, ConditionalProbabilityModel  # noqa: F401
 
 
-class get_loss(torch.nn.Module):                                  # AE.py:57-70 (forward value only)
+class get_loss(torch.nn.Module):                                  # AE.py:57-70
+    """Rate-distortion loss d + lambda * r.  The Chamfer term is differentiable w.r.t. both clouds
+    (ops.chamfer_distance: HIP forward + pccx_chamfer_grad backward); the models of this module are
+    inference-only (their forwards do not record a graph), so training goes through pccx.train."""
+
     def forward(self, pc_pred, pc_target, fbpp, λ):
         d, _ = ops.chamfer_distance(pc_pred, pc_target)
         return d + λ * fbpp
 
 
-class STEQuantize:                                                # AE.py:72-85 (forward)
-    @staticmethod
-    def apply(x):
-        return x.round()
+class STEQuantize:                                                # AE.py:72-85
+    """apply(x) = x.round() with the straight-through gradient of AE.py:83-85 (ops.ste_round)."""
+    apply = staticmethod(ops.ste_round)

@@ -31,26 +31,38 @@ def save_point_cloud(pc, filename, path='./viewing/'):            # pn_kit.py:39
     plyio.save_point_cloud(pc, os.path.join(path, filename))
 
 
+def _up(t):
+    """The reference's scripts shuttle tensors between host and device freely (decompress.py:110-116 denormalises on
+    the CPU).  There is no CPU compute path here: a host tensor is uploaded, the HIP kernel runs, and the result goes
+    back to the device the caller used."""
+    t = torch.as_tensor(t)
+    return (t if t.is_cuda else t.cuda()), t.device
+
+
 def normalize(pc, margin=0.01):                                   # pn_kit.py:47-60, pc (1,N,3)
-    out, center, longest = ops.normalize(pc, margin)
+    x, dev = _up(pc)
+    out, center, longest = (t.to(dev) for t in ops.normalize(x.float(), margin))
     if pc.shape[0] == 1:
         return out, center[0], longest[0]
     return out, center, longest
 
 
 def denormalize(pc, cetner, longest, margin=0.01):                # pn_kit.py:62-66
-    B = pc.shape[0]
-    c = torch.as_tensor(cetner, dtype=torch.float32, device=pc.device).reshape(-1, 3).expand(B, 3).contiguous()
-    l = torch.as_tensor(longest, dtype=torch.float32, device=pc.device).reshape(-1).expand(B).contiguous()
-    return ops.denormalize(pc, c, l, margin)
+    x, dev = _up(pc)
+    B = x.shape[0]
+    c = torch.as_tensor(cetner, dtype=torch.float32).to(x.device).reshape(-1, 3).expand(B, 3).contiguous()
+    l = torch.as_tensor(longest, dtype=torch.float32).to(x.device).reshape(-1).expand(B).contiguous()
+    return ops.denormalize(x.float(), c, l, margin).to(dev)
 
 
 def farthest_point_sample_batch(xyz, npoint, start_idx=None):     # pn_kit.py:309-330
-    return ops.farthest_point_sample_batch(xyz, npoint, start_idx)
+    x, dev = _up(xyz)
+    return ops.farthest_point_sample_batch(x, npoint, start_idx).to(dev)
 
 
 def index_points(points, idx):                                    # pn_kit.py:332-360
-    return ops.index_points(points, idx)
+    x, dev = _up(points)
+    return ops.index_points(x, torch.as_tensor(idx).to(x.device)).to(dev)
 
 
 def encode_sampled_np(sampled_xyz, scale, N, min_bpp):            # pn_kit.py:380-401

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void octree_decode_full_kernel(const uint8_t *
     __shared__ int s_w[17];
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint8_t *bytes = bytes_all + (size_t)b * stride;
-    const int nb = nbytes[b];
+    const int nb = min(max(nbytes[b], 0), stride);     // never read past the row, whatever the caller's count says
     float *o = out + (size_t)b * S_out * 3;
     const int nbits = nb >= 1 ? 8 * (nb - 1) + 1 : 0;
     int parents = (nbits >= 1 && stream_bit(bytes, nb, 0)) ? 1 : 0;

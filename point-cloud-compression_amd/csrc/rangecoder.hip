@@ -377,3 +377,24 @@ extern "C" int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int 
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
+
+// torchac's float -> 16-bit CDF conversion (torchac 0.9.3 _convert_to_int_and_normalize, needs_normalization=True; the
+// same formula as prob_forward_kernel's epilogue): cdf_int[l] = (round(cdf[l] * (2^16 - (Lp - 1))) + l) mod 2^16.
+__global__ void cdf_float_to_int_kernel(const float *__restrict__ cdf, int64_t n, int Lp, int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int l = (int)(i % Lp);
+    out[i] = ((int)rintf(__fmul_rn(cdf[i], (float)(65536 - (Lp - 1)))) + l) & 0xFFFF;
+}
+
+extern "C" int pccx_cdf_float_to_int(const float *cdf, int64_t nrows, int Lp, int32_t *cdf_int, void *stream)
+{
+    if (nrows == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(cdf && cdf_int, "pccx_cdf_float_to_int: null pointer");
+    PCCX_CHECK_ARG(nrows > 0 && Lp >= 2 && Lp <= 65536, "pccx_cdf_float_to_int: bad shape");
+    const int64_t n = nrows * Lp;
+    hipLaunchKernelGGL(cdf_float_to_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cdf, n, Lp, cdf_int);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

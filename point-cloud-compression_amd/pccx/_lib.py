@@ -52,6 +52,7 @@ _SIGNATURES = {
     "pccx_prob_forward": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_range_encode": [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_range_decode": [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_cdf_float_to_int": [_P, C.c_int64, C.c_int, _P, _P],
     "pccx_packed_linear_floats": [C.c_int, C.c_int],
     "pccx_pack_linear": [_P, C.c_int, C.c_int, _P],
     "pccx_linear": [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],

@@ -18,6 +18,16 @@ from . import models, ops
 from .ops import stage
 
 
+def packed_layout(B, s_stride, p_cap):
+    """Byte offsets of the five sections of one batch's packed stream buffer (SoA, so that every section is a dense
+    tensor the kernels write in place): s_nbytes (B) i32 | p_nbytes (B) i32 | c (B,4) f32 | s_bytes (B,s_stride) u8 |
+    p_bytes (B,p_cap) u8.  Everything the three files of compress.py:139-152 need, in ONE device->host copy."""
+    o_sn, o_pn, o_c = 0, 4 * B, 8 * B
+    o_sb = o_c + 16 * B
+    o_pb = o_sb + B * s_stride
+    return o_sn, o_pn, o_c, o_sb, o_pb, o_pb + B * p_cap
+
+
 @dataclasses.dataclass
 class Compressed:
     s_bytes: torch.Tensor     # (B, stride) u8  packed octree streams
@@ -27,6 +37,22 @@ class Compressed:
     c: torch.Tensor           # (B, 4) f32      centre xyz + longest side
     n_points: int
     extras: dict = None       # intermediates for tests / diagnostics
+    packed: torch.Tensor = None   # the u8 buffer the five fields above are views of (packed_layout), when built by Codec
+
+    @classmethod
+    def alloc(cls, B, s_stride, p_cap, n_points, device):
+        return cls.from_packed(torch.empty(packed_layout(B, s_stride, p_cap)[-1], device=device, dtype=torch.uint8),
+                               B, s_stride, p_cap, n_points)
+
+    @classmethod
+    def from_packed(cls, packed, B, s_stride, p_cap, n_points):
+        """Views over a packed buffer (device: as produced by Codec.compress; or the same bytes uploaded from the host)."""
+        o_sn, o_pn, o_c, o_sb, o_pb, end = packed_layout(B, s_stride, p_cap)
+        if packed.numel() != end or packed.dtype != torch.uint8:
+            raise ValueError(f"packed stream buffer: expected {end} bytes of uint8, got {packed.numel()} of {packed.dtype}")
+        return cls(packed[o_sb:o_pb].view(B, s_stride), packed[o_sn:o_pn].view(torch.int32),
+                   packed[o_pb:end].view(B, p_cap), packed[o_pn:o_c].view(torch.int32),
+                   packed[o_c:o_sb].view(torch.float32).view(B, 4), n_points, None, packed)
 
     def bits(self):
         """Total bits per cloud of the three files (eval.py:189 numerator)."""
@@ -36,12 +62,25 @@ class Compressed:
         return self.bits().double() / self.n_points
 
     def to_host(self):
-        """One device->host transfer of everything the three files need (cached)."""
+        """ONE device->host transfer of everything the three files need (cached).  Raises PccxError when a range-coder
+        output buffer was too small (the kernel reports that as a negative byte count)."""
         if getattr(self, "_host", None) is None:
-            sn, pn = self.s_nbytes.cpu().numpy(), self.p_nbytes.cpu().numpy()
-            sb = self.s_bytes[:, :max(int(sn.max()), 1)].cpu().numpy() if len(sn) else np.zeros((0, 1), np.uint8)
-            pb = self.p_bytes[:, :max(int(pn.max()), 1)].cpu().numpy() if len(pn) else np.zeros((0, 1), np.uint8)
-            self._host = (sb, sn, pb, pn, self.c.cpu().numpy().astype(np.float32))
+            B = self.s_bytes.shape[0]
+            if self.packed is None:       # assembled by hand (e.g. from files): gather the five pieces first
+                comp = Compressed.alloc(B, self.s_bytes.shape[1], self.p_bytes.shape[1], self.n_points, self.s_bytes.device)
+                for dst, src in ((comp.s_bytes, self.s_bytes), (comp.s_nbytes, self.s_nbytes), (comp.p_bytes, self.p_bytes),
+                                 (comp.p_nbytes, self.p_nbytes), (comp.c, self.c)):
+                    dst.copy_(src)
+                packed = comp.packed
+            else:
+                packed = self.packed
+            h = Compressed.from_packed(packed.cpu(), B, self.s_bytes.shape[1], self.p_bytes.shape[1], self.n_points)
+            sn, pn = h.s_nbytes.numpy(), h.p_nbytes.numpy()
+            if (pn < 0).any() or (sn < 0).any():
+                from ._lib import PccxError
+                raise PccxError("range coder / octree output buffer too small for clouds %s (negative byte count): "
+                                "raise `cap`" % np.nonzero((pn < 0) | (sn < 0))[0].tolist())
+            self._host = (h.s_bytes.numpy(), sn, h.p_bytes.numpy(), pn, h.c.numpy())
         return self._host
 
     def files(self, b):
@@ -51,11 +90,20 @@ class Compressed:
 
 
 class Codec:
-    def __init__(self, ae, prob, K=256, ALPHA=2, N0=1024, octree_mode="reference", margin=0.01, decoder_matmul="f32",
-                 sa_matmul="f32", pn_matmul="f32"):
+    def __init__(self, ae, prob, K=256, ALPHA=2, N0=1024, octree_mode="reference", margin=0.01, matmul=None,
+                 decoder_matmul=None, sa_matmul=None, pn_matmul=None):
+        """matmul: how the three transforms (SetAbstraction, PointNet, decoder) form their fp32 products --
+        "f32" = v_mfma_f32_16x16x4_f32 (bit-for-bit a k-ordered fmaf chain), "bf16x3" = each fp32 operand split exactly into
+        three bf16 pieces, six products per pair on the bf16 matrix cores, fp32 accumulate (fp32-level error, 2.6x the
+        rate).  None = pccx.DEFAULT_MATMUL.  The per-stage arguments override it."""
+        from . import DEFAULT_MATMUL
+        matmul = matmul or DEFAULT_MATMUL
         self.ae, self.prob = ae, prob
-        self.decoder_matmul = decoder_matmul                 # "bf16x3": EXPERIMENTAL opt-in (models.AE.decode)
-        self.sa_matmul, self.pn_matmul = sa_matmul, pn_matmul  # "bf16x3": EXPERIMENTAL opt-in (models.AE.encode)
+        self.decoder_matmul = decoder_matmul or matmul
+        self.sa_matmul, self.pn_matmul = sa_matmul or matmul, pn_matmul or matmul
+        for m in (self.decoder_matmul, self.sa_matmul, self.pn_matmul):
+            if m not in ("f32", "bf16x3"):
+                raise ValueError(f"matmul={m!r}: expected 'f32' or 'bf16x3'")
         self.K, self.ALPHA, self.N0 = K, ALPHA, N0
         self.k = K // ALPHA                                  # compress.py:46
         self.octree_mode = octree_mode
@@ -78,8 +126,10 @@ class Codec:
             fps_idx = ops.farthest_point_sample_batch(pcn, S, start_idx)             # compress.py:96
         with stage("gather"):
             sampled = ops.index_points(pcn, fps_idx)
+        comp = Compressed.alloc(B, (ops.octree_bits_capacity(S) + 7) // 8, models.range_cap(S * d), N, pc.device)
         with stage("octree_encode"):
-            oc = ops.octree_encode(sampled, N, ops.OCTREE_BPP_DICT[self.K])          # compress.py:98
+            oc = ops.octree_encode(sampled, N, ops.OCTREE_BPP_DICT[self.K],          # compress.py:98
+                                   out_bytes=comp.s_bytes, out_nbytes=comp.s_nbytes)
         with stage("octree_decode"):
             rec, _ = ops.octree_decode(oc["bytes"], oc["nbytes"], self.octree_mode, S)   # compress.py:100
         scale = float((N / self.N0) ** (1 / 3))
@@ -90,13 +140,13 @@ class Codec:
         with stage("prob"):
             cdf_int = self.prob.run(rec, ("cdf_int",))["cdf_int"]                    # compress.py:131-134
         with stage("range_encode"):
-            p_bytes, p_nbytes = models.range_encode(cdf_int, q.view(B, S * d), L)    # compress.py:135-136
-        c = torch.cat([center, longest[:, None]], dim=1)                             # compress.py:149-152
-        extras = None
+            models.range_encode(cdf_int, q.view(B, S * d), L, out=comp.p_bytes, nb=comp.p_nbytes)   # compress.py:135-136
+        comp.c[:, :3].copy_(center)                                                  # compress.py:149-152
+        comp.c[:, 3].copy_(longest)
         if keep_extras:
-            extras = dict(pcn=pcn, fps_idx=fps_idx, sampled=sampled, octree=oc, rec_sampled=rec, patches=patches,
+            comp.extras = dict(pcn=pcn, fps_idx=fps_idx, sampled=sampled, octree=oc, rec_sampled=rec, patches=patches,
                           latent_raw=raw, latent=latent, latent_q=q, cdf_int=cdf_int, knn_idx=nn.idx)
-        return Compressed(oc["bytes"], oc["nbytes"], p_bytes, p_nbytes, c, N, extras)
+        return comp
 
     def decompress(self, comp, S=64):
         """Inverse pipeline (decompress.py:80-116) -> (B, S*k, 3) f32."""

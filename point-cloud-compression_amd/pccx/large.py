@@ -39,8 +39,8 @@ def split_blocks(pc, block=8192):
 
 
 def compress_large(codec, pc, seed=11, rank=0, world=1, block=8192, batch=256):
-    """Compress this rank's share of the blocks of one large cloud.  Returns (list of (block index,
-    Compressed batch slices), number of blocks)."""
+    """Compress this rank's share of the blocks of one large cloud.  Returns (list of (block indices,
+    Compressed batch), number of blocks, order, n_valid_last): everything decompress_large needs."""
     from . import dist
     blocks, order, n_last = split_blocks(pc, block)
     mine = dist.shard_indices(blocks.shape[0], rank, world)
@@ -50,3 +50,34 @@ def compress_large(codec, pc, seed=11, rank=0, world=1, block=8192, batch=256):
         starts = [dist.fps_start_index(seed, j, block) for j in ids]
         out.append((ids, codec.compress(blocks[ids], starts)))
     return out, blocks.shape[0], order, n_last
+
+
+def unsplit_blocks(rows, ids, order, n_points, block=8192, out=None):
+    """Inverse of split_blocks for the blocks ``ids``: rows (len(ids), block, 3) -> written into ``out`` (n_points,3) at
+    the ORIGINAL indices of those blocks' points (out[order[j*block + i]] = rows[j', i]); the padding rows of the last
+    block (copies of its final point on the way in) are dropped.  Rows of a decoded block correspond to the block's
+    input points as a SET (the decoder regenerates the block's points), so this restores the cloud's size, its
+    block-to-region placement and, for rows == the input blocks, the cloud itself bit for bit."""
+    if out is None:
+        out = torch.empty(n_points, 3, device=rows.device, dtype=rows.dtype)
+    ids_t = torch.as_tensor(list(ids), device=rows.device, dtype=torch.int64)
+    pos = ids_t[:, None] * block + torch.arange(block, device=rows.device)[None]          # position in Morton order
+    keep = pos < n_points                                                                  # drops the padding
+    out[order[pos[keep]]] = rows.reshape(-1, block, 3)[keep]
+    return out
+
+
+def decompress_large(codec, parts, n_blocks, order, n_points, block=8192, out=None, S=64):
+    """Decode the (block indices, Compressed) batches of compress_large and place them back (unsplit_blocks).  With
+    world > 1 every rank fills the rows of ITS blocks in ``out``; rows of other ranks' blocks stay untouched (blocks are
+    independent, so metrics are per-block sums gathered with dist.gather_summaries -- the cloud itself is only
+    exchanged if a caller wants it in one place)."""
+    if out is None:
+        dev = parts[0][1].s_bytes.device if parts else "cuda"
+        out = torch.zeros(n_points, 3, device=dev, dtype=torch.float32)
+    for ids, comp in parts:
+        rec = codec.decompress(comp, S=S)
+        if rec.shape[1] != block:
+            raise ValueError(f"decoded blocks have {rec.shape[1]} points, expected {block} (S*k must equal the block size)")
+        unsplit_blocks(rec, ids, order, n_points, block, out)
+    return out

@@ -22,30 +22,138 @@ def _conv_stack(chans, relu):
     return mods
 
 
+def _pccx_default_matmul():
+    from . import DEFAULT_MATMUL
+    return DEFAULT_MATMUL
+
+
+def _folded(conv, relu, device):
+    from .families import FoldedLinear          # generic runtime-shaped fp32 MFMA layer (csrc/linear.hip)
+    return FoldedLinear(conv.weight, conv.bias, relu, None, device)
+
+
 class _Params(nn.Module):
-    def forward(self, *a, **k):
-        raise _lib.PccxError(f"{type(self).__name__} is a parameter container; use the owning model's HIP entry points")
+    """Sub-modules of the reference's models.  They hold the parameters under the reference's state_dict keys AND are
+    callable like the reference's (compress.py:113-121 calls ae.sa(x) / ae.pn(x), decompress.py:97-101 ae.inv_pool /
+    ae.inv_mlp): forward runs HIP kernels -- the owning AE's fused entry points when the module is one of AE's and the
+    shapes are the fused kernel's, otherwise the generic layer kernels (pccx_linear / pccx_group_max).  No torch compute."""
+
+    _fused = None                 # set by the owning AE: a callable taking the reference's arguments, or None
+    _layers = None                # generic path: packed layers, built lazily on the input's device
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._layers = None
+        return r
+
+    def _own(self, fused):
+        object.__setattr__(self, "_fused", fused)      # not a sub-module / buffer: plain attribute
+
+
+class _ConvStack(_Params):
+    def _stack(self, device):
+        if self._layers is None or self._layers[0] != torch.device(device):
+            object.__setattr__(self, "_layers", (torch.device(device), [_folded(m[0], len(m) > 1, device) for m in self.mlp_Modules]))
+        return self._layers[1]
+
+    def _rows(self, points):
+        x = _f32c(points, type(self).__name__)
+        if x.dim() != 3:
+            raise _lib.PccxError(f"{type(self).__name__}: expected [B, C, N], got {tuple(x.shape)}")
+        B, Cc, N = x.shape
+        rows = x.permute(0, 2, 1).reshape(B * N, Cc).contiguous()          # channels-last rows
+        for layer in self._stack(x.device):
+            rows = layer(rows)
+        return rows, B, N
 
 
 class SetAbstraction(_Params):      # pn_kit.SetAbstraction (pn_kit.py:146-161), bn=False
-    def __init__(self, npoint, K, in_channel, mlp):
+    def __init__(self, npoint, K, in_channel, mlp, bn=False, finalRelu=True):
         super().__init__()
-        self.npoint, self.K = npoint, K
+        if bn:
+            raise _lib.PccxError("pccx.SetAbstraction: bn=True is not on the codec path (AE.py:16 uses bn=False)")
+        self.npoint, self.K, self.finalRelu = npoint, K, finalRelu
         self.conv0 = nn.Conv2d(in_channel + 3, mlp[0], 1)
         self.conv1 = nn.Conv2d(mlp[0], mlp[1], 1)
         self.conv2 = nn.Conv2d(mlp[1], mlp[2], 1)
 
+    def forward(self, xyz, start_idx=None):
+        """pn_kit.SetAbstraction.forward (pn_kit.py:164-211): xyz [B, 3, N] -> (new_xyz [B, 3, S], new_points [B, D', S])."""
+        x = _f32c(xyz, "SetAbstraction")
+        B, Cc, N = x.shape
+        if self._fused is not None and self.npoint == N and Cc == 3:
+            return self._fused(x)
+        from .families import group_max
+        from . import ops
+        pts = x.permute(0, 2, 1).contiguous()                                              # :173
+        S = self.npoint
+        new_xyz = pts if S == N else ops.index_points(pts, ops.farthest_point_sample_batch(pts, S, start_idx))   # :180-183
+        nn_ = ops.knn_points(new_xyz, pts, self.K, patch_scale=1.0)                        # :190-191 (nn - centre)
+        rows = nn_.knn.reshape(B * S * self.K, Cc).contiguous()
+        if self._layers is None or self._layers[0] != x.device:
+            object.__setattr__(self, "_layers", (x.device, [_folded(self.conv0, True, x.device), _folded(self.conv1, True, x.device),
+                                                            _folded(self.conv2, self.finalRelu, x.device)]))
+        for layer in self._layers[1]:
+            rows = layer(rows)                                                             # :198-205
+        feat = group_max(rows.view(B * S, self.K, -1)).view(B, S, -1)                      # :207
+        return new_xyz.permute(0, 2, 1), feat.permute(0, 2, 1)                             # :209-211
 
-class PointNet(_Params):            # pn_kit.PointNet (pn_kit.py:98-121), bn=False
-    def __init__(self, in_channel, mlps, relu):
+
+class PointNet(_ConvStack):         # pn_kit.PointNet (pn_kit.py:98-121), bn=False
+    def __init__(self, in_channel, mlps, relu, bn=False):
         super().__init__()
+        if bn:
+            raise _lib.PccxError("pccx.PointNet: bn=True is not on the codec path (AE.py:17 uses bn=False)")
         self.mlp_Modules = _conv_stack([in_channel] + list(mlps), relu)
 
+    def forward(self, points):
+        """pn_kit.PointNet.forward (pn_kit.py:124-144): points [B, C, N] -> [B, D] (max over the N points)."""
+        if self._fused is not None:
+            r = self._fused(points)
+            if r is not None:
+                return r
+        from .families import group_max
+        rows, B, N = self._rows(points)
+        return group_max(rows.view(B, N, -1))
 
-class MLP(_Params):                 # pn_kit.MLP (pn_kit.py:263-286), bn=False
-    def __init__(self, in_channel, mlps, relu):
+
+class MLP(_ConvStack):              # pn_kit.MLP (pn_kit.py:263-286), bn=False
+    def __init__(self, in_channel, mlps, relu, bn=False):
         super().__init__()
+        if bn:
+            raise _lib.PccxError("pccx.MLP: bn=True is not on the codec path (AE.py:27 uses bn=False)")
         self.mlp_Modules = _conv_stack([in_channel] + list(mlps), relu)
+
+    def forward(self, points):
+        """pn_kit.MLP.forward (pn_kit.py:288-305): points [B, C, N] -> [B, D, N]."""
+        rows, B, N = self._rows(points)
+        return rows.view(B, N, -1).permute(0, 2, 1)
+
+
+class LinearStack(nn.Sequential):
+    """nn.Sequential of Linear / ReLU (AE.py:19-26 inv_pool) with the reference's state_dict keys; forward = one
+    pccx_linear launch per Linear (ReLU fused)."""
+
+    _layers = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._layers = None
+        return r
+
+    def forward(self, x):
+        x = _f32c(x, "inv_pool")
+        if self._layers is None or self._layers[0] != x.device:
+            mods, layers = list(self), []
+            for i, m in enumerate(mods):
+                if isinstance(m, nn.Linear):
+                    layers.append(_folded(m, i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU), x.device))
+            object.__setattr__(self, "_layers", (x.device, layers))
+        lead = x.shape[:-1]
+        rows = x.reshape(-1, x.shape[-1]).contiguous()
+        for layer in self._layers[1]:
+            rows = layer(rows)
+        return rows.view(*lead, -1)
 
 
 def _host(t):
@@ -78,18 +186,46 @@ class AE(nn.Module):
 
     def __init__(self, K, k, d, L):
         super().__init__()
-        if d > 16:
-            raise _lib.PccxError("pccx.AE supports bottleneck d <= 16")
+        if d > 16 or d < 1 or d * L > 128 or K % 16 != 0 or not 16 <= K <= 1024:
+            raise _lib.PccxError(
+                f"pccx.AE: the fused kernels cover --d 1..16 (got {d}), --d * --L <= 128 (got {d * L}) and --K a multiple of 16 "
+                f"in 16..1024 (got {K}); the reference's defaults are --K 256 --d 16 --L 7 (compress.py:30-34)")
         self.sa = SetAbstraction(npoint=K, K=16, in_channel=0, mlp=[32, 64, 128])
         self.pn = PointNet(3 + 128, [128, 256, 512, d], [True, True, True, False])
-        self.inv_pool = nn.Sequential(nn.Linear(d, 256), nn.ReLU(), nn.Linear(256, 1024), nn.ReLU(),
-                                      nn.Linear(1024, k * 128), nn.ReLU())
+        self.inv_pool = LinearStack(nn.Linear(d, 256), nn.ReLU(), nn.Linear(256, 1024), nn.ReLU(),
+                                    nn.Linear(1024, k * 128), nn.ReLU())
         self.inv_mlp = MLP(d + 128, [128, 64, 32, 3], [True, True, True, False])
         self.K, self.k, self.d, self.L = K, k, d, L
         self._enc_blob = self._dec_blob = None
+        self.sa._own(self._sa_call)
+        self.pn._own(self._pn_call)
 
-    def quantize(self, x):          # AE.STEQuantize.forward (AE.py:79-81)
-        return x.round()
+    def quantize(self, x):          # AE.STEQuantize.forward (AE.py:79-81); straight-through gradient (AE.py:83-85)
+        from .ops import ste_round
+        return ste_round(x)
+
+    # ---- the reference's per-module calls (compress.py:113-121), on the fused kernels ----------------------------
+    def _sa_call(self, x):
+        """ae.sa(x): x [P, 3, K] -> (new_xyz [P, 3, K] (= x, npoint == K, pn_kit.py:180-181), features [P, 128, K])."""
+        P, _, K = x.shape
+        if K % 16 != 0 or not 16 <= K <= 1024:
+            raise _lib.PccxError(f"ae.sa: K={K} must be a multiple of 16 in 16..1024")
+        patches = x.permute(0, 2, 1).contiguous()
+        feat = torch.empty(P, 8, K, 16, device=x.device, dtype=torch.float32)
+        self._launch_sa(patches, feat, _pccx_default_matmul())
+        return x, feat.permute(0, 1, 3, 2).reshape(P, 128, K)
+
+    def _pn_call(self, points):
+        """ae.pn(cat(x_patches, features)): [P, 3 + 128, K] -> raw latent [P, d] (before the sigmoid of compress.py:126)."""
+        x = _f32c(points, "ae.pn")
+        if x.dim() != 3 or x.shape[1] != 131 or x.shape[2] % 16 != 0 or not 16 <= x.shape[2] <= 1024:
+            return None                                   # not the fused kernel's shape: generic path
+        P, _, K = x.shape
+        patches = x[:, :3].permute(0, 2, 1).contiguous()
+        feat = x[:, 3:].reshape(P, 8, 16, K).permute(0, 1, 3, 2).contiguous()
+        outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
+        self._launch_pn(patches, feat, outs, _pccx_default_matmul())
+        return outs[0]
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -125,7 +261,7 @@ class AE(nn.Module):
         return self._enc_blob, self._dec_blob
 
     def _sa_b3_blob(self, device):
-        """EXPERIMENTAL: bf16x3 planes of the SetAbstraction conv1 / conv2 weights, built on the device."""
+        """bf16x3 planes of the SetAbstraction conv1 / conv2 weights, built on the device."""
         enc, _ = self._blobs(device)
         if getattr(self, "_sa_b3", None) is None or self._sa_b3.device != enc.device:
             self._sa_b3 = torch.empty(_lib.load().pccx_sa_b3_blob_floats(), device=enc.device, dtype=torch.float32)
@@ -133,55 +269,66 @@ class AE(nn.Module):
         return self._sa_b3
 
     def _pn_b3_blob(self, device):
-        """EXPERIMENTAL: bf16x3 planes of the PointNet weight stream, built on the device."""
+        """bf16x3 planes of the PointNet weight stream, built on the device."""
         enc, _ = self._blobs(device)
         if getattr(self, "_pn_b3", None) is None or self._pn_b3.device != enc.device:
             self._pn_b3 = torch.empty(_lib.load().pccx_pn_b3_blob_floats(), device=enc.device, dtype=torch.float32)
             _lib.call("pccx_pack_pn_b3", enc.data_ptr(), self._pn_b3.data_ptr(), _stream())
         return self._pn_b3
 
-    def encode(self, patches, sa_matmul="f32", pn_matmul="f32"):
-        """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
-        = ae.sa + ae.pn + sigmoid spread + round (compress.py:113-127, AE.py:37-45).
-        sa_matmul / pn_matmul = "bf16x3" (EXPERIMENTAL, opt-in): SetAbstraction conv1 / conv2, the PointNet chain as fp32 products of three bf16 pieces per
-        operand on the bf16 matrix cores (fp32-level error; a latent within ~1e-6 of a rounding boundary may flip)."""
-        x = _f32c(patches, "AE.encode")
+    def _launch_sa(self, x, feat, matmul):
         P, K, _ = x.shape
         enc, _ = self._blobs(x.device)
+        if matmul == "bf16x3":
+            _lib.call("pccx_sa_forward_b3", x.data_ptr(), P, K, enc.data_ptr(), self._sa_b3_blob(x.device).data_ptr(),
+                      feat.data_ptr(), _stream())
+        elif matmul == "f32":
+            _lib.call("pccx_sa_forward", x.data_ptr(), P, K, enc.data_ptr(), feat.data_ptr(), _stream())
+        else:
+            raise ValueError(f"sa_matmul={matmul!r}: expected 'f32' or 'bf16x3'")
+
+    def _launch_pn(self, x, feat, outs, matmul):
+        P, K, _ = x.shape
+        enc, _ = self._blobs(x.device)
+        if matmul == "bf16x3":
+            _lib.call("pccx_pn_forward_b3", x.data_ptr(), feat.data_ptr(), P, K, enc.data_ptr(), self._pn_b3_blob(x.device).data_ptr(),
+                      self.d, self.L, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+        elif matmul == "f32":
+            _lib.call("pccx_pn_forward", x.data_ptr(), feat.data_ptr(), P, K, enc.data_ptr(), self.d, self.L,
+                      outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
+        else:
+            raise ValueError(f"pn_matmul={matmul!r}: expected 'f32' or 'bf16x3'")
+
+    def encode(self, patches, sa_matmul=None, pn_matmul=None):
+        """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
+        = ae.sa + ae.pn + sigmoid spread + round (compress.py:113-127, AE.py:37-45).
+        sa_matmul / pn_matmul: "f32" (exact-fp32 MFMA) or "bf16x3" (fp32 products of three bf16 pieces per operand on the
+        bf16 matrix cores: fp32-level error; a latent within ~1e-6 of a rounding boundary may round the other way);
+        None = pccx.DEFAULT_MATMUL."""
+        x = _f32c(patches, "AE.encode")
+        P, K, _ = x.shape
         ws = workspace("sa_feat", P * K * 128, x.device)
         outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
         with stage("sa_forward"):
-            if sa_matmul == "bf16x3":
-                _lib.call("pccx_sa_forward_b3", x.data_ptr(), P, K, enc.data_ptr(), self._sa_b3_blob(x.device).data_ptr(),
-                          ws.data_ptr(), _stream())
-            elif sa_matmul == "f32":
-                _lib.call("pccx_sa_forward", x.data_ptr(), P, K, enc.data_ptr(), ws.data_ptr(), _stream())
-            else:
-                raise ValueError(f"sa_matmul={sa_matmul!r}: expected 'f32' or 'bf16x3'")
+            self._launch_sa(x, ws, sa_matmul or _pccx_default_matmul())
         with stage("pn_forward"):
-            if pn_matmul == "bf16x3":
-                _lib.call("pccx_pn_forward_b3", x.data_ptr(), ws.data_ptr(), P, K, enc.data_ptr(), self._pn_b3_blob(x.device).data_ptr(),
-                          self.d, self.L, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
-            elif pn_matmul == "f32":
-                _lib.call("pccx_pn_forward", x.data_ptr(), ws.data_ptr(), P, K, enc.data_ptr(), self.d, self.L,
-                          outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
-            else:
-                raise ValueError(f"pn_matmul={pn_matmul!r}: expected 'f32' or 'bf16x3'")
+            self._launch_pn(x, ws, outs, pn_matmul or _pccx_default_matmul())
         return tuple(outs)
 
     def _b3_blob(self, device):
-        """EXPERIMENTAL: bf16x3 planes of the decoder's big Linear, built on the device from the packed fp32 blob."""
+        """bf16x3 planes of the decoder's big Linear, built on the device from the packed fp32 blob."""
         _, dec = self._blobs(device)
         if getattr(self, "_dec_b3", None) is None or self._dec_b3.device != dec.device:
             self._dec_b3 = torch.empty(_lib.load().pccx_dec_b3_blob_floats(self.k), device=dec.device, dtype=torch.float32)
             _lib.call("pccx_pack_ae_decoder_b3", dec.data_ptr(), self.k, self._dec_b3.data_ptr(), _stream())
         return self._dec_b3
 
-    def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01, matmul="f32"):
+    def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01, matmul=None):
         """latent_q (BS,d) -> decoded patches (BS,k,3) (AE.py:48-53).  With centres/center/longest/S/scale
         it returns instead the reassembled, denormalised cloud (B,S*k,3) of decompress.py:104-116.
-        matmul="bf16x3" (EXPERIMENTAL, opt-in) evaluates the 1024 -> k*128 Linear as fp32 products of three bf16
-        pieces per operand on the bf16 matrix cores: fp32-level error, not bit-identical to the default."""
+        matmul="bf16x3" evaluates the matrix products as fp32 products of three bf16 pieces per operand on the bf16
+        matrix cores (fp32-level error, not bit-identical to "f32"); None = pccx.DEFAULT_MATMUL."""
+        matmul = matmul or _pccx_default_matmul()
         q = _f32c(latent_q, "AE.decode")
         P = q.shape[0]
         _, dec = self._blobs(q.device)
@@ -263,14 +410,27 @@ class ConditionalProbabilityModel(nn.Module):
         return self.run(sampled_xyz, ("pmf",))["pmf"]
 
 
-def range_encode(cdf_int, latent_q, L, cap=None):
-    """torchac.encode_float_cdf on device: cdf_int (B,nsym,L+1) int32, latent_q (B,nsym) -> (bytes (B,cap) u8, nbytes (B))."""
+def range_cap(nsym):
+    """Default output capacity per cloud of the range coder: 16-bit frequencies with every symbol's frequency >= 1 cost at
+    most 16 bits per symbol, plus the flush."""
+    return int(nsym) * 2 + 16
+
+
+def range_encode(cdf_int, latent_q, L, cap=None, out=None, nb=None):
+    """torchac.encode_float_cdf on device: cdf_int (B,nsym,L+1) int32, latent_q (B,nsym) -> (bytes (B,cap) u8, nbytes (B)).
+    A cloud whose stream does not fit ``cap`` bytes comes back with a NEGATIVE nbytes; codec.Compressed.to_host() raises on it
+    (unreachable with the default cap).  out / nb: caller-provided dense destinations."""
     B = cdf_int.shape[0]
     nsym = cdf_int[0].numel() // (L + 1)
-    cap = cap or (nsym * 2 + 16)
     q = _f32c(latent_q.reshape(B, nsym), "range_encode")
-    out = torch.empty(B, cap, device=q.device, dtype=torch.uint8)
-    nb = torch.empty(B, device=q.device, dtype=torch.int32)
+    if out is None:
+        out = torch.empty(B, cap or range_cap(nsym), device=q.device, dtype=torch.uint8)
+    if nb is None:
+        nb = torch.empty(B, device=q.device, dtype=torch.int32)
+    cap = out.shape[1]
+    if (out.shape[0] != B or out.dtype != torch.uint8 or not out.is_contiguous() or tuple(nb.shape) != (B,)
+            or nb.dtype != torch.int32 or not nb.is_contiguous()):
+        raise _lib.PccxError("range_encode: out must be dense (B,cap) u8 and nb dense (B,) i32")
     _lib.call("pccx_range_encode", cdf_int.contiguous().data_ptr(), q.data_ptr(), B, nsym, int(L), out.data_ptr(), cap,
               nb.data_ptr(), _stream())
     return out, nb

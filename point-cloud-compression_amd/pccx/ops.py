@@ -210,6 +210,30 @@ class _ChamferFn(torch.autograd.Function):
         return gx, gy
 
 
+class _STERound(torch.autograd.Function):
+    """AE.STEQuantize (AE.py:72-85): forward x.round() (pccx_round: round half to even, as torch.round), backward the
+    incoming gradient unchanged (straight-through estimator)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = _f32c(x, "STEQuantize")
+        y = torch.empty_like(xc)
+        _lib.call("pccx_round", xc.data_ptr(), xc.numel(), y.data_ptr(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def ste_round(x):
+    """AE.STEQuantize.apply.  compress.py:127 hands over a HOST tensor (the script moved the latents to the CPU at :121):
+    such an input is uploaded, rounded by the kernel and returned on the caller's device -- there is no CPU compute path."""
+    if isinstance(x, torch.Tensor) and not x.is_cuda:
+        return _STERound.apply(x.cuda()).to(x.device)
+    return _STERound.apply(x)
+
+
 def chamfer_distance(x, y, batch_reduction="mean"):
     """pytorch3d.loss.chamfer_distance defaults (AE.py:67, eval.py:204): squared distances,
     point mean, both directions summed; returns (value, None).  Differentiable w.r.t. x and y for
@@ -225,19 +249,31 @@ def chamfer_distance(x, y, batch_reduction="mean"):
     return per.float(), None
 
 
-def octree_encode(centres, N, min_bpp):
+def octree_bits_capacity(S):
+    """Longest possible stream of S centres in bits (1 + 8*S*16); the packed rows are (cap + 7) // 8 bytes."""
+    return int(_lib.load().pccx_octree_bits_capacity(int(S)))
+
+
+def octree_encode(centres, N, min_bpp, out_bytes=None, out_nbytes=None):
     """pn_kit.encode_sampled_np (pn_kit.py:380-401) + binary_array_to_byte_array (:463-467),
     batched on the GPU.  centres (B,S,3).  Returns dict of device tensors:
-    bits (B,cap) u8 one byte per bit, nbits (B), depth (B), bytes (B,stride) u8, nbytes (B)."""
+    bits (B,cap) u8 one byte per bit, nbits (B), depth (B), bytes (B,stride) u8, nbytes (B).
+    out_bytes / out_nbytes: caller-provided dense destinations of that shape (codec.Compressed's packed buffer)."""
     centres = _f32c(centres, "octree_encode")
     B, S, _ = centres.shape
-    cap = _lib.load().pccx_octree_bits_capacity(S)
+    cap = octree_bits_capacity(S)
     dev = centres.device
+    if out_bytes is None:
+        out_bytes = torch.empty(B, (cap + 7) // 8, device=dev, dtype=torch.uint8)
+    if out_nbytes is None:
+        out_nbytes = torch.empty(B, device=dev, dtype=torch.int32)
+    if (tuple(out_bytes.shape) != (B, (cap + 7) // 8) or out_bytes.dtype != torch.uint8 or not out_bytes.is_contiguous()
+            or tuple(out_nbytes.shape) != (B,) or out_nbytes.dtype != torch.int32 or not out_nbytes.is_contiguous()):
+        raise _lib.PccxError("octree_encode: out_bytes must be dense (B, (cap+7)//8) u8 and out_nbytes dense (B,) i32")
     r = dict(bits=torch.empty(B, cap, device=dev, dtype=torch.uint8),
              nbits=torch.empty(B, device=dev, dtype=torch.int32),
              depth=torch.empty(B, device=dev, dtype=torch.int32),
-             bytes=torch.empty(B, (cap + 7) // 8, device=dev, dtype=torch.uint8),
-             nbytes=torch.empty(B, device=dev, dtype=torch.int32))
+             bytes=out_bytes, nbytes=out_nbytes)
     _lib.call("pccx_octree_encode", centres.data_ptr(), B, S, int(N), float(min_bpp), r["bits"].data_ptr(),
               r["nbits"].data_ptr(), r["depth"].data_ptr(), r["bytes"].data_ptr(), r["nbytes"].data_ptr(), _stream())
     return r

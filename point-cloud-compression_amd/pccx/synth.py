@@ -59,3 +59,29 @@ def cad_cloud(seed, n=8192):
 def cad_batch(first_seed, count, n=8192):
     """(count,n,3) float32; cloud i uses seed first_seed+i (default_rng(11+i))."""
     return np.stack([cad_cloud(first_seed + i, n) for i in range(count)])
+
+
+def room_cloud(seed, n=None):
+    """Room-like cloud for configs[3] (S3DIS Area_1 stand-in): floor, ceiling, four walls and a few boxes
+    (furniture), area-uniform samples, metres; ``n`` points (default: seeded, 0.5-1 M).  (n,3) float32, deterministic."""
+    rng = np.random.default_rng(seed)
+    if n is None:
+        n = int(rng.integers(500_000, 1_000_001))
+    W, D, H = rng.uniform(4, 12), rng.uniform(4, 10), rng.uniform(2.6, 3.6)
+    rects = [((0, 0, 0), (W, 0, 0), (0, D, 0)), ((0, 0, H), (W, 0, 0), (0, D, 0)),          # floor, ceiling
+             ((0, 0, 0), (W, 0, 0), (0, 0, H)), ((0, D, 0), (W, 0, 0), (0, 0, H)),          # walls
+             ((0, 0, 0), (0, D, 0), (0, 0, H)), ((W, 0, 0), (0, D, 0), (0, 0, H))]
+    for _ in range(int(rng.integers(4, 10))):                                                # boxes standing on the floor
+        e = rng.uniform(0.3, 1.8, size=3) * np.array([1, 1, 0.7])
+        o = np.array([rng.uniform(0, W - e[0]), rng.uniform(0, D - e[1]), 0.0])
+        ex, ey, ez = np.diag(e)
+        rects += [(o, ex, ey), (o + ez, ex, ey), (o, ex, ez), (o + ey, ex, ez), (o, ey, ez), (o + ex, ey, ez)]
+    areas = np.array([np.linalg.norm(np.cross(np.asarray(u, float), np.asarray(v, float))) for _, u, v in rects])
+    counts = np.floor(areas / areas.sum() * n).astype(int)
+    counts[0] += n - counts.sum()
+    parts = []
+    for (o, u, v), c in zip(rects, counts):
+        ab = rng.uniform(0, 1, size=(int(c), 2))
+        parts.append(np.asarray(o, float) + ab[:, :1] * np.asarray(u, float) + ab[:, 1:] * np.asarray(v, float))
+    p = np.concatenate(parts) + rng.normal(0, 0.002, size=(n, 3))                            # sensor noise, 2 mm
+    return p[rng.permutation(n)].astype(np.float32)

@@ -11,6 +11,7 @@ What is executed from the reference, unmodified, imported from /root/reference:
     normalize / denormalize / pmf_to_cdf / PointNet / MLP / SetAbstraction (pn_kit.py)
   * AE.AE / AE.ConditionalProbabilityModel                           (AE.py)
   * PPPF_AE.PPPF_AE, pppe_pcd_ae.PointCloudAE forward                 (PPPF_AE.py, pppe_pcd_ae.py)
+  * eval.calc_uc (uniformity coefficient, eval.py:127-151)            (eval.py, imported with an argv that matches no file)
   * train_pppe_pcd_ae.set_model_and_loss / train_one_epoch (two iterations on CPU, scaler=None) with
     pppe_pcd_ae.RateDistortionLoss / estimate_bits_per_point_conditional (train_pppe_pcd_ae.py:171-252)
 
@@ -72,7 +73,36 @@ def _bind_absent_third_party():
         sys.modules[m.__name__] = m
 
 
+def make_eval_uc():
+    """7. eval.calc_uc (eval.py:127-151), the reference's own function: eval.py is a script (argparse + the evaluation
+    loop run at import), so it is imported with an argv whose glob matches nothing and an output file in a scratch
+    directory; open3d (absent) is a placeholder module -- calc_uc does not touch it; pytorch3d's knn_points inside it is
+    the oracle's definition, as everywhere (PARITY UNPINNED for its tie order)."""
+    import tempfile
+    _bind_absent_third_party()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+    tmp = tempfile.mkdtemp()
+    argv, cwd = sys.argv, os.getcwd()
+    sys.argv = ["eval.py", "--input_glob", os.path.join(tmp, "none", "*.ply"), "--output_file", os.path.join(tmp, "out.csv"),
+                "--device", "cpu"]
+    os.chdir(tmp)
+    try:
+        import eval as ref_eval                      # runs the (empty) evaluation loop, writes tmp/out.csv
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    torch.set_num_threads(1)
+    uc = np.array([ref_eval.calc_uc(a, b) for a, b in synth.uc_cases()], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "eval_uc.npz"), uc=uc)
+    print("eval_uc.npz", uc)
+
+
 def main():
+    if "--only-eval-uc" in sys.argv:
+        sys.argv.remove("--only-eval-uc")
+        return make_eval_uc()
     _bind_absent_third_party()
     sys.path.insert(0, REF)
     import octree_np as ref_octree
@@ -263,7 +293,8 @@ def main():
     tr["bn_running_var_sample"] = np.concatenate([synth.sample64(v.numpy()) for k, v in ae.named_buffers() if k.endswith("running_var")])
     np.savez_compressed(os.path.join(HERE, "train_step.npz"), **tr)
 
-    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz", "train_step.npz"):
+    make_eval_uc()
+    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz", "train_step.npz", "eval_uc.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -148,3 +148,20 @@ def sample64(a):
     """Up to 64 evenly strided entries of a tensor, flattened (keeps the fixtures small)."""
     f = np.asarray(a).reshape(-1)
     return f[:: max(1, f.size // 64)][:64].astype(np.float32)
+
+
+def uc_cases():
+    """(input cloud, decompressed cloud) pairs for eval.calc_uc (eval.py:127-151): a jittered copy in another order, a
+    decoder-like cloud (points regenerated on a coarser lattice around the input), and a subsampled-and-repeated cloud
+    (clumpy: a large coefficient).  8192 / 8192 / 6000 points, all with >= 1024 points as calc_uc's region needs."""
+    from pccx import synth as cloud_synth
+    out = []
+    a = cloud_synth.cad_cloud(41, 8192)
+    rng = np.random.default_rng(41)
+    out.append((a, (a + rng.normal(0, 1.5e-3, a.shape)).astype(np.float32)[rng.permutation(8192)]))
+    b = cloud_synth.cad_cloud(42, 8192)
+    out.append((b, (np.round(b * 96) / 96 + rng.normal(0, 8e-4, b.shape)).astype(np.float32)))
+    c = cloud_synth.cad_cloud(43, 6000)
+    sub = c[rng.permutation(6000)[:3000]]
+    out.append((c, np.concatenate([sub, sub + rng.normal(0, 2e-4, sub.shape).astype(np.float32)]).astype(np.float32)))
+    return out

@@ -20,6 +20,17 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 K, k, d, L = synth.MODEL_CFG
 
 
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def matmul_mode(request):
+    """Every test of this module runs in BOTH arithmetic modes of the three transforms at the SAME tolerances against
+    the oracle / golden fixtures: exact-fp32 MFMA, and fp32 products formed from three bf16 pieces per operand."""
+    import pccx
+    old = pccx.DEFAULT_MATMUL
+    pccx.DEFAULT_MATMUL = request.param
+    yield request.param
+    pccx.DEFAULT_MATMUL = old
+
+
 @pytest.fixture(scope="module")
 def nets():
     ae = models.AE(K, k, d, L)
@@ -116,14 +127,11 @@ def test_sa_knn_ties_on_lattice_patch(nets):
 
 
 def _sa_features(ae, patches):
-    """ae.sa through the C ABI: (P,K,3) -> (P,128,K) feature map (device layout [P][8][K][16])."""
-    from pccx import _lib
-    x = torch.from_numpy(patches).cuda().contiguous()
-    P, Kp, _ = x.shape
-    enc, _ = ae._blobs(x.device)
-    feat = torch.empty(P * 8 * Kp * 16, device="cuda", dtype=torch.float32)
-    _lib.call("pccx_sa_forward", x.data_ptr(), P, Kp, enc.data_ptr(), feat.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    return feat.view(P, 8, Kp, 16).permute(0, 1, 3, 2).reshape(P, 128, Kp).cpu().numpy()
+    """ae.sa as the reference calls it (compress.py:113-115): [P,3,K] -> (new_xyz, features [P,128,K]), current matmul mode."""
+    x = torch.from_numpy(patches).cuda().permute(0, 2, 1)
+    new_xyz, feat = ae.sa(x)
+    assert torch.equal(new_xyz, x)                      # npoint == K: the points themselves (pn_kit.py:180-181)
+    return feat.cpu().numpy()
 
 
 def test_sa_feature_map_with_ties_and_near_ties_at_the_16th_neighbour(nets):
@@ -269,8 +277,8 @@ def test_range_coder_other_alphabets_and_ragged_lengths(L, nsym):
         assert np.array_equal(cport.range_decode(cdf[b].astype(np.int32), want), sym[b])
 
 
-def test_decoder_bf16x3_experimental_matches_fp32_path(nets):
-    """EXPERIMENTAL opt-in: the decoder's 1024 -> k*128 Linear as fp32 products of three bf16 pieces per operand on
+def test_decoder_bf16x3_matches_fp32_path(nets):
+    """the decoder's 1024 -> k*128 Linear as fp32 products of three bf16 pieces per operand on
     the bf16 matrix cores.  Not bit-identical to the fp32 MFMA path; the bar is the same as any fp32 summation
     reorder: raw patches within 2e-6 absolute of the default path (values are O(0.1)) and within the decoder
     golden tolerance of the oracle."""
@@ -278,7 +286,7 @@ def test_decoder_bf16x3_experimental_matches_fp32_path(nets):
     rng = np.random.default_rng(21)
     for P in (1, 37, 300):
         lq = rng.integers(-3, 4, size=(P, d)).astype(np.float32)
-        a = ae.decode(torch.from_numpy(lq).cuda()).cpu().numpy()
+        a = ae.decode(torch.from_numpy(lq).cuda(), matmul="f32").cpu().numpy()
         b = ae.decode(torch.from_numpy(lq).cuda(), matmul="bf16x3").cpu().numpy()
         assert np.isfinite(b).all()
         assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max()), (P, np.abs(a - b).max(), np.abs(a).max())
@@ -293,13 +301,13 @@ def test_decoder_bf16x3_experimental_matches_fp32_path(nets):
     center = rng.random((B, 3)).astype(np.float32)
     longest = (rng.random(B) + 0.5).astype(np.float32)
     args = [torch.from_numpy(x).cuda() for x in (lq, centres, center, longest)]
-    p0 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0).cpu().numpy()
+    p0 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0, matmul="f32").cpu().numpy()
     p1 = ae.decode(args[0], args[1], args[2], args[3], S=S, scale=2.0, matmul="bf16x3").cpu().numpy()
     assert np.abs(p0 - p1).max() <= 4e-6 * max(1.0, np.abs(p0).max())
 
 
-def test_sa_bf16x3_experimental_matches_fp32_path(nets):
-    """EXPERIMENTAL opt-in: SetAbstraction conv1 / conv2 as bf16x3-split fp32 products.  Feature map within 1e-6 of the
+def test_sa_bf16x3_matches_fp32_path(nets):
+    """SetAbstraction conv1 / conv2 as bf16x3-split fp32 products.  Feature map within 1e-6 of the
     exact-fp32 kernel (features are O(0.1)), latents within 2e-6, symbols equal except at a rounding boundary."""
     from pccx import _lib
     ae = nets[0]
@@ -314,22 +322,22 @@ def test_sa_bf16x3_experimental_matches_fp32_path(nets):
     _lib.call("pccx_sa_forward_b3", x.data_ptr(), P, K, enc.data_ptr(), ae._sa_b3_blob(x.device).data_ptr(), f1.data_ptr(), st)
     a, b = f0.cpu().numpy(), f1.cpu().numpy()
     assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max()), (np.abs(a - b).max(), np.abs(a).max())
-    _, lat0, q0 = ae.encode(x)
-    _, lat1, q1 = ae.encode(x, sa_matmul="bf16x3")
+    _, lat0, q0 = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
+    _, lat1, q1 = ae.encode(x, sa_matmul="bf16x3", pn_matmul="f32")
     assert np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max() <= 2e-6
     _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
 
 
-def test_pointnet_bf16x3_experimental_matches_fp32_path(nets):
-    """EXPERIMENTAL opt-in: the PointNet chain (131->128->256->512->d) on bf16x3 operands, eight waves x one tile per pass,
+def test_pointnet_bf16x3_matches_fp32_path(nets):
+    """the PointNet chain (131->128->256->512->d) on bf16x3 operands, eight waves x one tile per pass,
     layer 2 k-outer in two halves.  Pre-sigmoid latents within 2e-5 relative of the exact-fp32 kernel (512-term sums of
     O(1) products), latents within 5e-6, symbols equal except at a rounding boundary; also against the oracle at the
     golden tolerance."""
     ae, _, oae, _ = nets
     patches = synth.patch_batch(K)
     x = torch.from_numpy(patches).cuda()
-    raw0, lat0, q0 = ae.encode(x)
-    raw1, lat1, q1 = ae.encode(x, pn_matmul="bf16x3")
+    raw0, lat0, q0 = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
+    raw1, lat1, q1 = ae.encode(x, sa_matmul="f32", pn_matmul="bf16x3")
     r0, r1 = raw0.cpu().numpy(), raw1.cpu().numpy()
     assert np.abs(r0 - r1).max() <= 2e-5 * max(1.0, np.abs(r0).max()), (np.abs(r0 - r1).max(), np.abs(r0).max())
     assert np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max() <= 5e-6
@@ -344,19 +352,19 @@ def test_pointnet_bf16x3_experimental_matches_fp32_path(nets):
 
 
 @pytest.mark.parametrize("Kx,kx,P", [(64, 32, 5), (512, 256, 3), (16, 8, 2)])
-def test_bf16x3_experimental_other_patch_sizes(Kx, kx, P):
-    """The experimental bf16x3 kernels at other patch sizes (K = 16: one tile, seven of PointNet's eight waves idle;
+def test_bf16x3_other_patch_sizes(Kx, kx, P):
+    """The bf16x3 kernels at other patch sizes (K = 16: one tile, seven of PointNet's eight waves idle;
     K = 512: four passes; other k for the decoder's per-point streams): same agreement with the exact-fp32 kernels."""
     ae = models.AE(Kx, kx, d, L)
     ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
     ae.pack("cuda")
     rng = np.random.default_rng(Kx + P)
     x = torch.from_numpy((rng.random((P, Kx, 3)).astype(np.float32) - 0.5)).cuda()
-    raw0, lat0, q0 = ae.encode(x)
+    raw0, lat0, q0 = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
     raw1, lat1, q1 = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3")
     assert np.abs(raw0.cpu().numpy() - raw1.cpu().numpy()).max() <= 2e-5 * max(1.0, float(raw0.abs().max()))
     assert np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max() <= 5e-6
     _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
-    a = ae.decode(q0).cpu().numpy()
+    a = ae.decode(q0, matmul="f32").cpu().numpy()
     b = ae.decode(q0, matmul="bf16x3").cpu().numpy()
     assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max())

@@ -17,6 +17,17 @@ pytestmark = pytest.mark.gpu
 K, k, d, L = synth.MODEL_CFG
 
 
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def matmul_mode(request):
+    """Every test of this module runs in BOTH arithmetic modes of the three transforms at the SAME tolerances against
+    the oracle / golden fixtures: exact-fp32 MFMA, and fp32 products formed from three bf16 pieces per operand."""
+    import pccx
+    old = pccx.DEFAULT_MATMUL
+    pccx.DEFAULT_MATMUL = request.param
+    yield request.param
+    pccx.DEFAULT_MATMUL = old
+
+
 @pytest.fixture(scope="module")
 def nets():
     ae = models.AE(K, k, d, L)
@@ -215,6 +226,64 @@ def test_large_cloud_block_partition_and_sharding(nets):
     assert sorted(seen) == list(range(nb))
 
 
+def test_room_scale_cloud_blocks_round_trip_and_block_oracle_parity(nets):
+    """configs[3] at its stated size (rooms of 0.5-1 M points, default_rng(100+i)): an 883 443-point room is
+    cut into 108 Morton blocks of 8192 points, the blocks are compressed by two "ranks" (block j -> rank j mod 2),
+    decoded and put back with the inverse permutation.  Properties: split / unsplit is the identity on the cloud (bit for
+    bit) and drops exactly the padding; every output row is written exactly once across the two ranks; a sampled block's
+    files equal the oracle's for the same block and FPS start (block-level parity: .s.bin / .c.bin bit-identical, latents
+    5e-5); each decoded block lies where its input block lies."""
+    from pccx import dist as pdist, large
+    ae, prob, oae, oprob = nets
+    pc_np = cloud_synth.room_cloud(100)
+    N = pc_np.shape[0]
+    assert 500_000 <= N <= 1_000_000
+    pc = torch.from_numpy(pc_np).cuda()
+    blocks, order, n_last = large.split_blocks(pc)
+    nb = (N + 8191) // 8192
+    assert blocks.shape == (nb, 8192, 3) and n_last == N - (nb - 1) * 8192
+    assert torch.equal(large.unsplit_blocks(blocks, list(range(nb)), order, N), pc)            # inverse permutation, padding dropped
+    cd = codec.Codec(ae, prob, K=K, octree_mode="reference")
+    out = torch.full((N, 3), float("nan"), device="cuda")
+    written = torch.zeros(N, dtype=torch.int32, device="cuda")
+    comp_of, bits = {}, 0
+    for rank in range(2):
+        parts, nblk, order2, n_last2 = large.compress_large(cd, pc, seed=11, rank=rank, world=2, batch=32)
+        assert nblk == nb and n_last2 == n_last and torch.equal(order2, order)
+        mine = torch.full((N, 3), float("nan"), device="cuda")
+        large.decompress_large(cd, parts, nblk, order, N, out=mine)
+        ok = torch.isfinite(mine).all(dim=1)
+        written += ok.int()
+        out[ok] = mine[ok]
+        for ids, comp in parts:
+            bits += int(comp.bits().sum())
+            for slot, j in enumerate(ids):
+                comp_of[j] = (comp, slot)
+    assert int(written.min()) == 1 and int(written.max()) == 1                                 # every point of the room exactly once
+    assert sorted(comp_of) == list(range(nb))
+    assert 0.3 < bits / (nb * 8192) < 1.5
+    # block-level oracle parity on sampled blocks (first, a middle one, the padded last one)
+    torch.set_num_threads(8)
+    for j in (0, nb // 3, nb - 1):
+        comp, slot = comp_of[j]
+        o, _ = ref_pipeline.compress_one(blocks[j].cpu().numpy(), oae, oprob, pdist.fps_start_index(11, j, 8192), K=K)
+        s, p, c = comp.files(slot)
+        assert s == o["s"] and c == o["c"]
+        sym = cport.range_decode(o["cdf_int"], p) if len(p) else None
+        if sym is not None and np.array_equal(sym.astype(np.float32) - L // 2, o["latent_q"].reshape(-1)):
+            assert p == o["p"]
+    # placement: the decoded rows of block j sit inside block j's (slightly grown) bounding box
+    lo, hi = blocks.amin(1), blocks.amax(1)
+    ext = (hi - lo).amax(1, keepdim=True)
+    pos = torch.arange(N, device="cuda")
+    rows = out[order]                                                                           # back in Morton order
+    blk = pos // 8192
+    inside = ((rows >= (lo - 0.75 * ext)[blk]) & (rows <= (hi + 0.75 * ext)[blk])).all(dim=1)
+    assert float(inside.float().mean()) > 0.99
+    psnr = float(codec.d1_psnr(pc[None], out[None])[0])
+    assert np.isfinite(psnr) and psnr > 15.0
+
+
 def test_modelnet40_test_set_scale_round_trip(nets):
     """BASELINE.json's full size: 2468 clouds x 8192 points (the ModelNet40 test split), in batches of 512.
     Size-independent properties only: the decoder recovers every symbol the encoder produced, every stream is
@@ -252,14 +321,14 @@ def test_modelnet40_test_set_scale_round_trip(nets):
     assert len(hashlib.sha256(b"".join(digests)).hexdigest()) == 64
 
 
-def test_bf16x3_experimental_agrees_with_fp32_at_scale(nets):
-    """EXPERIMENTAL opt-in kernels (SetAbstraction, PointNet, decoder on bf16x3 operands) against the exact-fp32 product
+def test_bf16x3_agrees_with_fp32_at_scale(nets):
+    """The bf16x3 kernels (SetAbstraction, PointNet, decoder on bf16x3 operands) against the exact-fp32 product
     path on 512 full-size clouds (524 288 symbols): a symbol may differ only where the fp32 latent sits within 1e-5 of a
     rounding boundary, at most a few per million do, the streams of every other cloud are byte-identical, and the
     reconstructions agree to 1e-5 of the cloud size wherever the symbols agree."""
     ae, prob, _, _ = nets
-    f32 = codec.Codec(ae, prob, K=K, octree_mode="reference")
-    b3 = codec.Codec(ae, prob, K=K, octree_mode="reference", decoder_matmul="bf16x3", sa_matmul="bf16x3", pn_matmul="bf16x3")
+    f32 = codec.Codec(ae, prob, K=K, octree_mode="reference", matmul="f32")
+    b3 = codec.Codec(ae, prob, K=K, octree_mode="reference", matmul="bf16x3")
     n = 512
     base = cloud_synth.cad_batch(3000, 64, 8192)
     rng = np.random.default_rng(3)

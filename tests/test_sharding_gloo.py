@@ -93,3 +93,36 @@ def test_bucketed_gradient_allreduce_two_ranks():
         want = (res[0][3][i] + res[1][3][i]) / 2
         np.testing.assert_allclose(res[0][2][i], want, rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(res[1][2][i], want, rtol=1e-6, atol=1e-7)
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with NO torchrun environment starts its own two rank processes (pccx/launch.py) before
+    anything touches a GPU, rendezvous on 127.0.0.1, and rank 0 prints exactly one JSON line carrying n_gpus = 2 and the
+    all-gathered dist.SUMMARY_FIELDS reduction.  (launch-check does no GPU work; gloo stands in for RCCL on CPU.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload",
+                        "launch-check", "--steps", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]      # gloo itself prints a connection note on stdout
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3
+    s = j["summary"]                                            # ranks contributed (1000, 8192, 30, 1e-4, 1, 0.5) * (r+1)-ish
+    assert s["files"] == 3 and abs(s["bpp"] - 3000.0 / (3 * 8192)) < 1e-12
+    assert abs(s["d1_psnr_db"] - (30.0 + 31.0) / 3) < 1e-12
+    assert abs(s["points_per_s"] - 3 * 8192 / 1.5) < 1e-9      # sum of points / MAX of seconds
+
+
+def test_launcher_propagates_a_failing_rank(tmp_path):
+    from pccx import launch
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\nr = int(os.environ['RANK'])\nassert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if r == 1:\n    sys.exit(7)\ntime.sleep(30)\n")
+    import time
+    t0 = time.time()
+    assert launch.spawn_ranks(str(script), [], 2) == 7          # rank 1 fails -> rank 0 is terminated, its code reported
+    assert time.time() - t0 < 20
