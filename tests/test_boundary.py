@@ -249,7 +249,10 @@ def test_torch_ops_agree_with_the_direct_path_and_chamfer_autograd():
     assert torch.equal(i0, r.idx) and torch.equal(d0, r.dists) and torch.equal(n0, r.knn)
     bits = torch.ops.pccx.octree_encode(pc[:, :64].contiguous(), 2048, 0.25)
     want = ops.octree_encode(pc[:, :64].contiguous(), 2048, 0.25)
-    assert torch.equal(bits[3], want["bytes"]) and torch.equal(bits[4], want["nbytes"])
+    assert torch.equal(bits[4], want["nbytes"]) and torch.equal(bits[1], want["nbits"])
+    for b in range(2):                                   # bytes past nbytes are scratch
+        n = int(bits[4][b])
+        assert torch.equal(bits[3][b, :n], want["bytes"][b, :n])
     x = pc[:, :300].clone().requires_grad_(True)
     y = pc[:, 300:900].clone().requires_grad_(True)
     loss = torch.ops.pccx.chamfer_distance(x, y)[0]
@@ -257,7 +260,10 @@ def test_torch_ops_agree_with_the_direct_path_and_chamfer_autograd():
     x2, y2 = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
     l2, _ = ops.chamfer_distance(x2, y2)
     l2.backward()
-    assert torch.equal(loss.detach(), l2.detach()) and torch.equal(x.grad, x2.grad) and torch.equal(y.grad, y2.grad)
+    assert torch.equal(loss.detach(), l2.detach())
+    # the backward scatters with float atomics (several x may share a nearest y): summation order is not fixed
+    torch.testing.assert_close(x.grad, x2.grad, rtol=1e-5, atol=1e-10)
+    torch.testing.assert_close(y.grad, y2.grad, rtol=1e-5, atol=1e-10)
     z = torch.tensor([0.5, 1.5, -0.2], device="cuda", requires_grad=True)
     torch.ops.pccx.ste_round(z).sum().backward()
     assert torch.equal(z.grad, torch.ones(3, device="cuda"))
