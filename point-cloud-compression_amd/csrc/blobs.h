@@ -101,3 +101,4 @@
 #define PRB_STREAM_FRAGS (17 * 32 + 16 * (32 * 2 + 2 * 8))
 #define PRB_STREAM_CHUNKS (4 * ((PRB_STREAM_FRAGS + 4 * PRB_WS_CHUNK - 1) / (4 * PRB_WS_CHUNK)))      // multiple of the ring depth
 #define PRB_BLOB_FLOATS (PRB_STREAM + (size_t)PRB_STREAM_CHUNKS * PRB_WS_CHUNK * 256)
+
