@@ -206,6 +206,14 @@ PCCX_API int pccx_pack_pn_b3(const float *enc_blob_dev, float *pn_b3_blob_dev, v
 PCCX_API int pccx_pn_forward_b3(const float *patches, const float *feat, int P, int K, const float *enc_blob,
                                 const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
                                 float *latent_q, void *stream);
+/* pccx_sa_forward_b3 + pccx_pn_forward_b3 in ONE kernel (compress.py:113-127: ae.sa, ae.pn, sigmoid spread, round): the
+ * (P,128,K) feature map of ae.sa stays inside the CU instead of making a round trip through HBM.  Same blobs, same arithmetic
+ * and results as the two calls.  pccx_ae_encode_b3_fused_ok(K) tells whether a K-point patch fits the kernel's LDS budget
+ * (K <= 512); otherwise run the two calls through a feature workspace. */
+PCCX_API int pccx_ae_encode_b3_fused_ok(int K);
+PCCX_API int pccx_ae_encode_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
+                               const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
+                               float *latent_q, void *stream);
 PCCX_API size_t pccx_dec_b3_blob_floats(int k);
 PCCX_API int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream);
 PCCX_API size_t pccx_ae_decode_b3_workspace_floats(int P);

@@ -1,0 +1,286 @@
+// encoder_fused.hip -- the whole analysis transform of AE.AE (AE.py:34-45) in ONE kernel, bf16x3 arithmetic:
+//   SetAbstraction (pn_kit.py:146-211) -> PointNet (pn_kit.py:98-144) -> sigmoid spread + round (AE.py:43-45)
+// without the (P,128,K) feature map ever leaving the CU.  encoder.hip runs the two modules as two kernels with the map in
+// HBM between them (8.4 MB per cloud written and read back: 18.6 GB per 1024 clouds against 0.2 GB of patches and weights);
+// here a wave's SetAbstraction output for 16 points IS its PointNet input tile and is handed over through 8 KiB of LDS:
+//
+//   workgroup = one patch, eight waves.  Per pass over 128 points (wave w owns points 16(8 it + w) ..):
+//     SA   : the wave's 16 points, two at a time (the 16 lanes of a DPP row are the 16 neighbours), exactly the arithmetic of
+//            sa_forward_kernel<true>; the 128 channel maxima of each point go to the wave's own staging rows in LDS
+//            ([point][132] floats: the pad makes the transposed read-back conflict-free);
+//     hand : the wave reads the rows back as PointNet's B operand (channel 16 kt + 4 g + r of point n in lane (g, n)) and
+//            splits them into bf16 planes -- no barrier, the rows are private to the wave;
+//     PN   : after one barrier (the weight ring shares LDS with the staging rows) the pass of pn_forward_b3_kernel: the
+//            1128-fragment weight stream through the LDS-DMA ring, layers 2 and 3 interleaved, running channel maximum.
+//   The ring starts cold in every pass (it may not prefetch into the staging rows): two exposed fills per 256-point patch.
+//
+// Arithmetic, weight blobs and results are those of pccx_sa_forward_b3 + pccx_pn_forward_b3 (same products, same order), so the
+// parity tests of the two-kernel path apply unchanged; tests/test_gpu_model.py also compares the two paths bit for bit.
+#include <math.h>
+
+#include "blobs.h"
+#include "common.h"
+#include "mfma_chain.h"
+
+#define FU_STAGE_STRIDE 132                               // floats per staged point: 128 channels + 4 (bank rotation)
+#define FU_STAGE_WAVE (16 * FU_STAGE_STRIDE)              // floats per wave
+#define FU_W1_FRAGS (1 * 4 * 3)
+#define FU_W2_FRAGS (2 * 8 * 3)
+
+__device__ __forceinline__ unsigned fu_umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// LDS map (bytes): [sw1 12 KiB][sw2 48 KiB][sb1 256][sb2 512][sx 12K][nbr 32K][region: max(ring 48 KiB, 8 staging blocks)]
+__host__ __device__ inline size_t fu_region_bytes()
+{
+    const size_t ring = (size_t)2 * PN_B3_CHUNK * 1024, stage = (size_t)8 * FU_STAGE_WAVE * 4;
+    return ring > stage ? ring : stage;
+}
+__host__ __device__ inline size_t fu_lds_bytes(int K)
+{
+    return (size_t)(FU_W1_FRAGS + FU_W2_FRAGS) * 1024 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32 + fu_region_bytes() + 8 * 16 * 4;
+}
+
+__global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *__restrict__ x, int K, const float *__restrict__ blob,
+                                                                  const float *__restrict__ sa3, const float *__restrict__ pn3, int d,
+                                                                  float spread, float half_spread, float *__restrict__ latent_raw,
+                                                                  float *__restrict__ latent, float *__restrict__ latent_q)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4 *sw1 = (f32x4 *)smem;
+    f32x4 *sw2 = sw1 + FU_W1_FRAGS * 64;
+    float *sb1 = (float *)(sw2 + FU_W2_FRAGS * 64);
+    float *sb2 = sb1 + 64;
+    float *sx = sb2 + 128;
+    unsigned short *nbr16 = (unsigned short *)(sx + 3 * K);
+    unsigned char *region = (unsigned char *)(nbr16 + 16 * K);          // 16-byte aligned: K % 16 == 0
+    f32x4 *swt = (f32x4 *)region;                                       // PointNet weight ring (2 x 24 KiB)
+    float *stage_all = (float *)region;                                 // ... or the eight staging blocks
+    float (*smax)[16] = (float (*)[16])(region + fu_region_bytes());
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const size_t P = blockIdx.x;
+    const float *xp = x + P * (size_t)K * 3;
+    const int ntiles = K >> 4;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    float *stage = stage_all + wu * FU_STAGE_WAVE;
+
+    {   // stage SetAbstraction weights + the patch
+        const f32x4 *gw1 = (const f32x4 *)sa3, *gw2 = (const f32x4 *)sa3 + FU_W1_FRAGS * 64;
+        for (int i = tid; i < FU_W1_FRAGS * 64; i += 512) sw1[i] = gw1[i];
+        for (int i = tid; i < FU_W2_FRAGS * 64; i += 512) sw2[i] = gw2[i];
+        if (tid < 64) sb1[tid] = blob[ENC_SA_B1 + tid];
+        if (tid < 128) sb2[tid] = blob[ENC_SA_B2 + tid];
+        for (int i = tid; i < 3 * K; i += 512) sx[i] = xp[i];
+    }
+    __syncthreads();
+
+    // ---- kNN-16 inside the patch (pn_kit.py:190): as sa_forward_kernel, one point per thread
+    unsigned jmask = 15u;
+    while ((int)jmask < K - 1) jmask = 2u * jmask + 1u;
+    for (int i = tid; i < K; i += 512) {
+        const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
+        unsigned tk[17];
+#pragma unroll
+        for (int s = 0; s < 17; ++s) tk[s] = 0xFFFFFFFFu;
+        for (int j0 = 0; j0 < K; j0 += 4) {
+            float dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dd[u] = pccx_sqdist(px, py, pz, sx[3 * (j0 + u)], sx[3 * (j0 + u) + 1], sx[3 * (j0 + u) + 2]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned key = (__float_as_uint(dd[u]) & ~jmask) | (unsigned)(j0 + u);
+#pragma unroll
+                for (int s = 16; s >= 1; --s) tk[s] = fu_umed3(tk[s - 1], key, tk[s]);
+                tk[0] = min(tk[0], key);
+            }
+        }
+        if (((tk[15] ^ tk[16]) & ~jmask) != 0u) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)(tk[s] & jmask);
+            continue;
+        }
+        float td[16];                                    // tie or near-tie at the boundary: the exact (distance, index) rule
+#pragma unroll
+        for (int s = 0; s < 16; ++s) td[s] = INFINITY;
+        for (int j = 0; j < K; ++j) {
+            const float dj = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
+#pragma unroll
+            for (int s = 15; s >= 1; --s) td[s] = __builtin_amdgcn_fmed3f(td[s - 1], dj, td[s]);
+            td[0] = fminf(td[0], dj);
+        }
+        const float T = td[15];
+        int need = 16;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) need -= td[s] < T ? 1 : 0;
+        int c = 0, ties = 0;
+        for (int j = 0; j < K; ++j) {
+            const float dj = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
+            const bool tie = dj == T;
+            if (dj < T || (tie && ties < need)) {
+                if (c < 16) nbr16[i * 16 + c] = (unsigned short)j;
+                ++c;
+            }
+            ties += tie ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 run;                                            // running max, channel 4g+r
+    run[0] = run[1] = run[2] = run[3] = -INFINITY;
+    const int passes = (ntiles + 7) / 8;                  // identical for all waves: barriers inside
+    for (int it = 0; it < passes; ++it) {
+        const int tile = it * 8 + w;
+        const bool valid = tile < ntiles;
+        const int p0 = (valid ? tile : 0) * 16;           // an idle wave recomputes tile 0 and discards it
+
+        // ---- SetAbstraction for points p0 .. p0+15, two per iteration (sa_forward_kernel<true>'s body)
+        for (int i0 = p0; i0 < p0 + 16; i0 += 2) {
+            f32x4 h0[2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int i = i0 + nt;
+                const int j = nbr16[i * 16 + n];
+                const float rel = g < 3 ? __fsub_rn(sx[3 * j + g], sx[3 * i + g]) : 1.0f;      // grouped_xyz -= new_xyz; bias input
+                h0[nt][0] = relu4(mfma16(w0a, rel, zero4));
+                h0[nt][1] = relu4(mfma16(w0b, rel, zero4));
+            }
+            f32x4 a1[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a1[0][mt] = a1[1][mt] = *(const f32x4 *)(sb1 + 16 * mt + 4 * g);
+            f32x4 a2[2][8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const float bv = sb2[16 * mt + n];
+                f32x4 b4 = {bv, bv, bv, bv};
+                a2[0][mt] = b4; a2[1][mt] = b4;
+            }
+            bf16x8 i1[2][1][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b3_split8(h0[nt][0], h0[nt][1], i1[nt][0]);
+            dense_b3<1, 4, 2>(sw1, lane, i1, a1);                                    // conv1
+            bf16x8 i2[2][2][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) b3_split8(relu4(a1[nt][2 * t]), relu4(a1[nt][2 * t + 1]), i2[nt][t]);
+            dense_b3<2, 8, 2, true>(sw2, lane, i2, a2);                              // conv2, transposed
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float mx[2];
+                max16_of_8_transposed_tiles(a2[nt], mx);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)           // lane (row g, j = n) holds channel 16*(2g + s2) + n of point i0 + nt
+                    stage[(i0 + nt - p0) * FU_STAGE_STRIDE + 16 * (2 * g + s2) + n] = fmaxf(mx[s2], 0.f);
+            }
+        }
+
+        // ---- hand-over: the wave's own rows, read back as PointNet's B operand and split into planes
+        bf16x8 i0p[1][5][3];
+        {
+            f32x4 in[9];
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) in[kt] = *(const f32x4 *)(stage + n * FU_STAGE_STRIDE + 16 * kt + 4 * g);
+            const int p = p0 + n;
+            in[8][0] = g == 0 ? sx[3 * p] : 0.f;          // channels 128,129,130 = x,y,z (g == 0, r = 0..2)
+            in[8][1] = g == 0 ? sx[3 * p + 1] : 0.f;
+            in[8][2] = g == 0 ? sx[3 * p + 2] : 0.f;
+            in[8][3] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b3_split8(in[2 * t], in[2 * t + 1], i0p[0][t]);
+            b3_split8(in[8], zero4, i0p[0][4]);
+        }
+        __syncthreads();                                  // every wave has its tile in registers: the region becomes the weight ring
+
+        // ---- PointNet pass (pn_forward_b3_kernel's), ring started cold
+        blob = opaque_uniform(blob);
+        WStreamT<PN_B3_CHUNK, 2, 8> ws{opaque_uniform(pn3), swt, (PN_B3_STREAM_FRAGS + PN_B3_CHUNK - 1) / PN_B3_CHUNK, lane, wu, false};   // data chunks only
+        ws.prologue();
+        int f = 0;                                        // fragment cursor of this pass (constant-folds)
+        f32x4 a0[1][8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a0[0][mt] = *(const f32x4 *)(blob + ENC_PN_B0 + 16 * mt + 4 * g);
+        dense_b3_stream<5, 8, 1>(ws, f, i0p, a0);
+        f32x4 a1p[1][16];
+        {
+            bf16x8 i1p[1][4][3];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b3_split8(relu4(a0[0][2 * t]), relu4(a0[0][2 * t + 1]), i1p[0][t]);
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a1p[0][mt] = *(const f32x4 *)(blob + ENC_PN_B1 + 16 * mt + 4 * g);
+            dense_b3_stream<4, 16, 1>(ws, f, i1p, a1p);
+        }
+        f32x4 a3[1][1];
+        a3[0][0] = *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
+#pragma clang loop unroll(full)
+        for (int h = 0; h < 2; ++h) {                     // layer 2 in two halves of 16 output tiles
+            f32x4 a2p[1][16];
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a2p[0][mt] = *(const f32x4 *)(blob + ENC_PN_B2 + 16 * (16 * h + mt) + 4 * g);
+#pragma clang loop unroll(full)
+            for (int kt = 0; kt < 8; ++kt) {
+                bf16x8 pl[1][1][3];
+                b3_split8(relu4(a1p[0][2 * kt]), relu4(a1p[0][2 * kt + 1]), pl[0][0]);
+                dense_b3_stream<1, 16, 1>(ws, f, pl, a2p);
+            }
+#pragma clang loop unroll(full)
+            for (int kt = 0; kt < 8; ++kt) {              // layer 3 over these 256 channels (no ReLU after it, AE.py:17)
+                bf16x8 pl[1][1][3];
+                b3_split8(relu4(a2p[0][2 * kt]), relu4(a2p[0][2 * kt + 1]), pl[0][0]);
+                dense_b3_stream<1, 1, 1>(ws, f, pl, a3);
+            }
+        }
+        ws.drain();
+        __syncthreads();                                  // every wave is done reading the ring: the region is staging again
+        if (valid)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) run[r] = fmaxf(run[r], row16_max(a3[0][0][r]));
+    }
+    if (n == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) smax[w][4 * g + r] = run[r];
+    __syncthreads();
+    if (tid < 16 && tid < d) {
+        float m = smax[0][tid];
+#pragma unroll
+        for (int k8 = 1; k8 < 8; ++k8) m = fmaxf(m, smax[k8][tid]);                                    // torch.max(points, 2)
+        const float s = 1.0f / (1.0f + expf(-m));
+        const float y = __fsub_rn(__fmul_rn(s, spread), half_spread);
+        latent_raw[P * d + tid] = m;
+        latent[P * d + tid] = y;
+        latent_q[P * d + tid] = rintf(y);
+    }
+}
+
+// 1 when the fused kernel can hold a K-point patch (its neighbour table grows with K), 0 when the caller must run
+// pccx_sa_forward_b3 + pccx_pn_forward_b3 through a feature workspace instead.
+extern "C" int pccx_ae_encode_b3_fused_ok(int K)
+{
+    return (K >= 16 && K <= 1024 && K % 16 == 0 && fu_lds_bytes(K) <= (size_t)160 * 1024) ? 1 : 0;
+}
+
+extern "C" int pccx_ae_encode_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
+                                 const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent, float *latent_q, void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(patches && enc_blob && sa_b3_blob && pn_b3_blob && latent_raw && latent && latent_q, "pccx_ae_encode_b3: null pointer");
+    PCCX_CHECK_ARG(P >= 0 && pccx_ae_encode_b3_fused_ok(K), "pccx_ae_encode_b3: K=%d does not fit the fused kernel (pccx_ae_encode_b3_fused_ok)", K);
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode_b3: unsupported d=%d L=%d", d, L);
+    const float spread = (float)((double)L - 0.2);
+    const float half = (float)(((double)L - 0.2) / 2);
+    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_pn_forward_b3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+    hipLaunchKernelGGL(sa_pn_forward_b3_kernel, dim3(P), dim3(512), fu_lds_bytes(K), (hipStream_t)stream, patches, K, enc_blob, sa_b3_blob,
+                       pn_b3_blob, d, spread, half, latent_raw, latent, latent_q);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

@@ -45,6 +45,8 @@ _SIGNATURES = {
     "pccx_pn_b3_blob_floats": [],
     "pccx_pack_pn_b3": [_P, _P, _P],
     "pccx_pn_forward_b3": [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P],
+    "pccx_ae_encode_b3_fused_ok": [C.c_int],
+    "pccx_ae_encode_b3": [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P],
     "pccx_dec_b3_blob_floats": [C.c_int],
     "pccx_pack_ae_decoder_b3": [_P, C.c_int, _P, _P],
     "pccx_ae_decode_b3_workspace_floats": [C.c_int],

@@ -299,20 +299,29 @@ class AE(nn.Module):
         else:
             raise ValueError(f"pn_matmul={matmul!r}: expected 'f32' or 'bf16x3'")
 
-    def encode(self, patches, sa_matmul=None, pn_matmul=None):
+    def encode(self, patches, sa_matmul=None, pn_matmul=None, fused=True):
         """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
         = ae.sa + ae.pn + sigmoid spread + round (compress.py:113-127, AE.py:37-45).
         sa_matmul / pn_matmul: "f32" (exact-fp32 MFMA) or "bf16x3" (fp32 products of three bf16 pieces per operand on the
         bf16 matrix cores: fp32-level error; a latent within ~1e-6 of a rounding boundary may round the other way);
-        None = pccx.DEFAULT_MATMUL."""
+        None = pccx.DEFAULT_MATMUL.  fused=False forces the two-kernel path (feature map through HBM) in bf16x3 mode."""
         x = _f32c(patches, "AE.encode")
         P, K, _ = x.shape
-        ws = workspace("sa_feat", P * K * 128, x.device)
         outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
+        sa_matmul, pn_matmul = sa_matmul or _pccx_default_matmul(), pn_matmul or _pccx_default_matmul()
+        if fused and sa_matmul == pn_matmul == "bf16x3" and _lib.load().pccx_ae_encode_b3_fused_ok(K):
+            # one kernel, the (P,128,K) feature map never leaves the CU (csrc/encoder_fused.hip)
+            enc, _ = self._blobs(x.device)
+            with stage("sa_pn_forward"):
+                _lib.call("pccx_ae_encode_b3", x.data_ptr(), P, K, enc.data_ptr(), self._sa_b3_blob(x.device).data_ptr(),
+                          self._pn_b3_blob(x.device).data_ptr(), self.d, self.L, outs[0].data_ptr(), outs[1].data_ptr(),
+                          outs[2].data_ptr(), _stream())
+            return tuple(outs)
+        ws = workspace("sa_feat", P * K * 128, x.device)
         with stage("sa_forward"):
-            self._launch_sa(x, ws, sa_matmul or _pccx_default_matmul())
+            self._launch_sa(x, ws, sa_matmul)
         with stage("pn_forward"):
-            self._launch_pn(x, ws, outs, pn_matmul or _pccx_default_matmul())
+            self._launch_pn(x, ws, outs, pn_matmul)
         return tuple(outs)
 
     def _b3_blob(self, device):

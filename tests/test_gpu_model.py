@@ -368,3 +368,29 @@ def test_bf16x3_other_patch_sizes(Kx, kx, P):
     a = ae.decode(q0, matmul="f32").cpu().numpy()
     b = ae.decode(q0, matmul="bf16x3").cpu().numpy()
     assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max())
+
+
+@pytest.mark.parametrize("Kx,P", [(256, 7), (64, 5), (16, 3), (48, 2), (512, 3), (1024, 1)])
+def test_fused_encoder_kernel_equals_the_two_kernel_path_bit_for_bit(Kx, P):
+    """pccx_ae_encode_b3 (SetAbstraction + PointNet + quantiser in one kernel, the feature map handed over inside the CU)
+    against pccx_sa_forward_b3 + pccx_pn_forward_b3 through the HBM feature map: the same products in the same order, so
+    raw latents, latents and symbols are IDENTICAL.  K = 48 leaves five of the eight waves without a tile; K = 1024 does
+    not fit the fused kernel's LDS budget and must fall back to the two kernels transparently."""
+    from pccx import _lib
+    ae = models.AE(Kx, Kx // 2, d, L)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    ae.pack("cuda")
+    assert bool(_lib.load().pccx_ae_encode_b3_fused_ok(Kx)) == (Kx <= 512)
+    rng = np.random.default_rng(Kx * 31 + P)
+    x = torch.from_numpy((rng.random((P, Kx, 3)).astype(np.float32) - 0.5)).cuda()
+    x[0, : Kx // 2] = x[0, Kx // 2:]                                  # duplicated points: the tie path of the in-patch kNN
+    a = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=True)
+    b = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # and twice in a row on a big launch (ring / staging reuse across passes and patches)
+    if Kx == 256:
+        xb = torch.from_numpy((rng.random((600, Kx, 3)).astype(np.float32) - 0.5)).cuda()
+        a = ae.encode(xb, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=True)
+        b = ae.encode(xb, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=False)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
