@@ -250,7 +250,9 @@ PCCX_API int pccx_cdf_float_to_int(const float *cdf, int64_t nrows, int Lp, int3
  * pppe_pcd_ae.py:556-568,697-707) on row-major "channels last" activations, with eval-mode
  * BatchNorm folded into W and b by the caller: out[M][N] = act(x[M][K] . W^T + b).
  * pccx_pack_linear (HOST pointers): W (N,K) row-major -> pccx_packed_linear_floats(N,K) floats.
- * pccx_linear: x (M, ldx>=K), wp packed (device), bias (N) or NULL, relu 0/1, out (M, ldo>=N). */
+ * pccx_linear: x (M, ldx>=K), wp packed (device), bias (N) or NULL, out (M, ldo>=N); `relu` is a flag word: bit 0 = ReLU,
+ * bit 1 = the autocast form of train_pppe_pcd_ae.py:193-217 (operands and result rounded to bf16, products on the bf16
+ * matrix cores, fp32 accumulate; pccx_linear_dw takes the same bit 1 in `flags`). */
 PCCX_API size_t pccx_packed_linear_floats(int N, int K);
 PCCX_API int pccx_pack_linear(const float *W_host, int N, int K, float *wp_host);
 PCCX_API int pccx_linear(const float *x, int M, int K, int ldx, const float *wp, const float *bias,
@@ -275,7 +277,7 @@ PCCX_API int pccx_quantize_st(const float *x, int64_t n, float qmin, float qmax,
 PCCX_API int pccx_pack_linear_device(const float *W, int N, int K, int transpose, float *wp, void *stream);
 /* dW (N,K) += dZ^T (M,N) . X (M,K)   (dW must be initialised by the caller) */
 PCCX_API int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N, int K, int ldz, int ldx,
-                            float *dW, void *stream);
+                            float *dW, int flags, void *stream);
 /* BatchNorm{1,2}d in training mode (pppe_pcd_ae.py:556-568): batch moments per channel, running stats
  * updated with `momentum` (running_* may be NULL); then y = [relu]((z-mean)*rstd*gamma+beta). */
 PCCX_API int pccx_bn_train_stats(const float *Z, int64_t M, int C, float eps, float momentum, double *sums,

@@ -32,8 +32,23 @@ extern "C" int pccx_pack_linear(const float *W_host, int N, int K, float *wp_hos
     return PCCX_OK;
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4 to_bf16x4(const f32x4 &v)      // round to nearest even (v_cvt_pk_bf16_f32)
+{
+    return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4v));
+}
+__device__ __forceinline__ f32x4 round_bf16x4(const f32x4 &v)
+{
+    return __builtin_convertvector(__builtin_convertvector(v, bf16x4v), f32x4);
+}
+
 // out[M][N] = act(x[M][K] . W^T + b).  Block = 4 waves; wave = 32 rows (2 point tiles) x MTB*16 columns.
-template <int MTB, bool VEC>
+// BF16 = the autocast form (train_pppe_pcd_ae.py:193-217, torch.cuda.amp.autocast around the forward): both operands rounded to
+// bf16, products on the bf16 matrix cores (one v_mfma_f32_16x16x16_bf16 per k-tile: its lane map -- four consecutive k per
+// lane -- is exactly the f32 fragment's), fp32 accumulate, result rounded to bf16 (the layer's output dtype under autocast).
+template <int MTB, bool VEC, bool BF16>
 __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int M, int K, int ldx,
                                                      const f32x4 *__restrict__ wp, int KT, int MT,
                                                      const float *__restrict__ bias, int N, int relu,
@@ -73,10 +88,16 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
         for (int m = 0; m < MTB; ++m) {
             if (mt0 + m < MT) {                                   // uniform
                 const f32x4 a = wp[((size_t)kt * MT + mt0 + m) * 64 + lane];
+                if (BF16) {
+                    const s16x4 a16 = to_bf16x4(a);
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a16, to_bf16x4(bx[0]), acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a16, to_bf16x4(bx[1]), acc[1][m], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[0][m] = mfma16(a[r], bx[0][r], acc[0][m]);
-                    acc[1][m] = mfma16(a[r], bx[1][r], acc[1][m]);
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][m] = mfma16(a[r], bx[0][r], acc[0][m]);
+                        acc[1][m] = mfma16(a[r], bx[1][r], acc[1][m]);
+                    }
                 }
             }
         }
@@ -89,6 +110,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x
         for (int m = 0; m < MTB; ++m) {
             const int c = 16 * (mt0 + m) + 4 * g;
             f32x4 v = acc[nt][m];
+            if (BF16) v = round_bf16x4(v);
             if (relu) v = relu4(v);
             float *po = out + (size_t)row * ldo + c;
             if (VEC && c + 3 < N) {
@@ -115,12 +137,15 @@ extern "C" int pccx_linear(const float *x, int M, int K, int ldx, const float *w
     constexpr int MTB = 4;
     dim3 grid((M + 127) / 128, (MT + MTB - 1) / MTB);
     PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear: N=%d too large", N);
-    if (vec)
-        hipLaunchKernelGGL((linear_kernel<MTB, true>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp,
-                           KT, MT, bias, N, relu, out, ldo);
-    else
-        hipLaunchKernelGGL((linear_kernel<MTB, false>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp,
-                           KT, MT, bias, N, relu, out, ldo);
+    const bool bf16 = (relu & 2) != 0;                     // flags: bit 0 = ReLU, bit 1 = autocast (bf16 operands and result)
+    relu &= 1;
+#define PCCX_LIN_LAUNCH(V, B)                                                                                                  \
+    hipLaunchKernelGGL((linear_kernel<MTB, V, B>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp, KT, MT, \
+                       bias, N, relu, out, ldo)
+    if (vec && bf16) PCCX_LIN_LAUNCH(true, true);
+    else if (vec) PCCX_LIN_LAUNCH(true, false);
+    else if (bf16) PCCX_LIN_LAUNCH(false, true);
+    else PCCX_LIN_LAUNCH(false, false);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -47,6 +47,10 @@ extern "C" int pccx_pack_linear_device(const float *W, int N, int K, int transpo
 }
 
 // ---- dW[N][K] += sum_m dZ[m][n] * X[m][k]: one wave per (16 n x 16 k) tile and row slice
+__device__ __forceinline__ float round_bf16(float v) { return (float)(__bf16)v; }
+
+// BF16 = the autocast backward: dZ and X rounded to bf16 (their products are then exact in fp32), fp32 accumulate
+template <bool BF16>
 __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict__ dZ, const float *__restrict__ X, long M, int N,
                                                         int K, int ldz, int ldx, int rows_per_slice, float *__restrict__ dW)
 {
@@ -60,8 +64,9 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict_
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (long m = m0; m < m1; m += 4) {
         const long mm = m + g;                                       // MFMA k index = row within the 4-row step
-        const float a = (mm < m1 && n < N) ? dZ[(size_t)mm * ldz + n] : 0.f;     // A[i = n][k = g]
-        const float b = (mm < m1 && k < K) ? X[(size_t)mm * ldx + k] : 0.f;      // B[k = g][j = k]
+        float a = (mm < m1 && n < N) ? dZ[(size_t)mm * ldz + n] : 0.f;           // A[i = n][k = g]
+        float b = (mm < m1 && k < K) ? X[(size_t)mm * ldx + k] : 0.f;            // B[k = g][j = k]
+        if (BF16) { a = round_bf16(a); b = round_bf16(b); }
         acc = mfma16(a, b, acc);
     }
     // D[i = n-row 4g+r][j = k-col c]
@@ -72,7 +77,8 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict_
     }
 }
 
-extern "C" int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N, int K, int ldz, int ldx, float *dW, void *stream)
+extern "C" int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N, int K, int ldz, int ldx, float *dW, int flags,
+                              void *stream)
 {
     if (M == 0) return PCCX_OK;
     PCCX_CHECK_ARG(dZ && X && dW && N >= 1 && K >= 1 && ldz >= N && ldx >= K, "pccx_linear_dw: bad arguments");
@@ -83,7 +89,10 @@ extern "C" int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N,
     slices = (int)((M + rps - 1) / rps);
     dim3 grid((N + 15) / 16, ((K + 15) / 16 + 3) / 4, slices);
     PCCX_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "pccx_linear_dw: shape too large");
-    hipLaunchKernelGGL(linear_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
+    if (flags & 2)
+        hipLaunchKernelGGL(linear_dw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
+    else
+        hipLaunchKernelGGL(linear_dw_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

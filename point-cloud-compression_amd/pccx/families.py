@@ -185,6 +185,20 @@ class PPPF_AE(_Packable):
         return x.view(B, P, 3), latent, q
 
 
+def pppf_flops_per_patch(model):
+    """Algorithmic FLOPs (2 * MACs of every Conv / Linear, rows x in x out) of one PPPF_AE forward on one patch."""
+    if model._packed is None:
+        raise _lib.PccxError("pppf_flops_per_patch: pack() the model first")
+    pk, e = model._packed, model.encoder
+    macs = 0
+    for mod, stack in zip((e.sa1, e.sa2, e.sa3), pk["sa"]):
+        macs += sum(mod.npoint * mod.nsample * l.N * l.K for l in stack)
+    macs += pk["enc"].N * pk["enc"].K + pk["dec"].N * pk["dec"].K
+    P = model.decoder.num_points
+    macs += sum(P * l.N * l.K for l in pk["mlp1"]) + sum(P * l.N * l.K for l in pk["mlp2"])
+    return 2 * macs
+
+
 # =================================================================================================
 # pppe PointCloudAE
 # =================================================================================================

@@ -7,7 +7,11 @@
 
 torch.autograd only sequences the backward: every Function below is a pair of HIP launches behind the
 C ABI (include/pccx.h, csrc/train.hip); parameters and optimizer state are plain tensors in HBM.
-fp32 throughout (the reference's CUDA autocast path is not reproduced).  Correctness-first.
+fp32 by default.  ``train_step(..., autocast=True)`` is the reference's CUDA branch (torch.cuda.amp.autocast around the forward,
+train_pppe_pcd_ae.py:193-205; BASELINE configs[4] names bf16): every Linear / 1x1 Conv rounds its operands to bf16, multiplies
+on the bf16 matrix cores with fp32 accumulation and rounds its result to bf16; BatchNorm, max-pool, the quantiser, the losses,
+clipping and Adam stay fp32 on fp32 master weights, as under autocast; the backward GEMMs (dX, dW) round their operands the same
+way.  bf16 has fp32's exponent range, so no GradScaler is needed (the reference's scaler guards fp16).  Correctness-first.
 """
 import math
 
@@ -17,6 +21,7 @@ from . import _lib, families, ops
 from .ops import _stream
 
 _SCRATCH = {}
+_AUTOCAST = False          # set by train_step(autocast=True) around forward + backward
 
 
 def _sums(C, device):
@@ -34,11 +39,11 @@ def _packed(W, transpose):
     return wp
 
 
-def _linear_raw(x, wp, bias, N, K):
+def _linear_raw(x, wp, bias, N, K, flags=0):
     M = x.shape[0]
     out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    _lib.call("pccx_linear", x.data_ptr(), M, K, x.stride(0), wp.data_ptr(), bias.data_ptr() if bias is not None else None, N, 0,
-              out.data_ptr(), N, _stream())
+    _lib.call("pccx_linear", x.data_ptr(), M, K, x.stride(0), wp.data_ptr(), bias.data_ptr() if bias is not None else None, N,
+              int(flags), out.data_ptr(), N, _stream())
     return out
 
 
@@ -51,7 +56,8 @@ class LinearFn(torch.autograd.Function):
         W2 = W.reshape(W.shape[0], -1).contiguous()
         ctx.save_for_backward(x, W2)
         ctx.has_bias, ctx.wshape = b is not None, W.shape
-        return _linear_raw(x, _packed(W2, False), b, W2.shape[0], W2.shape[1])
+        ctx.flags = 2 if _AUTOCAST else 0
+        return _linear_raw(x, _packed(W2, False), b, W2.shape[0], W2.shape[1], ctx.flags)
 
     @staticmethod
     def backward(ctx, dz):
@@ -59,9 +65,9 @@ class LinearFn(torch.autograd.Function):
         dz = dz.contiguous()
         N, K = W2.shape
         M = x.shape[0]
-        dx = _linear_raw(dz, _packed(W2, True), None, K, N) if ctx.needs_input_grad[0] else None      # dX = dZ . W
+        dx = _linear_raw(dz, _packed(W2, True), None, K, N, ctx.flags) if ctx.needs_input_grad[0] else None      # dX = dZ . W
         dW = torch.zeros_like(W2)
-        _lib.call("pccx_linear_dw", dz.data_ptr(), x.data_ptr(), M, N, K, N, x.stride(0), dW.data_ptr(), _stream())
+        _lib.call("pccx_linear_dw", dz.data_ptr(), x.data_ptr(), M, N, K, N, x.stride(0), dW.data_ptr(), ctx.flags, _stream())
         db = None
         if ctx.has_bias:
             db = torch.zeros(N, device=dz.device, dtype=torch.float32)
@@ -299,16 +305,41 @@ class Adam:
         return acc
 
 
-def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_parallel=False, loss_type="chamfer"):
+def step_flops(model, batch):
+    """Algorithmic FLOPs of one training step's GEMMs for ``batch`` clouds: 2 * MACs of every Linear / 1x1 Conv of the forward
+    (rows x in x out), times 3 for forward + dX + dW (the first layers' dX on raw coordinates is not computed: negligible)."""
+    enc, dec = model.encoder, model.decoder
+    macs = 0
+    rows_in = {0: None}
+    sa = enc.sa_modules
+    for br in sa[0].branches:
+        rows = batch * br.npoint * br.K
+        for layer in br.mlp_stack:
+            macs += rows * layer[0].weight.shape[0] * layer[0].weight.shape[1]
+    for m in (sa[1], sa[2]):
+        rows = batch * m.npoint * m.K
+        for layer in m.mlp_stack:
+            macs += rows * layer[0].weight.shape[0] * layer[0].weight.shape[1]
+    for lin in (enc.global_conv[0], enc.global_conv[3], dec.fc_coarse[0], dec.fc_coarse[2], dec.expansion_mlp[0], dec.expansion_mlp[2]):
+        macs += batch * lin.weight.shape[0] * lin.weight[0].numel()
+    return 3 * 2 * macs
+
+
+def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_parallel=False, loss_type="chamfer", autocast=False):
     """One iteration of train_one_epoch (train_pppe_pcd_ae.py:184-226).  ``opt`` covers ae + prob
     parameters as the reference's optimizer does; returns (loss, dist, rate) as python floats.
     data_parallel=True averages the gradients over the ranks of the default process group (bucketed
     all-reduce, dist.allreduce_mean_) between backward and the clipped Adam step."""
+    global _AUTOCAST
     for p in opt.params:
         p.grad = None
-    coarse, fine, cond, y_q = forward_train(model, batch_x, starts)
-    fbpp = estimate_bits_per_point(model, y_q, cond.detach())
-    loss, dist, rate = rd_loss(fine, batch_x, fbpp, lam, loss_type)
+    _AUTOCAST = bool(autocast)              # the Linear layers of forward (and, through ctx.flags, of backward) take the bf16 form
+    try:
+        coarse, fine, cond, y_q = forward_train(model, batch_x, starts)
+        fbpp = estimate_bits_per_point(model, y_q, cond.detach())
+        loss, dist, rate = rd_loss(fine.float(), batch_x.float(), fbpp, lam, loss_type)      # :205 casts back to fp32 for the loss
+    finally:
+        _AUTOCAST = False
     loss.backward()
     if data_parallel:
         from . import dist as pdist

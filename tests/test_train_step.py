@@ -196,3 +196,70 @@ def test_training_step_matches_reference_run():
         assert d.max() <= 2.2e-3 * (it + 1), (it, d.max())
         if it == 0:
             assert np.median(d) <= 0.05 * 1e-3 and (d > 1e-4).mean() < 0.25, (np.median(d), (d > 1e-4).mean())
+
+
+@pytest.mark.gpu
+def test_autocast_linear_matches_bf16_operand_arithmetic():
+    """The autocast form of the generic layer (flags bit 1): operands rounded to bf16, exact products, fp32 accumulate, result
+    rounded to bf16.  Reference: the same roundings in float64 on the CPU (products of bf16 values are exact in fp32/64, so
+    only the accumulation order differs: 1e-5 relative before the final rounding = at most one bf16 ulp after it)."""
+    from pccx import train
+    rng = np.random.default_rng(3)
+    bf = lambda a: torch.from_numpy(a).bfloat16().double().numpy()
+    for M, K, N in [(300, 195, 128), (37, 3, 32), (64, 512, 70)]:
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        gz = rng.standard_normal((M, N)).astype(np.float32)
+        xg, Wg, bg = (torch.from_numpy(t).cuda().requires_grad_(True) for t in (x, W, b))
+        train._AUTOCAST = True
+        try:
+            z = train.LinearFn.apply(xg, Wg, bg)
+        finally:
+            train._AUTOCAST = False
+        z.backward(torch.from_numpy(gz).cuda())
+        want = bf(x) @ bf(W).T + b.astype(np.float64)
+        got = z.detach().cpu().numpy().astype(np.float64)
+        assert np.array_equal(got, torch.from_numpy(got).bfloat16().double().numpy())          # the result IS a bf16 value
+        ulp = np.maximum(np.abs(want), 1e-30) * 2.0 ** -7
+        assert (np.abs(got - want) <= ulp).all()
+        # backward: dX = bf16(dZ) . bf16(W) rounded to bf16; dW = bf16(dZ)^T . bf16(X) in fp32
+        dx_want = bf(gz) @ bf(W)
+        assert (np.abs(xg.grad.cpu().numpy() - dx_want) <= np.maximum(np.abs(dx_want), 1e-3) * 2.0 ** -7).all()
+        dw_want = bf(gz).T @ bf(x)
+        np.testing.assert_allclose(Wg.grad.cpu().numpy(), dw_want, rtol=1e-4, atol=1e-4 * np.abs(dw_want).max())
+
+
+@pytest.mark.gpu
+def test_autocast_training_step_stays_close_to_the_fp32_reference_run():
+    """train_step(autocast=True) -- the CUDA branch of train_pppe_pcd_ae.py:193-217 with bf16 (BASELINE configs[4]) -- against
+    the reference's own fp32 run (tests/golden/train_step.npz).  Stated tolerance: bf16 operands carry 2^-8 relative rounding,
+    sums over 64-1500 terms average it down; loss / distortion within 2 % of the fp32 fixture, clipped gradients within 8 % of
+    the largest entry, the loss still decreases.  (The reference's fp16 + GradScaler branch itself cannot run here: no CUDA.)"""
+    import os
+    from pccx import families, train
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_step.npz"))
+    names = list(gold["param_names"])
+    o = _models(2048)
+    g = families.PointCloudAE(64, 16, 2048)
+    g.load_state_dict(o.state_dict())
+    g = g.cuda()
+    opt = train.Adam(g.parameters(), lr=1e-3)
+    x = torch.from_numpy(synth.train_input(2, 2048)).cuda()
+    st = gold["starts"][0]
+    want = gold["scalars"][0]
+    loss, dist, rate = train.train_step(g, opt, x, [[st[0], st[1]], st[2], st[3]], lam=float(want[3]), loss_type="chamfer", autocast=True)
+    assert abs(dist - want[1]) <= 2e-2 * abs(want[1]), (dist, want[1])
+    assert abs(loss - want[0]) <= 2e-2 * abs(want[0]), (loss, want[0])
+    sd = dict(g.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values() if p.grad is not None)))
+    coef = min(1.0, 1.0 / (gn + 1e-6))
+    wg = gold["grads_0"]
+    got_g = np.concatenate([synth.sample64(sd[k].grad.cpu().numpy()) * coef if sd[k].grad is not None
+                            else np.full(synth.sample64(sd[k].detach().cpu().numpy()).shape, np.nan, np.float32) for k in names])
+    m = ~np.isnan(wg)
+    assert np.abs(got_g[m] - wg[m]).max() <= 8e-2 * np.abs(wg[m]).max()
+    first = dist
+    for _ in range(5):
+        loss, dist, rate = train.train_step(g, opt, x, [[st[0], st[1]], st[2], st[3]], lam=float(want[3]), loss_type="chamfer", autocast=True)
+    assert np.isfinite(loss) and dist < first
