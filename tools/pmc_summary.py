@@ -4,7 +4,8 @@
   python tools/pmc_summary.py --sq DIR --fetch DIR --write DIR --tcc DIR --tag round1_d
 
   profiles/<tag>_pmc_summary.csv   pass,kernel,counter,mean_per_launch,launches  (+ derived MFMA utilisation rows)
-  profiles/round1_traffic.json     HBM bytes per launch per kernel, read by bench.py for roofline.traffic
+  profiles/<round>_traffic.json    HBM bytes per launch per kernel (round = the tag up to its first "_"), read by bench.py for
+                                   roofline.traffic (labelled there as scaled from this committed pass)
 
 Each DIR is the -d directory of ONE rocprofv3 pass (the counters do not fit one pass and gpurun refuses
 --pmc together with trace domains), collected with `bench.py --steps 1 --warmup 1 --batch 256 --cpu-clouds 0`:
@@ -48,6 +49,7 @@ def main():
     for k in ("sq", "fetch", "write", "tcc"):
         ap.add_argument("--" + k, required=True)
     ap.add_argument("--tag", required=True)
+    ap.add_argument("--batch", type=int, default=256, help="clouds per launch the passes ran at (bench.py --batch)")
     args = ap.parse_args()
     passes = {k: load(getattr(args, k)) for k in ("sq", "fetch", "write", "tcc")}
     mine = [k for k in passes["sq"] if not k.startswith("at::") and "rocclr" not in k]
@@ -89,10 +91,10 @@ def main():
             ent["l2_hit_rate"] = h / (h + m) if h + m else None
         kernels[kern] = ent
     note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate passes, bench.py --steps 1 --warmup 1 "
-            "--batch 256 --cpu-clouds 0 (tools/pmc_summary.py, tag %s). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
+            "--batch 256 --cpu-clouds 0 --one-mode (tools/pmc_summary.py, tag %s). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
             "doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); Infinity-Cache hits are counted." % args.tag)
-    with open(os.path.join(ROOT, "profiles", "round1_traffic.json"), "w") as f:
-        json.dump({"note": note, "kernels": kernels}, f, indent=1)
+    with open(os.path.join(ROOT, "profiles", args.tag.split("_")[0] + "_traffic.json"), "w") as f:
+        json.dump({"note": note, "batch": args.batch, "kernels": kernels}, f, indent=1)
     print(out)
     for k, v in kernels.items():
         print(f"{k:34s} hbm {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB  l2 hit {v.get('l2_hit_rate')}")

@@ -1,0 +1,12 @@
+set -o pipefail
+O=$GRAFT_REPO_ROOT/gpurun_out/r2p; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py > $O/bench_under_rocprof.json 2> $O/trace.err; echo "trace rc=$?"
+B="python3 bench.py --steps 1 --warmup 1 --batch 256 --cpu-clouds 0 --one-mode"
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/sq --output-format csv -- $B > $O/sq.log 2>&1; echo "sq rc=$?"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- $B > $O/fetch.log 2>&1; echo "fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- $B > $O/write.log 2>&1; echo "write rc=$?"
+timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- $B > $O/tcc.log 2>&1; echo "tcc rc=$?"
+ls $O $O/trace | head -30
