@@ -63,7 +63,6 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
     float (*smax)[16] = (float (*)[16])(region + fu_region_bytes());
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane >> 4, n = lane & 15;
     const size_t P = blockIdx.x;
     const float *xp = x + P * (size_t)K * 3;
     const int ntiles = K >> 4;
@@ -132,16 +131,22 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
     }
     __syncthreads();
 
-    const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (lane < 16) smax[wu][lane] = -INFINITY;            // running channel maximum of this wave, kept in LDS between passes
+    const int lane0 = lane;
 
-    f32x4 run;                                            // running max, channel 4g+r
-    run[0] = run[1] = run[2] = run[3] = -INFINITY;
     const int passes = (ntiles + 7) / 8;                  // identical for all waves: barriers inside
     for (int it = 0; it < passes; ++it) {
-        const int tile = it * 8 + w;
+        const int tile = it * 8 + wu;
         const bool valid = tile < ntiles;
         const int p0 = (valid ? tile : 0) * 16;           // an idle wave recomputes tile 0 and discards it
+        // Each phase derives its lane indices from a freshly "laundered" lane id: otherwise the compiler computes every
+        // lane-dependent address of BOTH phases once, ahead of the pass loop, and carries them (in scratch) through the other
+        // phase: 57 spilled VGPRs, 94 KB of scratch writes per patch = 6 GB of HBM traffic per 1024 clouds.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        int g = lane >> 4, n = lane & 15;
+        const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
 
         // ---- SetAbstraction for points p0 .. p0+15, two per iteration (sa_forward_kernel<true>'s body)
         for (int i0 = p0; i0 < p0 + 16; i0 += 2) {
@@ -202,6 +207,9 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         __syncthreads();                                  // every wave has its tile in registers: the region becomes the weight ring
 
         // ---- PointNet pass (pn_forward_b3_kernel's), ring started cold
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        g = lane >> 4; n = lane & 15;
         blob = opaque_uniform(blob);
         WStreamT<PN_B3_CHUNK, 2, 8> ws{opaque_uniform(pn3), swt, (PN_B3_STREAM_FRAGS + PN_B3_CHUNK - 1) / PN_B3_CHUNK, lane, wu, false};   // data chunks only
         ws.prologue();
@@ -240,14 +248,15 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
             }
         }
         ws.drain();
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row16_max(a3[0][0][r]);
+                if (n == 0) smax[wu][4 * g + r] = fmaxf(smax[wu][4 * g + r], v);
+            }
+        }
         __syncthreads();                                  // every wave is done reading the ring: the region is staging again
-        if (valid)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) run[r] = fmaxf(run[r], row16_max(a3[0][0][r]));
     }
-    if (n == 0)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) smax[w][4 * g + r] = run[r];
     __syncthreads();
     if (tid < 16 && tid < d) {
         float m = smax[0][tid];
