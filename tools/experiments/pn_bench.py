@@ -13,7 +13,7 @@ from bench import seeded_state_dict, AE_SEED, AE_LAST_GAIN
 from pccx import models, synth, ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 0, 9, 8, 10]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 100]
 K, k, d, L = 256, 128, 16, 7
 ae = models.AE(K, k, d, L)
 ae.load_state_dict(seeded_state_dict(ae, AE_SEED, last_gain=AE_LAST_GAIN))
