@@ -45,7 +45,7 @@ __host__ __device__ inline size_t fu_lds_bytes(int K)
     return (size_t)(FU_W1_FRAGS + FU_W2_FRAGS) * 1024 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32 + fu_region_bytes() + 8 * 16 * 4;
 }
 
-__global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *__restrict__ x, int K, const float *__restrict__ blob,
+__global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *__restrict__ x, int npatches, int K, const float *__restrict__ blob,
                                                                   const float *__restrict__ sa3, const float *__restrict__ pn3, int d,
                                                                   float spread, float half_spread, float *__restrict__ latent_raw,
                                                                   float *__restrict__ latent, float *__restrict__ latent_q)
@@ -63,73 +63,100 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
     float (*smax)[16] = (float (*)[16])(region + fu_region_bytes());
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t P = blockIdx.x;
-    const float *xp = x + P * (size_t)K * 3;
     const int ntiles = K >> 4;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     float *stage = stage_all + wu * FU_STAGE_WAVE;
 
-    {   // stage SetAbstraction weights + the patch
+    {   // stage the SetAbstraction weights ONCE per workgroup: a workgroup walks patches blockIdx.x, + gridDim.x, ...
         const f32x4 *gw1 = (const f32x4 *)sa3, *gw2 = (const f32x4 *)sa3 + FU_W1_FRAGS * 64;
         for (int i = tid; i < FU_W1_FRAGS * 64; i += 512) sw1[i] = gw1[i];
         for (int i = tid; i < FU_W2_FRAGS * 64; i += 512) sw2[i] = gw2[i];
         if (tid < 64) sb1[tid] = blob[ENC_SA_B1 + tid];
         if (tid < 128) sb2[tid] = blob[ENC_SA_B2 + tid];
-        for (int i = tid; i < 3 * K; i += 512) sx[i] = xp[i];
     }
+  for (size_t P = blockIdx.x; P < (size_t)npatches; P += gridDim.x) {
+    const float *xp = x + P * (size_t)K * 3;
+    for (int i = tid; i < 3 * K; i += 512) sx[i] = xp[i];
     __syncthreads();
 
-    // ---- kNN-16 inside the patch (pn_kit.py:190): as sa_forward_kernel, one point per thread
+    // ---- kNN-16 inside the patch (pn_kit.py:190), the selection of sa_forward_kernel with TWO threads per point: thread t and
+    // t + 256 each keep the 17 smallest packed keys of one half of the candidates (key = distance bits with the candidate index in
+    // the low log2(K) bits, one v_med3_u32 per slot per candidate); the upper thread hands its 17 keys over through LDS (the
+    // region is idle until the first SetAbstraction phase) and the lower one inserts them: the 17 smallest of the union are
+    // among the two lists.  A tie or near-tie at the 16th / 17th rank takes the exact (distance, index) selection over all
+    // candidates, as before.
     unsigned jmask = 15u;
     while ((int)jmask < K - 1) jmask = 2u * jmask + 1u;
-    for (int i = tid; i < K; i += 512) {
-        const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
+    unsigned *kmerge = (unsigned *)region;                 // [256][17]
+    const int khalf = tid >> 8, kslot = tid & 255;
+    for (int ib = 0; ib < K; ib += 256) {
+        const int i = ib + kslot;
+        const bool act = i < K;
         unsigned tk[17];
 #pragma unroll
         for (int s = 0; s < 17; ++s) tk[s] = 0xFFFFFFFFu;
-        for (int j0 = 0; j0 < K; j0 += 4) {
-            float dd[4];
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (act) {
+            px = sx[3 * i]; py = sx[3 * i + 1]; pz = sx[3 * i + 2];
+            const int jb = khalf * (K >> 1), je = jb + (K >> 1);          // K % 16 == 0: halves are multiples of 8
+            for (int j0 = jb; j0 < je; j0 += 4) {
+                float dd[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                dd[u] = pccx_sqdist(px, py, pz, sx[3 * (j0 + u)], sx[3 * (j0 + u) + 1], sx[3 * (j0 + u) + 2]);
+                for (int u = 0; u < 4; ++u)
+                    dd[u] = pccx_sqdist(px, py, pz, sx[3 * (j0 + u)], sx[3 * (j0 + u) + 1], sx[3 * (j0 + u) + 2]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned key = (__float_as_uint(dd[u]) & ~jmask) | (unsigned)(j0 + u);
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned key = (__float_as_uint(dd[u]) & ~jmask) | (unsigned)(j0 + u);
+#pragma unroll
+                    for (int s = 16; s >= 1; --s) tk[s] = fu_umed3(tk[s - 1], key, tk[s]);
+                    tk[0] = min(tk[0], key);
+                }
+            }
+            if (khalf == 1) {
+#pragma unroll
+                for (int s = 0; s < 17; ++s) kmerge[s * 256 + kslot] = tk[s];
+            }
+        }
+        __syncthreads();
+        if (act && khalf == 0) {
+#pragma unroll
+            for (int q = 0; q < 17; ++q) {
+                const unsigned key = kmerge[q * 256 + kslot];
 #pragma unroll
                 for (int s = 16; s >= 1; --s) tk[s] = fu_umed3(tk[s - 1], key, tk[s]);
                 tk[0] = min(tk[0], key);
             }
-        }
-        if (((tk[15] ^ tk[16]) & ~jmask) != 0u) {
+            if (((tk[15] ^ tk[16]) & ~jmask) != 0u) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)(tk[s] & jmask);
-            continue;
-        }
-        float td[16];                                    // tie or near-tie at the boundary: the exact (distance, index) rule
+                for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)(tk[s] & jmask);
+            } else {
+                float td[16];                            // tie or near-tie at the boundary: the exact (distance, index) rule
 #pragma unroll
-        for (int s = 0; s < 16; ++s) td[s] = INFINITY;
-        for (int j = 0; j < K; ++j) {
-            const float dj = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
+                for (int s = 0; s < 16; ++s) td[s] = INFINITY;
+                for (int j = 0; j < K; ++j) {
+                    const float dj = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
 #pragma unroll
-            for (int s = 15; s >= 1; --s) td[s] = __builtin_amdgcn_fmed3f(td[s - 1], dj, td[s]);
-            td[0] = fminf(td[0], dj);
-        }
-        const float T = td[15];
-        int need = 16;
+                    for (int s = 15; s >= 1; --s) td[s] = __builtin_amdgcn_fmed3f(td[s - 1], dj, td[s]);
+                    td[0] = fminf(td[0], dj);
+                }
+                const float T = td[15];
+                int need = 16;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) need -= td[s] < T ? 1 : 0;
-        int c = 0, ties = 0;
-        for (int j = 0; j < K; ++j) {
-            const float dj = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
-            const bool tie = dj == T;
-            if (dj < T || (tie && ties < need)) {
-                if (c < 16) nbr16[i * 16 + c] = (unsigned short)j;
-                ++c;
+                for (int s = 0; s < 16; ++s) need -= td[s] < T ? 1 : 0;
+                int c = 0, ties = 0;
+                for (int j = 0; j < K; ++j) {
+                    const float dj = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
+                    const bool tie = dj == T;
+                    if (dj < T || (tie && ties < need)) {
+                        if (c < 16) nbr16[i * 16 + c] = (unsigned short)j;
+                        ++c;
+                    }
+                    ties += tie ? 1 : 0;
+                }
             }
-            ties += tie ? 1 : 0;
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (lane < 16) smax[wu][lane] = -INFINITY;            // running channel maximum of this wave, kept in LDS between passes
@@ -268,6 +295,8 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         latent[P * d + tid] = y;
         latent_q[P * d + tid] = rintf(y);
     }
+    __syncthreads();                                      // smax / sx / nbr16 are rewritten for the next patch
+  }
 }
 
 // 1 when the fused kernel can hold a K-point patch (its neighbour table grows with K), 0 when the caller must run
@@ -288,8 +317,11 @@ extern "C" int pccx_ae_encode_b3(const float *patches, int P, int K, const float
     const float half = (float)(((double)L - 0.2) / 2);
     PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_pn_forward_b3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024));
-    hipLaunchKernelGGL(sa_pn_forward_b3_kernel, dim3(P), dim3(512), fu_lds_bytes(K), (hipStream_t)stream, patches, K, enc_blob, sa_b3_blob,
-                       pn_b3_blob, d, spread, half, latent_raw, latent, latent_q);
+    // one workgroup per CU at a time (LDS): a grid of 8 workgroups per CU, each walking P / grid patches, keeps the SetAbstraction
+    // weights staged and still balances the tail
+    const int grid = P < 2048 ? P : 2048;
+    hipLaunchKernelGGL(sa_pn_forward_b3_kernel, dim3(grid), dim3(512), fu_lds_bytes(K), (hipStream_t)stream, patches, P, K, enc_blob,
+                       sa_b3_blob, pn_b3_blob, d, spread, half, latent_raw, latent, latent_q);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
