@@ -189,7 +189,8 @@ PCCX_API int pccx_ae_decode(const float *latent_q, int P, int d, int k, const fl
                             const float *nrm_center, const float *nrm_longest, int S, double margin,
                             float *pc_out, void *stream);
 
-/* EXPERIMENTAL, opt-in: the same synthesis transform with the K = 1024 Linear and inv_mlp evaluated as
+/* The bf16x3 arithmetic mode (the default of the host layer since round 2, validated against every
+ * oracle / golden parity test at the f32 tolerances): the same synthesis transform with the K = 1024 Linear and inv_mlp evaluated as
  * fp32 products of three bf16 pieces per operand on the bf16 matrix cores (six v_mfma_f32_16x16x32_bf16 passes,
  * fp32 accumulate; error at the level of an fp32 summation reorder, not bit-identical to pccx_ae_decode).
  * b3_blob: pccx_dec_b3_blob_floats(k) floats on the device, filled once from the packed decoder blob (already on
@@ -197,12 +198,12 @@ PCCX_API int pccx_ae_decode(const float *latent_q, int P, int d, int k, const fl
  * reference lines as pccx_ae_decode (AE.py:48-53, decompress.py:97-116). */
 PCCX_API size_t pccx_sa_b3_blob_floats(void);
 PCCX_API int pccx_pack_sa_b3(const float *enc_blob_dev, float *sa_b3_blob_dev, void *stream);
-/* pccx_sa_forward (pn_kit.py:164-211) with conv1 / conv2 on bf16x3 operands; same EXPERIMENTAL status. */
+/* pccx_sa_forward (pn_kit.py:164-211) with conv1 / conv2 on bf16x3 operands. */
 PCCX_API int pccx_sa_forward_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
                                 float *feat, void *stream);
 PCCX_API size_t pccx_pn_b3_blob_floats(void);
 PCCX_API int pccx_pack_pn_b3(const float *enc_blob_dev, float *pn_b3_blob_dev, void *stream);
-/* pccx_pn_forward (pn_kit.py:124-144, AE.py:43-45) on bf16x3 operands; same EXPERIMENTAL status. */
+/* pccx_pn_forward (pn_kit.py:124-144, AE.py:43-45) on bf16x3 operands. */
 PCCX_API int pccx_pn_forward_b3(const float *patches, const float *feat, int P, int K, const float *enc_blob,
                                 const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
                                 float *latent_q, void *stream);

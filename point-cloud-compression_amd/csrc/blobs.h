@@ -34,7 +34,7 @@
 #define ENC_PN_STREAM_CHUNKS (2 * ((ENC_PN_STREAM_FRAGS + 2 * WS_CHUNK - 1) / (2 * WS_CHUNK)))      // even
 #define ENC_BLOB_FLOATS (ENC_PN_STREAM + ENC_PN_STREAM_CHUNKS * WS_CHUNK * 256)
 
-// EXPERIMENTAL PointNet weight stream on bf16x3 operands (encoder.hip: pn_forward_b3_kernel): L0 [5][8][3], L1 [4][16][3],
+// PointNet weight stream on bf16x3 operands (encoder.hip: pn_forward_b3_kernel): L0 [5][8][3], L1 [4][16][3],
 // then per half h of layer 2's outputs: L2 [8][16][3] and L3 [8][1][3] fragments, [kt32][mt][plane] each (pccx_pack_pn_b3),
 // padded to chunks of 24.
 #define PN_B3_CHUNK 24
@@ -68,7 +68,7 @@
 #define DEC_G_W(k) (DEC_G_B + (k) * 128)
 #define DEC_BLOB_FLOATS(k) (DEC_G_W(k) + (size_t)(k) * DEC_STREAM_CHUNKS * DEC_WS_CHUNK * 256)
 
-// ---- experimental: decoder GEMM as fp32 products of three bf16 pieces per operand (decoder.hip, dec_main_kernel<true>).
+// ---- bf16x3 mode: decoder GEMM as fp32 products of three bf16 pieces per operand (decoder.hip, dec_main_kernel<true>).
 // Per point p: [32 k-steps of 32][8 m-tiles][3 planes hi/mid/lo] bf16 A fragments of v_mfma_f32_16x16x32_bf16
 // (1 KiB each: lane (m = lane%16, kg = lane/16) holds 8 bf16 of k-slots 8*kg + j <-> channel 32t + 16*(j>>2) + 4*kg + (j&3),
 // the order in which two fp32 C tiles concatenate), then the inv_mlp layers in the same form (L0 [5][8][3] with the odd ninth

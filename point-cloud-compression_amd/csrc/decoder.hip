@@ -10,7 +10,7 @@
 //                     accumulators feed inv_mlp directly from registers (n index = patch).  The
 //                     (BS,16384) activation of the reference never exists in memory.
 // MFMA-bound; weights (64 MiB) and activations stream from L2 / Infinity Cache as 1 KiB fragments.
-// dec_main_kernel<true> is the EXPERIMENTAL, opt-in bf16x3 variant; <false> is the product.
+// dec_main_kernel<true> is the bf16x3 variant (the host layer's default mode); <false> is the exact-fp32 product.
 #include <math.h>
 
 #include "blobs.h"
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void dec_head_kernel(const float *__restric
 #define DEC_GROUP 64                       // patch blocks per group of the block order (dec_main_kernel)
 
 
-// ---- experimental bf16x3 operands: x = hi + mid + lo exactly, each a bf16 (round to nearest even)
+// ---- bf16x3 operands: x = hi + mid + lo exactly, each a bf16 (round to nearest even)
 __device__ __forceinline__ unsigned b3_rne(float x)
 {
     unsigned u = __float_as_uint(x);
@@ -98,7 +98,7 @@ __device__ __forceinline__ uint4 b3_load_async(const uint4 *p)    // placed exac
 }
 
 // grid: x = patch block (8 n-tiles = 128 patches), y = point p.  4 waves, wave w owns n-tiles 2w, 2w+1.
-// B3 = false: exact fp32 MFMA GEMM (the product path).  B3 = true (experimental, opt-in): the K = 1024 GEMM runs as six
+// B3 = false: exact fp32 MFMA GEMM (the product path).  B3 = true (the bf16x3 mode): the K = 1024 GEMM runs as six
 // v_mfma_f32_16x16x32_bf16 passes over pre-split operands (blob3 / h2p hold bf16 planes); the inv_mlp tail is unchanged.
 template <bool B3>
 __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restrict__ h2p, const float *__restrict__ latent_q,
@@ -389,7 +389,7 @@ extern "C" int pccx_ae_decode(const float *latent_q, int P, int d, int k, const 
     return PCCX_OK;
 }
 
-// ---- experimental bf16x3 decoder GEMM (opt-in) ---------------------------------------
+// ---- bf16x3 decoder GEMM ---------------------------------------
 extern "C" size_t pccx_dec_b3_blob_floats(int k) { return DEC_B3_BLOB_FLOATS(k > 0 ? k : 0); }
 
 extern "C" int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream)

@@ -9,8 +9,9 @@
 // (v_mfma_f32_16x16x4_f32, exact fp32) as register-resident chains (mfma_chain.h).
 // MFMA-bound: 5.42 GFLOP (SA) + 6.19 GFLOP (PointNet) per 8192-point cloud.
 //
-// sa_forward_kernel<true> and pn_forward_b3_kernel are EXPERIMENTAL, opt-in variants that form the
-// same fp32 products from three bf16 pieces per operand on the bf16 matrix cores; the exact-fp32 kernels are the product.
+// sa_forward_kernel<true> and pn_forward_b3_kernel are the bf16x3 variants that form the
+// same fp32 products from three bf16 pieces per operand on the bf16 matrix cores; in that mode the default encoder is the fused
+// kernel of encoder_fused.hip (these two then serve ae.sa / ae.pn called separately, and K > 512).
 #include <math.h>
 
 #include "blobs.h"
@@ -33,7 +34,7 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
-// B3 (EXPERIMENTAL, opt-in): conv1 and conv2 as fp32 products of three bf16 pieces per operand on the
+// B3 (the bf16x3 mode): conv1 and conv2 as fp32 products of three bf16 pieces per operand on the
 // bf16 matrix cores.  blob3 = [conv1: 1 kt32 x 4 mt x 3 planes][conv2: 2 x 8 x 3] fragments (pccx_pack_sa_b3).
 #define SA_W1_FRAGS(b3) ((b3) ? 1 * 4 * 3 : 2 * 4)
 #define SA_W2_FRAGS(b3) ((b3) ? 2 * 8 * 3 : 4 * 8)
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void pn_forward_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------
-// EXPERIMENTAL (opt-in): PointNet + quantiser on bf16x3 operands.  Workgroup = one patch, EIGHT
+// PointNet + quantiser on bf16x3 operands.  Workgroup = one patch, EIGHT
 // waves, ONE 16-point tile per wave per pass (the bf16 planes of two tiles of the 256-channel activation do not fit the
 // register file), so the weight stream is shared by 128 points per pass as in the fp32 kernel.  Layer 2 runs k-outer in
 // two halves of 16 output tiles (64 accumulator VGPRs): each pair of input tiles is split into its three planes once per
@@ -448,7 +449,7 @@ extern "C" int pccx_sa_forward(const float *patches, int P, int K, const float *
     return launch_sa(patches, P, K, enc_blob, nullptr, feat, (hipStream_t)stream);
 }
 
-// EXPERIMENTAL, opt-in: see sa_forward_kernel<true>
+// bf16x3 mode: see sa_forward_kernel<true>
 extern "C" int pccx_sa_forward_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob, float *feat,
                                   void *stream)
 {
@@ -469,7 +470,7 @@ extern "C" int pccx_pn_forward(const float *patches, const float *feat, int P, i
     return launch_pn(patches, feat, P, K, enc_blob, d, L, latent_raw, latent, latent_q, (hipStream_t)stream);
 }
 
-// EXPERIMENTAL, opt-in: see pn_forward_b3_kernel
+// bf16x3 mode: see pn_forward_b3_kernel
 extern "C" int pccx_pn_forward_b3(const float *patches, const float *feat, int P, int K, const float *enc_blob, const float *pn_b3_blob,
                                   int d, int L, float *latent_raw, float *latent, float *latent_q, void *stream)
 {

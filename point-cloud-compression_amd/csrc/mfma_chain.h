@@ -106,7 +106,7 @@ __device__ __forceinline__ void max16_of_8_transposed_tiles(const f32x4 (&t)[8],
 }
 
 // ------------------------------------------------------------------------------------------
-// EXPERIMENTAL bf16x3 operands: fp32 products formed on the bf16 matrix cores from three bf16
+// bf16x3 operands: fp32 products formed on the bf16 matrix cores from three bf16
 // pieces per operand (x = hi + mid + lo exactly), the six products of weight i + j <= 4 accumulated in fp32.
 // ------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
