@@ -468,9 +468,16 @@ def bench_pppe_train(args, rk):
     kw = dict(lam=1e-3, data_parallel=rk.world > 1)
     if args.autocast:
         kw["autocast"] = True
-    for _ in range(args.warmup):
-        train.train_step(model, opt, x, starts, **kw)
-    dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), args.steps, torch.cuda.synchronize)
+    if args.graph:
+        if rk.world > 1:
+            raise SystemExit("--graph: the captured step is single-GPU (the gradient all-reduce is not captured)")
+        gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=args.autocast, warmup=max(args.warmup, 1))
+        dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), args.steps, torch.cuda.synchronize)
+        keep["o"] = tuple(float(t) for t in keep["o"])
+    else:
+        for _ in range(args.warmup):
+            train.train_step(model, opt, x, starts, **kw)
+        dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), args.steps, torch.cuda.synchronize)
     if rk.rank == 0:
         flop = train.step_flops(model, Bt) if hasattr(train, "step_flops") else None
         rf = None
@@ -484,7 +491,8 @@ def bench_pppe_train(args, rk):
             "unit": "clouds/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
-                       "parallelism": f"dp{rk.world}", "weights": "seeded random"},
+                       "parallelism": f"dp{rk.world}", "weights": "seeded random",
+                       "launch": "one hipGraph replay per step" if args.graph else "eager (about 600 launches per step)"},
             "roofline": rf, "cpu_baseline": None, "loss": keep["o"][0]}), flush=True)
 
 
@@ -507,6 +515,7 @@ def main():
                          "launch-check = no GPU work, exercises the N-rank launch and the summary all-gather")
     ap.add_argument("--rooms", type=int, default=8, help="s3dis: number of rooms")
     ap.add_argument("--autocast", action="store_true", help="pppe-train: the bf16 autocast branch of train_pppe_pcd_ae.py:193-217")
+    ap.add_argument("--graph", action="store_true", help="pppe-train: capture the step once as a hipGraph and replay it (single GPU)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU / on CPU")
     args = ap.parse_args()

@@ -312,6 +312,11 @@ PCCX_API int pccx_sumsq_accumulate(const float *g, int64_t n, double *acc, void 
 PCCX_API int pccx_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                             const double *gnorm_sq, float max_norm, float lr, float beta1, float beta2,
                             float eps, int step, void *stream);
+/* pccx_adam_step with lr and the bias corrections read from device memory: hyper = {lr, 1 - beta1^t, 1 - beta2^t} (3 floats).
+ * No per-step launch argument, so the training step can be captured as a hipGraph (pccx.train.GraphedTrainStep). */
+PCCX_API int pccx_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                const double *gnorm_sq, float max_norm, const float *hyper, float beta1, float beta2,
+                                float eps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -446,6 +446,41 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// The same update with lr and the two bias corrections read from DEVICE memory (hyper = {lr, 1 - beta1^t, 1 - beta2^t}): nothing
+// that changes from step to step is a launch argument, so the whole training step can be captured once as a hipGraph and replayed.
+__global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
+                                const double *__restrict__ gnorm_sq, float max_norm, const float *__restrict__ hyper, float b1, float b2,
+                                float eps)
+{
+    const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
+    float clip = 1.f;
+    if (gnorm_sq) {
+        const float norm = (float)sqrt(*gnorm_sq);
+        clip = fminf(1.f, max_norm / (norm + 1e-6f));
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int pccx_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const double *gnorm_sq,
+                                  float max_norm, const float *hyper, float beta1, float beta2, float eps, void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hyper, "pccx_adam_step_dev: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n,
+                       gnorm_sq, max_norm, hyper, beta1, beta2, eps);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 extern "C" int pccx_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const double *gnorm_sq,
                               float max_norm, float lr, float beta1, float beta2, float eps, int step, void *stream)
 {

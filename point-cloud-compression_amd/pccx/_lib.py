@@ -76,6 +76,7 @@ _SIGNATURES = {
     "pccx_rate_from_logits": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "pccx_sumsq_accumulate": [_P, C.c_int64, _P, _P],
     "pccx_adam_step": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P],
+    "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
 _RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,

@@ -289,15 +289,39 @@ class Adam:
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
+        self.hyper = None           # device {lr, 1 - b1^t, 1 - b2^t}: set by make_capturable()
+
+    def make_capturable(self, device):
+        """Read lr and the bias corrections from device memory (pccx_adam_step_dev) so that step() has no per-step launch
+        argument: advance() bumps t and refreshes them, step() can then sit inside a captured hipGraph."""
+        if self.hyper is None:
+            self.hyper = torch.zeros(3, device=device, dtype=torch.float32)
+            self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        return self
+
+    def advance(self):
+        self.t += 1
+        self._hyper_host[0] = self.lr
+        self._hyper_host[1] = 1.0 - self.betas[0] ** self.t
+        self._hyper_host[2] = 1.0 - self.betas[1] ** self.t
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
 
     def step(self, max_norm=None):
-        self.t += 1
+        capturable = self.hyper is not None
+        if not capturable:
+            self.t += 1
         live = [(p, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
         acc = None
         if max_norm is not None and live:
             acc = torch.zeros(1, device=live[0][0].device, dtype=torch.float64)
             for p, _, _ in live:
                 _lib.call("pccx_sumsq_accumulate", p.grad.contiguous().data_ptr(), p.numel(), acc.data_ptr(), _stream())
+        if capturable:
+            for p, m, v in live:
+                _lib.call("pccx_adam_step_dev", p.data_ptr(), p.grad.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                          acc.data_ptr() if acc is not None else None, float(max_norm or 0.0), self.hyper.data_ptr(),
+                          float(self.betas[0]), float(self.betas[1]), float(self.eps), _stream())
+            return acc
         for p, m, v in live:
             _lib.call("pccx_adam_step", p.data_ptr(), p.grad.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                       acc.data_ptr() if acc is not None else None, float(max_norm or 0.0), float(self.lr), float(self.betas[0]),
@@ -323,6 +347,65 @@ def step_flops(model, batch):
     for lin in (enc.global_conv[0], enc.global_conv[3], dec.fc_coarse[0], dec.fc_coarse[2], dec.expansion_mlp[0], dec.expansion_mlp[2]):
         macs += batch * lin.weight.shape[0] * lin.weight[0].numel()
     return 3 * 2 * macs
+
+
+class GraphedTrainStep:
+    """The whole iteration of train_step -- forward, rate term, loss, backward, clipping, Adam: about 600 small launches at batch
+    4 -- captured ONCE as a hipGraph and replayed (MI355X-first: HIP graphs for a launch-bound inner loop instead of a tracing
+    compiler).  Everything that changes from step to step lives in device memory the graph reads: the batch, the FPS start indices,
+    lambda, and Adam's lr / bias corrections (Adam.make_capturable).  Shapes are fixed at construction.  The ``warmup`` eager
+    iterations run before the capture are REAL optimisation steps on the construction batch (they also size the scratch buffers).
+    Single-GPU: the data-parallel gradient all-reduce is not captured."""
+
+    def __init__(self, model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, loss_type="chamfer", autocast=False, warmup=2):
+        dev = batch_x.device
+        self.model, self.opt, self.grad_clip, self.loss_type, self.autocast = model, opt, grad_clip, loss_type, autocast
+        opt.make_capturable(dev)
+        as_dev = lambda s_: torch.as_tensor(s_).to(device=dev, dtype=torch.int32).contiguous().clone()
+        self.x = batch_x.detach().clone().contiguous()
+        self.starts = [[as_dev(s_) for s_ in starts[0]], as_dev(starts[1]), as_dev(starts[2])]
+        self.lam = torch.tensor(float(lam), device=dev, dtype=torch.float32)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                opt.advance()
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+
+    def _body(self):
+        global _AUTOCAST
+        for p in self.opt.params:
+            p.grad = None
+        _AUTOCAST = bool(self.autocast)
+        try:
+            coarse, fine, cond, y_q = forward_train(self.model, self.x, self.starts)
+            fbpp = estimate_bits_per_point(self.model, y_q, cond.detach())
+            loss, dist, rate = rd_loss(fine, self.x, fbpp, self.lam, self.loss_type)
+        finally:
+            _AUTOCAST = False
+        loss.backward()
+        self.opt.step(max_norm=self.grad_clip)
+        return loss.detach(), dist, rate
+
+    def __call__(self, batch_x=None, starts=None, lam=None, sync=True):
+        """One iteration.  Returns (loss, dist, rate) as floats (sync=True) or the device scalars of the graph (sync=False)."""
+        if batch_x is not None:
+            self.x.copy_(batch_x)
+        if starts is not None:
+            for dst, src in zip(self.starts[0], starts[0]):
+                dst.copy_(torch.as_tensor(src).to(dst.device, torch.int32))
+            self.starts[1].copy_(torch.as_tensor(starts[1]).to(self.x.device, torch.int32))
+            self.starts[2].copy_(torch.as_tensor(starts[2]).to(self.x.device, torch.int32))
+        if lam is not None:
+            self.lam.fill_(float(lam))
+        self.opt.advance()
+        self.graph.replay()
+        return tuple(float(t) for t in self.out) if sync else self.out
 
 
 def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_parallel=False, loss_type="chamfer", autocast=False):

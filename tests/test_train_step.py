@@ -263,3 +263,33 @@ def test_autocast_training_step_stays_close_to_the_fp32_reference_run():
     for _ in range(5):
         loss, dist, rate = train.train_step(g, opt, x, [[st[0], st[1]], st[2], st[3]], lam=float(want[3]), loss_type="chamfer", autocast=True)
     assert np.isfinite(loss) and dist < first
+
+
+@pytest.mark.gpu
+def test_graphed_training_step_replays_the_eager_step():
+    """train.GraphedTrainStep (the iteration captured once as a hipGraph, Adam's lr / bias corrections, the batch, the FPS starts
+    and lambda read from device memory) against the eager train_step from the same initial state: same kernels in the same
+    order, so losses agree to the noise of the fp32 atomics (1e-4) and the parameters after four iterations to 1e-4."""
+    import copy
+    from pccx import families, train
+    o = _models(2048)
+    g1 = families.PointCloudAE(64, 16, 2048)
+    g1.load_state_dict(o.state_dict())
+    g1 = g1.cuda()
+    g2 = copy.deepcopy(g1)
+    x = torch.from_numpy(synth.train_input(2, 2048)).cuda()
+    rng = np.random.default_rng(5)
+    starts = [[rng.integers(0, 2048, 2), rng.integers(0, 2048, 2)], rng.integers(0, 512, 2), rng.integers(0, 128, 2)]
+    opt1, opt2 = train.Adam(g1.parameters(), lr=1e-3), train.Adam(g2.parameters(), lr=1e-3)
+    eager = [train.train_step(g1, opt1, x, starts, lam=1e-3) for _ in range(4)]
+    gs = train.GraphedTrainStep(g2, opt2, x, starts, lam=1e-3, warmup=2)          # two eager iterations, then the capture
+    graphed = [gs() for _ in range(2)]                                          # iterations 3 and 4 as replays
+    assert opt2.t == 4
+    for (l1, d1, r1), (l2, d2, r2) in zip(eager[2:], graphed):
+        assert abs(l1 - l2) <= 1e-4 * abs(l1) and abs(d1 - d2) <= 1e-4 * abs(d1), (l1, l2)
+    for (k1, p1), (_, p2) in zip(g1.named_parameters(), g2.named_parameters()):
+        assert float((p1 - p2).abs().max()) <= 1e-4 * max(1.0, float(p1.abs().max())), k1
+    # new data through the same graph: a different batch changes the loss, and stays finite
+    x2 = torch.from_numpy(synth.train_input(2, 2048)[:, ::-1].copy()).cuda()
+    l3, _, _ = gs(batch_x=x2, lam=2e-3)
+    assert np.isfinite(l3)
