@@ -93,6 +93,9 @@ PCCX_API int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, f
  * gX (B,P,3), gY (B,Q,3) receive grad_out * dL/dX, dL/dY (buffers are zeroed here). */
 PCCX_API int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
                                const int32_t *nn_yx, float grad_out, float *gX, float *gY, void *stream);
+/* pccx_chamfer_grad with the upstream gradient scalar read from device memory (no host sync: usable under hipGraph capture). */
+PCCX_API int pccx_chamfer_grad_dev(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
+                                   const int32_t *nn_yx, const float *grad_out_dev, float *gX, float *gY, void *stream);
 
 /* D2 (point-to-plane) PSNR support (eval.py:58-60,73-81).  pccx_estimate_normals: PCA normal of
  * every point over its K neighbours nbr (B,N,K) int64 (e.g. pccx_knn with K=30, as open3d's

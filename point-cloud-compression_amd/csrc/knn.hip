@@ -634,8 +634,9 @@ extern "C" int pccx_point_plane_err(const float *X, int B, int P, const float *Y
 // ------------------------------------------------------------------------------------------
 __global__ void chamfer_grad_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, int Q,
                                     const int32_t *__restrict__ nn_xy, const int32_t *__restrict__ nn_yx, float wx, float wy,
-                                    float *__restrict__ gX, float *__restrict__ gY)
+                                    const float *__restrict__ g_dev, float *__restrict__ gX, float *__restrict__ gY)
 {
+    if (g_dev) { wx *= *g_dev; wy *= *g_dev; }        // upstream gradient read on the device (no host sync; hipGraph capture)
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const float *x = X + (size_t)b * P * 3, *y = Y + (size_t)b * Q * 3;
@@ -658,8 +659,25 @@ __global__ void chamfer_grad_kernel(const float *__restrict__ X, int P, const fl
     }
 }
 
+static int chamfer_grad_launch(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy, const int32_t *nn_yx,
+                               float grad_out, const float *g_dev, float *gX, float *gY, void *stream);
+
 extern "C" int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
                                  const int32_t *nn_yx, float grad_out, float *gX, float *gY, void *stream)
+{
+    return chamfer_grad_launch(X, B, P, Y, Q, nn_xy, nn_yx, grad_out, nullptr, gX, gY, stream);
+}
+
+// the same with the upstream gradient (a scalar) read from device memory
+extern "C" int pccx_chamfer_grad_dev(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
+                                     const int32_t *nn_yx, const float *grad_out_dev, float *gX, float *gY, void *stream)
+{
+    PCCX_CHECK_ARG(grad_out_dev, "pccx_chamfer_grad_dev: null pointer");
+    return chamfer_grad_launch(X, B, P, Y, Q, nn_xy, nn_yx, 1.0f, grad_out_dev, gX, gY, stream);
+}
+
+static int chamfer_grad_launch(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy, const int32_t *nn_yx,
+                               float grad_out, const float *g_dev, float *gX, float *gY, void *stream)
 {
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(X && Y && nn_xy && nn_yx && gX && gY, "pccx_chamfer_grad: null pointer");
@@ -668,7 +686,7 @@ extern "C" int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, i
     PCCX_CHECK_HIP(hipMemsetAsync(gY, 0, sizeof(float) * (size_t)B * Q * 3, (hipStream_t)stream));
     const int n = P > Q ? P : Q;
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, nn_xy, nn_yx,
-                       grad_out / ((float)B * P), grad_out / ((float)B * Q), gX, gY);
+                       grad_out / ((float)B * P), grad_out / ((float)B * Q), g_dev, gX, gY);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -23,6 +23,7 @@ _SIGNATURES = {
     "pccx_ball_query": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P],
     "pccx_nn_dist": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],
     "pccx_chamfer_grad": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P],
+    "pccx_chamfer_grad_dev": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P],
     "pccx_estimate_normals": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_point_plane_err": [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P],
     "pccx_octree_bits_capacity": [C.c_int],

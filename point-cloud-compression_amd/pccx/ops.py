@@ -205,8 +205,9 @@ class _ChamferFn(torch.autograd.Function):
     def backward(ctx, g):
         x, y, nxy, nyx = ctx.saved_tensors
         gx, gy = torch.empty_like(x), torch.empty_like(y)
-        _lib.call("pccx_chamfer_grad", x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), y.shape[1], nxy.data_ptr(),
-                  nyx.data_ptr(), float(g), gx.data_ptr(), gy.data_ptr(), _stream())
+        gd = g.detach().to(torch.float32).reshape(1).contiguous()        # stays on the device: no sync inside backward
+        _lib.call("pccx_chamfer_grad_dev", x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), y.shape[1], nxy.data_ptr(),
+                  nyx.data_ptr(), gd.data_ptr(), gx.data_ptr(), gy.data_ptr(), _stream())
         return gx, gy
 
 

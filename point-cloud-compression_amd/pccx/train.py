@@ -358,6 +358,9 @@ class GraphedTrainStep:
     Single-GPU: the data-parallel gradient all-reduce is not captured."""
 
     def __init__(self, model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, loss_type="chamfer", autocast=False, warmup=2):
+        if loss_type != "chamfer":
+            raise _lib.PccxError("GraphedTrainStep: loss_type='chamfer' (what train_pppe_pcd_ae.py:48 builds) is the captured loss; "
+                                 "the smooth-L1 backward still reads its upstream gradient on the host")
         dev = batch_x.device
         self.model, self.opt, self.grad_clip, self.loss_type, self.autocast = model, opt, grad_clip, loss_type, autocast
         opt.make_capturable(dev)
@@ -365,13 +368,14 @@ class GraphedTrainStep:
         self.x = batch_x.detach().clone().contiguous()
         self.starts = [[as_dev(s_) for s_ in starts[0]], as_dev(starts[1]), as_dev(starts[2])]
         self.lam = torch.tensor(float(lam), device=dev, dtype=torch.float32)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                opt.advance()
-                self._body()
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup > 0:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    opt.advance()
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
