@@ -286,9 +286,9 @@ def bench_ipdae(args, rk):
 
         # ---- host-to-host leg (the reference's window): two streams, pinned double buffers ---------------------
         if mode == args.matmul:
-            probe = cd.compress(clouds[:1], starts[:1])
-            row = probe.packed.numel()                                            # bytes per cloud of the packed streams
-            s_stride, p_cap = probe.s_bytes.shape[1], probe.p_bytes.shape[1]
+            from pccx import models as _models                                    # sizes of the packed stream buffer (codec.packed_layout)
+            s_stride, p_cap = (ops.octree_bits_capacity(S) + 7) // 8, _models.range_cap(S * D_LAT)
+            row = codec.packed_layout(1, s_stride, p_cap)[-1]                     # bytes per cloud
             copy_stream = torch.cuda.Stream(device=dev)
             main_stream = torch.cuda.current_stream()
             pin_comp = [torch.empty(row * B, dtype=torch.uint8).pin_memory() for _ in range(2)]
