@@ -467,8 +467,9 @@ def bench_pppf(args, rk):
         print(json.dumps({
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split operands)", "data": "synthetic",
+            "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": args.matmul,
                        "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
             "roofline": rf, "cpu_baseline": None}), flush=True)
 
@@ -559,6 +560,7 @@ def main():
     import pccx
     if args.matmul is None:
         args.matmul = pccx.DEFAULT_MATMUL
+    pccx.DEFAULT_MATMUL = args.matmul            # the generic layers of the secondary workloads follow the flag too
     rk = Ranks(args)
     if rk.world != args.gpus and rk.rank == 0:
         print(f"[bench] note: WORLD_SIZE={rk.world} from the launcher overrides --gpus {args.gpus}", file=sys.stderr)

@@ -262,6 +262,13 @@ PCCX_API int pccx_pack_linear(const float *W_host, int N, int K, float *wp_host)
 PCCX_API int pccx_linear(const float *x, int M, int K, int ldx, const float *wp, const float *bias,
                          int N, int relu, float *out, int ldo, void *stream);
 
+/* The same layer in the bf16x3 arithmetic: pccx_pack_linear_b3 splits the packed f32 fragments (device)
+ * into three bf16 planes per K = 32 block, pccx_linear_b3 forms each fp32 product from six bf16 MFMA products, fp32 accumulate. */
+PCCX_API size_t pccx_packed_linear_b3_floats(int N, int K);
+PCCX_API int pccx_pack_linear_b3(const float *wp_dev, int N, int K, float *wplanes_dev, void *stream);
+PCCX_API int pccx_linear_b3(const float *x, int M, int K, int ldx, const float *wplanes, const float *bias,
+                            int N, int relu, float *out, int ldo, void *stream);
+
 /* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
  * x (G,Kn,C) -> out (G,C). */
 PCCX_API int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream);

@@ -150,6 +150,147 @@ extern "C" int pccx_linear(const float *x, int M, int K, int ldx, const float *w
     return PCCX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same layer in the bf16x3 arithmetic of the tuned path: fp32 products formed from three bf16 pieces
+// per operand, six v_mfma_f32_16x16x32_bf16 per K = 32 block, fp32 accumulate (fp32-level error, 2.6x the f32 MFMA rate).
+// Weights: the packed f32 fragments are split ONCE on the device into planes [kt32][mt][plane] (pccx_pack_linear_b3);
+// activations are split in registers per k-block (two f32x4 fragments = one K = 32 operand, b3_split8) and reused by the MTB
+// column tiles of the wave.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" size_t pccx_packed_linear_b3_floats(int N, int K)
+{
+    if (N < 1 || K < 1) return 0;
+    return (size_t)(((K + 15) / 16 + 1) / 2) * (size_t)((N + 15) / 16) * 3 * 256;
+}
+
+__global__ __launch_bounds__(256) void linear_b3_pack_kernel(const f32x4 *__restrict__ wp, int KT16, int MT, uint4 *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, T = (KT16 + 1) / 2;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)T * MT) return;
+    const int mt = (int)(item % MT), t = (int)(item / MT);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v0 = wp[((size_t)(2 * t) * MT + mt) * 64 + lane];
+    const f32x4 v1 = 2 * t + 1 < KT16 ? wp[((size_t)(2 * t + 1) * MT + mt) * 64 + lane] : zero;   // an odd last k-tile pairs with zeros
+    bf16x8 pl[3];
+    b3_split8(v0, v1, pl);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) out[(((size_t)t * MT + mt) * 3 + p) * 64 + lane] = __builtin_bit_cast(uint4, pl[p]);
+}
+
+// wp_dev: the fragments of pccx_pack_linear (uploaded) or pccx_pack_linear_device -> out_dev: pccx_packed_linear_b3_floats(N,K) floats
+extern "C" int pccx_pack_linear_b3(const float *wp_dev, int N, int K, float *out_dev, void *stream)
+{
+    PCCX_CHECK_ARG(wp_dev && out_dev && N >= 1 && K >= 1, "pccx_pack_linear_b3: bad arguments");
+    const int KT16 = (K + 15) / 16, MT = (N + 15) / 16;
+    const long items = (long)((KT16 + 1) / 2) * MT;
+    hipLaunchKernelGGL(linear_b3_pack_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)wp_dev,
+                       KT16, MT, (uint4 *)out_dev);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+template <int MTB, bool VEC>
+__global__ __launch_bounds__(256) void linear_b3_kernel(const float *__restrict__ x, int M, int K, int ldx, const uint4 *__restrict__ wpl,
+                                                        int KT32, int MT, const float *__restrict__ bias, int N, int relu,
+                                                        float *__restrict__ out, int ldo)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int row0 = (blockIdx.x * 4 + w) * 32;
+    if (row0 >= M) return;                                        // whole wave
+    const int mt0 = blockIdx.y * MTB;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    f32x4 acc[2][MTB];
+#pragma unroll
+    for (int m = 0; m < MTB; ++m) {
+        f32x4 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (mt0 + m) + 4 * g + r;
+            b[r] = (bias && c < N) ? bias[c] : 0.f;
+        }
+        acc[0][m] = b; acc[1][m] = b;
+    }
+    for (int t = 0; t < KT32; ++t) {
+        bf16x8 pl[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int row = row0 + nt * 16 + n;
+            const float *px = x + (size_t)(row < M ? row : M - 1) * ldx;
+            f32x4 v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 32 * t + 16 * h + 4 * g;
+                if (VEC && k + 3 < K) {
+                    v[h] = *(const f32x4 *)(px + k);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[h][r] = k + r < K ? px[k + r] : 0.f;
+                }
+            }
+            b3_split8(v[0], v[1], pl[nt]);
+        }
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) {
+            if (mt0 + m < MT) {                                   // uniform
+                const uint4 *wq = wpl + (((size_t)t * MT + mt0 + m) * 3) * 64 + lane;
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = __builtin_bit_cast(bf16x8, wq[p * 64]);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], pl[0][PB[q]], acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], pl[1][PB[q]], acc[1][m], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int row = row0 + nt * 16 + n;
+        if (row >= M) continue;
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) {
+            const int c = 16 * (mt0 + m) + 4 * g;
+            f32x4 v = acc[nt][m];
+            if (relu) v = relu4(v);
+            float *po = out + (size_t)row * ldo + c;
+            if (VEC && c + 3 < N) {
+                *(f32x4 *)po = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < N) po[r] = v[r];
+            }
+        }
+    }
+}
+
+// pccx_linear with the weights given as bf16x3 planes (pccx_pack_linear_b3); relu: bit 0 only
+extern "C" int pccx_linear_b3(const float *x, int M, int K, int ldx, const float *wplanes, const float *bias, int N, int relu,
+                              float *out, int ldo, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(x && wplanes && out, "pccx_linear_b3: null pointer");
+    PCCX_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && ldx >= K && ldo >= N, "pccx_linear_b3: bad shape M=%d K=%d N=%d ldx=%d ldo=%d", M, K,
+                   N, ldx, ldo);
+    const int KT32 = ((K + 15) / 16 + 1) / 2, MT = (N + 15) / 16;
+    const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    constexpr int MTB = 4;
+    dim3 grid((M + 127) / 128, (MT + MTB - 1) / MTB);
+    PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear_b3: N=%d too large", N);
+    relu &= 1;
+    if (vec)
+        hipLaunchKernelGGL((linear_b3_kernel<MTB, true>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const uint4 *)wplanes,
+                           KT32, MT, bias, N, relu, out, ldo);
+    else
+        hipLaunchKernelGGL((linear_b3_kernel<MTB, false>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const uint4 *)wplanes,
+                           KT32, MT, bias, N, relu, out, ldo);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // out[g][c] = max_k x[g][k][c]   (torch.max(new_features, 3)[0], pointnet_sa_module.py:91)
 __global__ void group_max_kernel(const float *__restrict__ x, long long G, int Kn, int C, float *__restrict__ out)
 {

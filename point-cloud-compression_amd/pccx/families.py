@@ -22,9 +22,11 @@ from .ops import _stream
 
 
 class FoldedLinear:
-    """Conv1x1 / Linear (+ eval BatchNorm) (+ ReLU) packed for pccx_linear."""
+    """Conv1x1 / Linear (+ eval BatchNorm) (+ ReLU) packed for pccx_linear.  matmul: "f32" (exact-fp32 MFMA) or "bf16x3" (fp32
+    products from three bf16 pieces per operand, pccx_linear_b3); None = pccx.DEFAULT_MATMUL at call time (the bf16 planes are
+    built on the device the first time they are needed)."""
 
-    def __init__(self, weight, bias, relu, bn=None, device="cuda"):
+    def __init__(self, weight, bias, relu, bn=None, device="cuda", matmul=None):
         W = weight.detach().to("cpu", torch.float32).reshape(weight.shape[0], -1).clone()
         b = bias.detach().to("cpu", torch.float32).clone() if bias is not None else torch.zeros(W.shape[0])
         if bn is not None:                                  # y = (z - mean) / sqrt(var + eps) * gamma + beta
@@ -36,11 +38,20 @@ class FoldedLinear:
         wp = torch.zeros(_lib.load().pccx_packed_linear_floats(self.N, self.K), dtype=torch.float32)
         _lib.call("pccx_pack_linear", W.data_ptr(), self.N, self.K, wp.data_ptr())
         self.wp, self.b = wp.to(device), b.contiguous().to(device)
+        self.matmul, self.wp3 = matmul, None
 
     def __call__(self, x):
         """x (M,K) f32 contiguous on the GPU -> (M,N)."""
+        from . import DEFAULT_MATMUL
         M = x.shape[0]
         out = torch.empty(M, self.N, device=x.device, dtype=torch.float32)
+        if (self.matmul or DEFAULT_MATMUL) == "bf16x3":
+            if self.wp3 is None:
+                self.wp3 = torch.empty(_lib.load().pccx_packed_linear_b3_floats(self.N, self.K), device=self.wp.device, dtype=torch.float32)
+                _lib.call("pccx_pack_linear_b3", self.wp.data_ptr(), self.N, self.K, self.wp3.data_ptr(), _stream())
+            _lib.call("pccx_linear_b3", x.data_ptr(), M, self.K, x.stride(0), self.wp3.data_ptr(), self.b.data_ptr(), self.N,
+                      self.relu, out.data_ptr(), self.N, _stream())
+            return out
         _lib.call("pccx_linear", x.data_ptr(), M, self.K, x.stride(0), self.wp.data_ptr(), self.b.data_ptr(), self.N,
                   self.relu, out.data_ptr(), self.N, _stream())
         return out

@@ -57,12 +57,22 @@ def test_oracle_families_match_reference(fam, oracle_nets):
     np.testing.assert_allclose(fine[:, ::16].numpy(), fam["pppe_fine_sample"], atol=1e-5, rtol=0)
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def matmul_mode(request):
+    """Both arithmetic modes of the generic layers (pccx_linear / pccx_linear_b3), same tolerances."""
+    import pccx
+    old = pccx.DEFAULT_MATMUL
+    pccx.DEFAULT_MATMUL = request.param
+    yield request.param
+    pccx.DEFAULT_MATMUL = old
+
+
 def _near_boundary(pre, tol):
     return np.abs(pre - np.floor(pre) - 0.5) < tol
 
 
 @pytest.mark.gpu
-def test_pppf_ae_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets):
+def test_pppf_ae_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets, matmul_mode):
     from pccx import families
     m, _ = oracle_nets
     g = families.PPPF_AE(512, 0, 16, 7)
@@ -90,7 +100,7 @@ def test_pppf_ae_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets):
 
 
 @pytest.mark.gpu
-def test_pppe_forward_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets):
+def test_pppe_forward_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets, matmul_mode):
     from pccx import families
     _, p = oracle_nets
     g = families.PointCloudAE(64, 16, 8192)
@@ -117,7 +127,7 @@ def test_pppe_forward_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets)
 
 
 @pytest.mark.gpu
-def test_generic_linear_ragged_shapes():
+def test_generic_linear_ragged_shapes(matmul_mode):
     from pccx import families
     rng = np.random.default_rng(0)
     for M, K, N, relu in [(1, 3, 3, True), (130, 3, 64, True), (257, 131, 128, False), (33, 1027, 128, True),
