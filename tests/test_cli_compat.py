@@ -134,3 +134,53 @@ def test_cli_compress_decompress_eval_end_to_end(tmp_path):
     for _, r in df.iterrows():
         bits = sum(os.stat(comp / (r.filename + e)).st_size * 8 for e in (".s.bin", ".p.bin", ".c.bin"))
         assert abs(r.bpp - bits / 8192) < 1e-12 and np.isfinite(r.p2pointPSNR) and r["uniformity coefficient"] > 0
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_shard_the_files_and_reproduce_the_single_rank_outputs(tmp_path):
+    """compress.py / decompress.py / eval.py under two ranks (pccx.launch.spawn_ranks; gloo stands in for RCCL because the test box
+    has one GPU, which both ranks share): file i -> rank i mod 2, the FPS start is a function of (seed, file index), so every
+    .s/.p/.c.bin, every decoded .ply and the CSV are the ones the single-rank run writes."""
+    from pccx import launch, models
+    K, k, d, L = synth.MODEL_CFG
+    data, mdl = tmp_path / "data", tmp_path / "model"
+    data.mkdir(); mdl.mkdir()
+    for i in range(5):
+        plyio.save_point_cloud(cloud_synth.cad_cloud(160 + i, 8192) * np.float32(2.0), str(data / f"c{i:02d}.ply"))
+    ae = models.AE(K, k, d, L)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    prob = models.ConditionalProbabilityModel(L, d)
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, synth.PROB_SEED, gain=synth.PROB_GAIN))
+    torch.save(ae.state_dict(), str(mdl / "ae.pkl"))
+    torch.save(prob.state_dict(), str(mdl / "prob.pkl"))
+    cli = os.path.join(PKG, "cli")
+    env1 = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    outs = {}
+    for world in (1, 2):
+        comp, dec, csvf = tmp_path / f"comp{world}", tmp_path / f"dec{world}", tmp_path / f"eval{world}.csv"
+        steps = [("compress.py", [str(data / "*.ply"), str(comp), str(mdl), "--batch", "2"]),
+                 ("decompress.py", [str(comp), str(dec), str(mdl), "--batch", "2", "--bin-ply-suffix"]),
+                 ("eval.py", ["--input_glob", str(data / "*.ply"), "--compressed_path", str(comp), "--decompressed_path", str(dec),
+                              "--output_file", str(csvf)])]
+        for script, argv in steps:
+            if world == 1:
+                subprocess.run([sys.executable, os.path.join(cli, script), *argv], check=True, capture_output=True, text=True,
+                               timeout=600, env=env1)
+            else:
+                code = ("import sys; sys.path.insert(0, %r); from pccx import launch; "
+                        "sys.exit(launch.spawn_ranks(%r, %r, 2, extra_env={'PCCX_DIST_BACKEND': 'gloo'}))"
+                        % (PKG, os.path.join(cli, script), argv))
+                r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env1)
+                assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = (comp, dec, csvf)
+    names = sorted(os.listdir(outs[1][0]))
+    assert names == sorted(os.listdir(outs[2][0])) and len(names) == 15
+    for n in names:
+        assert open(outs[1][0] / n, "rb").read() == open(outs[2][0] / n, "rb").read(), n
+    for n in sorted(os.listdir(outs[1][1])):
+        assert np.array_equal(plyio.read_point_cloud(str(outs[1][1] / n)), plyio.read_point_cloud(str(outs[2][1] / n))), n
+    import pandas as pd
+    a, b = pd.read_csv(outs[1][2]), pd.read_csv(outs[2][2])
+    assert list(a.filename) == list(b.filename) and len(a) == 5
+    for col in ("p2pointPSNR", "p2planePSNR", "chamfer_distance", "bpp", "uniformity coefficient"):
+        assert np.allclose(a[col].values, b[col].values, rtol=0, atol=0), col
