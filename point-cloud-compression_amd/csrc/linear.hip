@@ -44,12 +44,22 @@ __device__ __forceinline__ f32x4 round_bf16x4(const f32x4 &v)
     return __builtin_convertvector(__builtin_convertvector(v, bf16x4v), f32x4);
 }
 
+// Column tiles per wave: wide (fewer re-reads of the rows) only while the grid still fills the chip several times over --
+// a layer with few rows (the decoder's 4 x 1024 -> 24576 Linear of the pppe model) needs its parallelism from the columns.
+static int pccx_linear_col_tiles(int M, int MT)
+{
+    const long rowblocks = ((long)M + 127) / 128;
+    if (MT >= 16 && rowblocks * ((MT + 15) / 16) >= 2048) return 16;
+    if (MT >= 8 && rowblocks * ((MT + 7) / 8) >= 2048) return 8;
+    return 4;
+}
+
 // out[M][N] = act(x[M][K] . W^T + b).  Block = 4 waves; wave = 32 rows (2 point tiles) x MTB*16 columns.
 // BF16 = the autocast form (train_pppe_pcd_ae.py:193-217, torch.cuda.amp.autocast around the forward): both operands rounded to
 // bf16, products on the bf16 matrix cores (one v_mfma_f32_16x16x16_bf16 per k-tile: its lane map -- four consecutive k per
 // lane -- is exactly the f32 fragment's), fp32 accumulate, result rounded to bf16 (the layer's output dtype under autocast).
 template <int MTB, bool VEC, bool BF16>
-__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ x, int M, int K, int ldx,
+__global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict__ x, int M, int K, int ldx,
                                                      const f32x4 *__restrict__ wp, int KT, int MT,
                                                      const float *__restrict__ bias, int N, int relu,
                                                      float *__restrict__ out, int ldo)
@@ -134,18 +144,26 @@ extern "C" int pccx_linear(const float *x, int M, int K, int ldx, const float *w
     if (M == 0) return PCCX_OK;
     const int KT = (K + 15) / 16, MT = (N + 15) / 16;
     const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
-    constexpr int MTB = 4;
-    dim3 grid((M + 127) / 128, (MT + MTB - 1) / MTB);
-    PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear: N=%d too large", N);
+    // columns per wave: every column block re-reads the wave's x rows, so wide layers take 16 column tiles per wave (a 512 -> 1024
+    // layer on 8.4 M rows re-read its 17 GB input 16 times with 4 tiles per wave: 114 ms, bandwidth-bound)
     const bool bf16 = (relu & 2) != 0;                     // flags: bit 0 = ReLU, bit 1 = autocast (bf16 operands and result)
     relu &= 1;
-#define PCCX_LIN_LAUNCH(V, B)                                                                                                  \
-    hipLaunchKernelGGL((linear_kernel<MTB, V, B>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp, KT, MT, \
+    const int mtb = pccx_linear_col_tiles(M, MT);
+    dim3 grid((M + 127) / 128, (MT + mtb - 1) / mtb);
+    PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear: N=%d too large", N);
+#define PCCX_LIN_LAUNCH(MTB_, V, B)                                                                                             \
+    hipLaunchKernelGGL((linear_kernel<MTB_, V, B>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const f32x4 *)wp, KT, MT, \
                        bias, N, relu, out, ldo)
-    if (vec && bf16) PCCX_LIN_LAUNCH(true, true);
-    else if (vec) PCCX_LIN_LAUNCH(true, false);
-    else if (bf16) PCCX_LIN_LAUNCH(false, true);
-    else PCCX_LIN_LAUNCH(false, false);
+#define PCCX_LIN_LAUNCH_M(MTB_)                                                                                                 \
+    do {                                                                                                                        \
+        if (vec && bf16) PCCX_LIN_LAUNCH(MTB_, true, true);                                                                     \
+        else if (vec) PCCX_LIN_LAUNCH(MTB_, true, false);                                                                       \
+        else if (bf16) PCCX_LIN_LAUNCH(MTB_, false, true);                                                                      \
+        else PCCX_LIN_LAUNCH(MTB_, false, false);                                                                               \
+    } while (0)
+    if (mtb == 16) PCCX_LIN_LAUNCH_M(16);
+    else if (mtb == 8) PCCX_LIN_LAUNCH_M(8);
+    else PCCX_LIN_LAUNCH_M(4);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
@@ -191,7 +209,7 @@ extern "C" int pccx_pack_linear_b3(const float *wp_dev, int N, int K, float *out
 }
 
 template <int MTB, bool VEC>
-__global__ __launch_bounds__(256) void linear_b3_kernel(const float *__restrict__ x, int M, int K, int ldx, const uint4 *__restrict__ wpl,
+__global__ __launch_bounds__(256, 2) void linear_b3_kernel(const float *__restrict__ x, int M, int K, int ldx, const uint4 *__restrict__ wpl,
                                                         int KT32, int MT, const float *__restrict__ bias, int N, int relu,
                                                         float *__restrict__ out, int ldo)
 {
@@ -277,16 +295,16 @@ extern "C" int pccx_linear_b3(const float *x, int M, int K, int ldx, const float
                    N, ldx, ldo);
     const int KT32 = ((K + 15) / 16 + 1) / 2, MT = (N + 15) / 16;
     const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
-    constexpr int MTB = 4;
-    dim3 grid((M + 127) / 128, (MT + MTB - 1) / MTB);
+    const int mtb = pccx_linear_col_tiles(M, MT);          // as pccx_linear: fewer re-reads of x for wide layers
+    dim3 grid((M + 127) / 128, (MT + mtb - 1) / mtb);
     PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear_b3: N=%d too large", N);
     relu &= 1;
-    if (vec)
-        hipLaunchKernelGGL((linear_b3_kernel<MTB, true>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const uint4 *)wplanes,
-                           KT32, MT, bias, N, relu, out, ldo);
-    else
-        hipLaunchKernelGGL((linear_b3_kernel<MTB, false>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const uint4 *)wplanes,
-                           KT32, MT, bias, N, relu, out, ldo);
+#define PCCX_LINB3_LAUNCH(MTB_, V)                                                                                              \
+    hipLaunchKernelGGL((linear_b3_kernel<MTB_, V>), grid, dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, (const uint4 *)wplanes, \
+                       KT32, MT, bias, N, relu, out, ldo)
+    if (mtb == 16) { if (vec) PCCX_LINB3_LAUNCH(16, true); else PCCX_LINB3_LAUNCH(16, false); }
+    else if (mtb == 8) { if (vec) PCCX_LINB3_LAUNCH(8, true); else PCCX_LINB3_LAUNCH(8, false); }
+    else { if (vec) PCCX_LINB3_LAUNCH(4, true); else PCCX_LINB3_LAUNCH(4, false); }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -57,6 +57,23 @@ class FoldedLinear:
         return out
 
 
+def cat_rows(parts):
+    """torch.cat(parts, dim=-1) flattened to rows, written into a buffer whose row stride is a multiple of 4 floats: the layer
+    kernels then take their 16-byte vector loads whatever the channel count (3, 131, 259, 1026 ...).  Returns the (rows, C) view."""
+    lead = parts[0].shape[:-1]
+    rows = 1
+    for d_ in lead:
+        rows *= int(d_)
+    C = sum(int(p.shape[-1]) for p in parts)
+    buf = torch.empty(rows, (C + 3) // 4 * 4, device=parts[0].device, dtype=torch.float32)
+    off = 0
+    for p in parts:
+        c = int(p.shape[-1])
+        buf[:, off:off + c].copy_(p.reshape(rows, c))
+        off += c
+    return buf[:, :C]
+
+
 def group_max(x):
     """(G,Kn,C) -> (G,C)."""
     G, Kn, Cc = x.shape
@@ -122,9 +139,7 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
         new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)                   # :66-68 (start index 0)
         idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
         grouped = ops.index_points(xyz, idx)                                        # :81 (not centred)
-        if feats is not None:
-            grouped = torch.cat([ops.index_points(feats, idx), grouped], dim=-1)    # :83 features first, xyz last
-        x = grouped.reshape(-1, grouped.shape[-1]).contiguous()
+        x = cat_rows([ops.index_points(feats, idx), grouped] if feats is not None else [grouped])   # :83 features first, xyz last
         for layer in stack:
             x = layer(x)                                                            # :90 Conv-BN-ReLU
         return new_xyz, group_max(x.view(B * self.npoint, self.nsample, -1)).view(B, self.npoint, -1)   # :91
@@ -187,10 +202,10 @@ class PPPF_AE(_Packable):
         lat_dec = pk["dec"](q)                                                      # :145
         P = self.decoder.num_points
         rep = lat_dec[:, None, :].expand(B, P, self.dim)
-        x = torch.cat([pk["grid"][None].expand(B, P, 2), rep], dim=-1).reshape(B * P, -1).contiguous()   # :99-101
+        x = cat_rows([pk["grid"][None].expand(B, P, 2), rep])                                             # :99-101
         for layer in pk["mlp1"]:
             x = layer(x)                                                            # :104 coarse
-        x = torch.cat([x.view(B, P, 3), rep], dim=-1).reshape(B * P, -1).contiguous()                      # :106
+        x = cat_rows([x.view(B, P, 3), rep])                                                                # :106
         for layer in pk["mlp2"]:
             x = layer(x)                                                            # :107 fine
         return x.view(B, P, 3), latent, q
@@ -233,10 +248,7 @@ class PointNetSetAbstraction(nn.Module):                # pppe_pcd_ae.py:573-611
         S = self.npoint
         new_xyz = xyz if S == N else ops.index_points(xyz, ops.farthest_point_sample_batch(xyz, S, start))   # :593-597
         nn_ = ops.knn_points(new_xyz, xyz, self.K, patch_scale=1.0)                  # :599-600 (nn - centre) * 1
-        grouped = nn_.knn
-        if feats is not None:
-            grouped = torch.cat([grouped, ops.index_points(feats, nn_.idx)], dim=-1)  # :606 xyz first
-        x = grouped.reshape(-1, grouped.shape[-1]).contiguous()
+        x = cat_rows([nn_.knn, ops.index_points(feats, nn_.idx)] if feats is not None else [nn_.knn])   # :606 xyz first
         for layer in stack:
             x = layer(x)
         return new_xyz, group_max(x.view(B * S, self.K, -1)).view(B, S, -1)          # :610
