@@ -169,6 +169,40 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
+// Wave-wide argmax of (value, index) pairs with torch.max's tie rule (largest value, then smallest index), without LDS traffic:
+// four DPP butterfly steps make every lane of a 16-lane row hold its row's winner (row_mirror, row_half_mirror, two quad
+// permutes: a few cycles each, where ds_bpermute -- what __shfl_xor compiles to -- costs an LDS round trip per step and made a
+// round of FPS ~2 us), then the four row winners are read as scalars and merged.  Returns the winner in every lane.
+__device__ __forceinline__ void row16_argmax(float &v, int &i)
+{
+#define PCCX_DPP_STEP(CTRL)                                                                              \
+    {                                                                                                    \
+        const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); \
+        const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, true);                          \
+        argmax_merge(v, i, ov, oi);                                                                      \
+    }
+    PCCX_DPP_STEP(0x140)   // row_mirror
+    PCCX_DPP_STEP(0x141)   // row_half_mirror
+    PCCX_DPP_STEP(0x1B)    // quad_perm [3,2,1,0]
+    PCCX_DPP_STEP(0xB1)    // quad_perm [1,0,3,2]
+#undef PCCX_DPP_STEP
+}
+
+__device__ __forceinline__ void wave_argmax(float &v, int &i)
+{
+    row16_argmax(v, i);
+    float rv[4];
+    int ri[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rv[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r));
+        ri[r] = __builtin_amdgcn_readlane(i, 16 * r);
+    }
+    v = rv[0]; i = ri[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) argmax_merge(v, i, rv[r], ri[r]);
+}
+
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
                                                    const int32_t *__restrict__ start, int64_t *__restrict__ out,
@@ -181,18 +215,25 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *p = xyz + (size_t)b * N * 3;
 
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    // Points live in registers in PAIRS (point tid + 2j*1024 and tid + (2j+1)*1024): the three differences, squares and the two adds
+    // of a round run as packed fp32 (v_pk_add_f32 / v_pk_mul_f32, no contraction: -ffp-contract=off), i.e. the operation sequence
+    // of pccx_sqdist per point at half the instruction count -- a round is bound by the VALU work of the CU's 8192 points.
+    constexpr int PP = (PPT + 1) / 2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 px[PP], py[PP], pz[PP], md[PP];
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        int i = tid + j * 1024;
-        if (i < N) {
-            px[j] = p[3 * i]; py[j] = p[3 * i + 1]; pz[j] = p[3 * i + 2];
-            md[j] = 1e10f;                 // distance = ones * 1e10 (:320)
-        } else {
-            px[j] = py[j] = pz[j] = 0.f;
-            md[j] = -INFINITY;             // never selected
+    for (int j = 0; j < PP; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + (2 * j + e) * 1024;
+            if (2 * j + e < PPT && i < N) {
+                px[j][e] = p[3 * i]; py[j][e] = p[3 * i + 1]; pz[j][e] = p[3 * i + 2];
+                md[j][e] = 1e10f;              // distance = ones * 1e10 (:320)
+            } else {
+                px[j][e] = py[j][e] = pz[j][e] = 0.f;
+                md[j][e] = -INFINITY;          // never selected
+            }
         }
-    }
     if (use_lds)
         for (int i = tid; i < 3 * N; i += 1024) sx[i] = p[i];
     __syncthreads();
@@ -207,28 +248,24 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
         float best = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            float d = pccx_sqdist(px[j], py[j], pz[j], cx, cy, cz);   // (:326)
-            if (d < md[j]) md[j] = d;                                 // (:327-328)
-            if (md[j] > best) { best = md[j]; bi = tid + j * 1024; }  // ascending index, strict '>'
-        }
+        for (int j = 0; j < PP; ++j) {
+            const f32x2 dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;   // (:326): (x - c)^2 summed x, y, z
+            f32x2 d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
 #pragma unroll
-        for (int o = 32; o; o >>= 1) {
-            float ov = __shfl_xor(best, o);
-            int oi = __shfl_xor(bi, o);
-            argmax_merge(best, bi, ov, oi);
+            for (int e = 0; e < 2; ++e) {
+                if (d[e] < md[j][e]) md[j][e] = d[e];                         // (:327-328)
+                if (md[j][e] > best) { best = md[j][e]; bi = tid + (2 * j + e) * 1024; }   // ascending index, strict '>'
+            }
         }
+        wave_argmax(best, bi);
         if (lane == 0) { part_v[par * 16 + w] = best; part_i[par * 16 + w] = bi; }
         __syncthreads();
-        float v = lane < 16 ? part_v[par * 16 + lane] : -INFINITY;
-        int vi = lane < 16 ? part_i[par * 16 + lane] : 0x7fffffff;
-#pragma unroll
-        for (int o = 8; o; o >>= 1) {
-            float ov = __shfl_xor(v, o);
-            int oi = __shfl_xor(vi, o);
-            argmax_merge(v, vi, ov, oi);
-        }
-        far = __shfl(vi, 0);                                          // torch.max(distance,-1)[1] (:329)
+        float v = part_v[par * 16 + (lane & 15)];                     // the 16 wave winners, one per lane of every row
+        int vi = part_i[par * 16 + (lane & 15)];
+        row16_argmax(v, vi);
+        far = __builtin_amdgcn_readfirstlane(vi);                     // torch.max(distance,-1)[1] (:329)
         par ^= 1;
     }
 }
@@ -258,23 +295,13 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
             if (d < m) { m = d; md[i] = d; }
             if (m > best) { best = m; bi = i; }
         }
-#pragma unroll
-        for (int o = 32; o; o >>= 1) {
-            float ov = __shfl_xor(best, o);
-            int oi = __shfl_xor(bi, o);
-            argmax_merge(best, bi, ov, oi);
-        }
+        wave_argmax(best, bi);
         if (lane == 0) { part_v[par][w] = best; part_i[par][w] = bi; }
         __syncthreads();
-        float v = lane < 16 ? part_v[par][lane] : -INFINITY;
-        int vi = lane < 16 ? part_i[par][lane] : 0x7fffffff;
-#pragma unroll
-        for (int o = 8; o; o >>= 1) {
-            float ov = __shfl_xor(v, o);
-            int oi = __shfl_xor(vi, o);
-            argmax_merge(v, vi, ov, oi);
-        }
-        far = __shfl(vi, 0);
+        float v = part_v[par][lane & 15];
+        int vi = part_i[par][lane & 15];
+        row16_argmax(v, vi);
+        far = __builtin_amdgcn_readfirstlane(vi);
         par ^= 1;
     }
 }
