@@ -81,6 +81,11 @@ PCCX_API int pccx_knn(const float *q, int B, int M, const float *ref, int N, int
  * index order with d2 < radius^2, padded with -1 (dists padded with 0). */
 PCCX_API int pccx_ball_query(const float *q, int B, int M, const float *ref, int N, int K,
                              float radius, float *dists, int64_t *idx, void *stream);
+/* The same query through a uniform grid hash of the candidates (cells of side >= radius, 27-cell walk, index order restored by
+ * a bitmap): identical results, for large N / small radius.  workspace: pccx_ball_query_grid_workspace_ints(B, N) int32; N <= 32768. */
+PCCX_API size_t pccx_ball_query_grid_workspace_ints(int B, int N);
+PCCX_API int pccx_ball_query_grid(const float *q, int B, int M, const float *ref, int N, int K, float radius,
+                                  int32_t *workspace, float *dists, int64_t *idx, void *stream);
 
 /* One-directional nearest neighbour: for each x in X (B,P,3) the min over Y (B,Q,3) of |x-y|^2.
  * d2: (B,P); nn: (B,P) int32 or NULL.  Building block of pytorch3d chamfer_distance (AE.py:67,

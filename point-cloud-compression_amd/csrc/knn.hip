@@ -443,6 +443,165 @@ extern "C" int pccx_ball_query(const float *q, int B, int M, const float *ref, i
 }
 
 // ------------------------------------------------------------------------------------------
+// ball query through a uniform grid hash (north_star: "ball-query as a coalesced grid-hash neighbour search";
+// pointnet_sa_module.py:18).  For large candidate sets and small radii the scan above visits every candidate up to the K-th hit;
+// here the candidates of a cloud are binned once into cells of side >= r (bq_grid_build_kernel: bounding box, cell histogram and
+// exclusive scan in LDS, scatter into a per-cloud cell-ordered index list), and a query visits only the 27 cells around its own
+// (9 contiguous runs of the list: the three z-neighbours of a column are adjacent).  pytorch3d's result is the first K hits IN
+// INDEX ORDER, which a cell walk does not produce: every hit sets its bit in a per-wave LDS bitmap over the N candidates, and
+// the bitmap is then read out in order (popcount prefix across the lanes), which restores the index order for free.
+// Results are identical to the scan (same pccx_sqdist, same strict d2 < r2 test); pccx.ops.ball_query picks the grid when the
+// box is at least four cells wide and N >= 4096.
+// ------------------------------------------------------------------------------------------
+#define BQ_GMAX 16                                   // cells per axis (<= 4096 cells: the histogram lives in LDS)
+#define BQ_NMAX 32768                                // candidates per cloud (4 KiB of bitmap per wave)
+
+// workspace per cloud (int32): [0..7] grid parameters (lo xyz and 1/cell as float bits, G), [8 .. 8+4096] cell starts, then N sorted indices
+extern "C" size_t pccx_ball_query_grid_workspace_ints(int B, int N) { return (size_t)(B > 0 ? B : 0) * (size_t)(8 + BQ_GMAX * BQ_GMAX * BQ_GMAX + 1 + (N > 0 ? N : 0)); }
+
+__device__ __forceinline__ int bq_cell(float v, float lo, float inv, int G)
+{
+    int c = (int)floorf((v - lo) * inv);
+    return c < 0 ? 0 : (c > G - 1 ? G - 1 : c);
+}
+
+__global__ __launch_bounds__(256) void bq_grid_build_kernel(const float *__restrict__ ref, int N, float radius, int32_t *__restrict__ ws,
+                                                            size_t ws_stride)
+{
+    __shared__ float red[6][256];
+    __shared__ int hist[BQ_GMAX * BQ_GMAX * BQ_GMAX + 1];
+    __shared__ int scan_tmp[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *rp = ref + (size_t)b * N * 3;
+    int32_t *w = ws + (size_t)b * ws_stride;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = rp[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[a][tid] = lo[a]; red[3 + a][tid] = hi[a]; }
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                red[a][tid] = fminf(red[a][tid], red[a][tid + o]);
+                red[3 + a][tid] = fmaxf(red[3 + a][tid], red[3 + a][tid + o]);
+            }
+        __syncthreads();
+    }
+    const float ext = fmaxf(fmaxf(red[3][0] - red[0][0], red[4][0] - red[1][0]), red[5][0] - red[2][0]);
+    int G = (int)floorf(ext / (radius * 1.0001f));       // cell = ext / G >= 1.0001 radius: the margin absorbs the rounding of the cell index
+    G = G < 1 ? 1 : (G > BQ_GMAX ? BQ_GMAX : G);
+    const float cell = ext > 0.f ? ext / (float)G : 1.f, inv = 1.f / cell;
+    const float lx = red[0][0], ly = red[1][0], lz = red[2][0];
+    const int cells = G * G * G;
+    for (int c = tid; c <= cells; c += 256) hist[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const int c = (bq_cell(rp[3 * i], lx, inv, G) * G + bq_cell(rp[3 * i + 1], ly, inv, G)) * G + bq_cell(rp[3 * i + 2], lz, inv, G);
+        atomicAdd(&hist[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan of hist[0..cells): each thread owns a contiguous slice
+    const int per = (cells + 255) / 256;
+    int local = 0;
+    for (int k = 0; k < per; ++k) { const int c = tid * per + k; if (c < cells) local += hist[c]; }
+    scan_tmp[tid] = local;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int v = scan_tmp[t]; scan_tmp[t] = run; run += v; } }
+    __syncthreads();
+    int run = scan_tmp[tid];
+    for (int k = 0; k < per; ++k) { const int c = tid * per + k; if (c < cells) { const int v = hist[c]; hist[c] = run; run += v; } }
+    if (tid == 0) hist[cells] = N;
+    __syncthreads();
+    for (int c = tid; c <= cells; c += 256) w[8 + c] = hist[c];
+    if (tid == 0) { w[0] = __float_as_int(lx); w[1] = __float_as_int(ly); w[2] = __float_as_int(lz); w[3] = __float_as_int(inv); w[4] = G; }
+    __syncthreads();                                      // hist now serves as the scatter cursors
+    int32_t *sorted = w + 8 + BQ_GMAX * BQ_GMAX * BQ_GMAX + 1;
+    for (int i = tid; i < N; i += 256) {
+        const int c = (bq_cell(rp[3 * i], lx, inv, G) * G + bq_cell(rp[3 * i + 1], ly, inv, G)) * G + bq_cell(rp[3 * i + 2], lz, inv, G);
+        sorted[atomicAdd(&hist[c], 1)] = i;               // order inside a cell is irrelevant: the bitmap restores index order
+    }
+}
+
+__global__ __launch_bounds__(256) void bq_grid_query_kernel(const float *__restrict__ q, int M, const float *__restrict__ ref, int N, int K,
+                                                            float r2, const int32_t *__restrict__ ws, size_t ws_stride,
+                                                            float *__restrict__ dists, int64_t *__restrict__ idx)
+{
+    extern __shared__ unsigned bq_bits[];                 // [4 waves][words]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wv, b = blockIdx.y;
+    if (m >= M) return;                                   // whole wave exits together (no block barrier below)
+    const int words = (N + 31) >> 5;
+    unsigned *bits = bq_bits + (size_t)wv * words;
+    for (int t = lane; t < words; t += 64) bits[t] = 0u;
+    const int32_t *w = ws + (size_t)b * ws_stride;
+    const float lx = __int_as_float(w[0]), ly = __int_as_float(w[1]), lz = __int_as_float(w[2]), inv = __int_as_float(w[3]);
+    const int G = w[4];
+    const int32_t *cstart = w + 8, *sorted = w + 8 + BQ_GMAX * BQ_GMAX * BQ_GMAX + 1;
+    const float *rp = ref + (size_t)b * N * 3;
+    const size_t qo = ((size_t)b * M + m) * 3;
+    const float qx = q[qo], qy = q[qo + 1], qz = q[qo + 2];
+    const int cx = bq_cell(qx, lx, inv, G), cy = bq_cell(qy, ly, inv, G), cz = bq_cell(qz, lz, inv, G);
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ix = cx + dx, iy = cy + dy;
+            if (ix < 0 || ix >= G || iy < 0 || iy >= G) continue;             // wave-uniform
+            const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz < G - 1 ? cz + 1 : G - 1;
+            const int col = (ix * G + iy) * G;
+            const int p0 = cstart[col + z0], p1 = cstart[col + z1 + 1];       // one contiguous run of the cell-ordered list
+            for (int p = p0 + lane; p < p1; p += 64) {
+                const int i = sorted[p];
+                if (pccx_sqdist(qx, qy, qz, rp[3 * i], rp[3 * i + 1], rp[3 * i + 2]) < r2) atomicOr(&bits[i >> 5], 1u << (i & 31));
+            }
+        }
+    // (LDS operations of one wave complete in order; the atomics above are visible to the reads below)
+    const size_t ob = ((size_t)b * M + m) * K;
+    int count = 0;
+    for (int base = 0; base < words && count < K; base += 64) {
+        const int t = base + lane;
+        unsigned wbits = t < words ? bits[t] : 0u;
+        const int pc = __popc(wbits);
+        int incl = pc;                                    // inclusive prefix sum of the popcounts across the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int pos = count + incl - pc;
+        while (wbits && pos < K) {
+            const int bit = __ffs(wbits) - 1;
+            wbits &= wbits - 1;
+            const int i = 32 * t + bit;
+            dists[ob + pos] = pccx_sqdist(qx, qy, qz, rp[3 * i], rp[3 * i + 1], rp[3 * i + 2]);
+            idx[ob + pos] = i;
+            ++pos;
+        }
+        count += __shfl(incl, 63);
+    }
+    if (count > K) count = K;
+    for (int k = count + lane; k < K; k += 64) { dists[ob + k] = 0.f; idx[ob + k] = -1; }
+}
+
+extern "C" int pccx_ball_query_grid(const float *q, int B, int M, const float *ref, int N, int K, float radius, int32_t *workspace,
+                                    float *dists, int64_t *idx, void *stream)
+{
+    if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(q && ref && dists && idx && workspace, "pccx_ball_query_grid: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1 && N <= BQ_NMAX && K >= 1 && radius > 0.f, "pccx_ball_query_grid: bad shape (N <= %d)", BQ_NMAX);
+    PCCX_CHECK_ARG(B <= 65535, "pccx_ball_query_grid: B=%d > 65535 unsupported", B);
+    const size_t stride = (size_t)8 + BQ_GMAX * BQ_GMAX * BQ_GMAX + 1 + (size_t)N;
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ref, N, radius, workspace, stride);
+    PCCX_CHECK_LAUNCH();
+    const size_t lds = (size_t)4 * ((N + 31) / 32) * 4;
+    hipLaunchKernelGGL(bq_grid_query_kernel, dim3((M + 3) / 4, B), dim3(256), lds, (hipStream_t)stream, q, M, ref, N, K, radius * radius,
+                       workspace, stride, dists, idx);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // nn_dist: LDS-tiled all-pairs min-reduce.  A 256-thread workgroup owns 1024 query points
 // (4 per thread, registers) and streams the other cloud through LDS in tiles of 1024 points
 // (12 KiB); every lane reads the same LDS address (broadcast, conflict-free), so one 12-byte LDS

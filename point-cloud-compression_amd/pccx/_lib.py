@@ -21,6 +21,8 @@ _SIGNATURES = {
     "pccx_gather": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_knn": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P],
     "pccx_ball_query": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P],
+    "pccx_ball_query_grid_workspace_ints": [C.c_int, C.c_int],
+    "pccx_ball_query_grid": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P],
     "pccx_nn_dist": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],
     "pccx_chamfer_grad": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P],
     "pccx_chamfer_grad_dev": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P],
@@ -85,7 +87,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
-             "pccx_packed_linear_floats": C.c_size_t, "pccx_packed_linear_b3_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t, "pccx_pn_b3_blob_floats": C.c_size_t,
+             "pccx_packed_linear_floats": C.c_size_t, "pccx_ball_query_grid_workspace_ints": C.c_size_t, "pccx_packed_linear_b3_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t, "pccx_pn_b3_blob_floats": C.c_size_t,
              "pccx_ae_decode_b3_workspace_floats": C.c_size_t}
 
 _lib = None

@@ -117,16 +117,37 @@ def test_knn_patches_fused_centre_and_scale():
     assert np.array_equal(r.knn[0].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("N,M,K,r", [(512, 128, 32, 0.2), (2048, 100, 64, 0.4), (100, 7, 128, 0.8), (777, 3, 5, 0.05)])
-def test_ball_query_vs_oracle(N, M, K, r):
+@pytest.mark.parametrize("method", ["scan", "grid"])
+@pytest.mark.parametrize("N,M,K,r", [(512, 128, 32, 0.2), (2048, 100, 64, 0.4), (100, 7, 128, 0.8), (777, 3, 5, 0.05),
+                                     (20000, 300, 48, 0.04), (32768, 64, 16, 0.02), (5000, 50, 8, 2.0), (1, 4, 3, 0.5)])
+def test_ball_query_vs_oracle(N, M, K, r, method):
+    """Both ball-query kernels -- the ordered scan and the grid hash (cells >= r, 27-cell walk, bitmap read-out) -- against the
+    oracle: the first K in-radius candidates IN INDEX ORDER, -1 padded, exact distances.  Includes a radius larger than the
+    cloud (one cell), a one-point cloud, queries outside the candidates' bounding box and points on cell boundaries."""
     rng = np.random.default_rng(N + K)
     ref = rng.random((2, N, 3)).astype(np.float32)
-    q = rng.random((2, M, 3)).astype(np.float32)
-    got = ops.ball_query(dev(q), dev(ref), K, r)
+    q = (rng.random((2, M, 3)) * 1.3 - 0.15).astype(np.float32)          # some queries lie outside the candidates' box
+    if N >= 16:
+        ref[0, :8] = np.round(ref[0, :8] * 8) / 8                        # points exactly on cell faces
+        q[0, :min(4, M)] = ref[0, :min(4, M)]
+    got = ops.ball_query(dev(q), dev(ref), K, r, method=method)
     for b in range(2):
         d, i = cport.ball_query(q[b], ref[b], K, r)
         assert np.array_equal(got.idx[b].cpu().numpy(), i)
         assert np.array_equal(got.dists[b].cpu().numpy(), d)
+
+
+def test_ball_query_grid_on_a_room_scale_block_matches_the_scan():
+    """The grid hash where it is meant to be used: 32 768 candidates of a room-like cloud (planes: very uneven cells), radius
+    5 cm, 2048 queries -- identical to the scan."""
+    from pccx import synth as cloud_synth
+    pc = cloud_synth.room_cloud(100, 32768)
+    ref = dev(pc[None])
+    q = dev(pc[None, ::16].copy())
+    a = ops.ball_query(q, ref, 32, 0.05, method="scan")
+    b = ops.ball_query(q, ref, 32, 0.05, method="grid")
+    assert torch.equal(a.idx, b.idx) and torch.equal(a.dists, b.dists)
+    assert int((a.idx >= 0).sum()) > 2048                                   # neighbourhoods are not empty
 
 
 @pytest.mark.parametrize("P,Q", [(8192, 8192), (1000, 3000), (1, 5), (5000, 1), (4097, 1025)])
