@@ -24,6 +24,7 @@ from pccx import models, ops, synth  # noqa: E402
 
 HBM_PEAK = 8000.0          # GB/s
 MFMA_F32_PEAK = 157.3      # TFLOP/s
+MFMA_B3_PEAK = 16 * 157.3 / 6   # fp32-equivalent TFLOP/s of the bf16x3 arithmetic: bf16 dense peak / six products
 VALU_F32_PEAK = 78.6       # TFLOP/s of non-fused packed fp32 (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 
 
@@ -73,9 +74,17 @@ def main():
         "S*N*12 B of candidate reads per cloud (L2/LDS side; HBM minimum 98 KB) + outputs")
     qb = xyz[:, :512].contiguous()
     cb = ops.sample_farthest_points(qb, 128)[0]
-    ms = timed(lambda: ops.ball_query(cb, qb, 64, 0.2), args.iters)
-    row("ball_query 128x512 r=0.2 nsample=64", ms, "hbm", B * (128 * 512 * 12 + 128 * 64 * 8), "GB/s", HBM_PEAK,
-        "PPPF sa1 shape (pointnet_sa_module.py:18); candidates broadcast from LDS")
+    ms = timed(lambda: ops.ball_query(cb, qb, 64, 0.2, method="scan"), args.iters)
+    row("ball_query scan 128x512 r=0.2 nsample=64", ms, "hbm", B * (128 * 512 * 12 + 128 * 64 * 8), "GB/s", HBM_PEAK,
+        "PPPF sa1 shape (pointnet_sa_module.py:18): ordered scan with early exit")
+    nb8 = min(B, 64)
+    big = xyz[:nb8].reshape(nb8 // 4, 4 * N, 3).contiguous()                      # 32768-point candidate sets
+    qbig = big[:, ::4].contiguous()
+    for meth in ("scan", "grid"):
+        ms = timed(lambda: ops.ball_query(qbig, big, 32, 0.05, method=meth), args.iters)
+        row(f"ball_query {meth} 8192x32768 r=0.05 nsample=32", ms, "hbm", (nb8 // 4) * (8192 * 27 * 12 * 40 + 32768 * 24 + 8192 * 32 * 12), "GB/s",
+            HBM_PEAK, "grid hash: ~27 cells x ~40 candidates of 12 B per query + the binning pass + outputs (the scan reads up to "
+            "all 32768 candidates per query from L2)")
     patches = ops.knn_points(centres, xyz, K, True, 2.0)[2]
     ms = timed(lambda: ops.octree_encode(centres, N, 0.25), args.iters)
     row("octree_encode (depth search + bits + bytes)", ms, "hbm", B * (S * 12 + 400), "GB/s", HBM_PEAK, "one wave per cloud: latency bound")
@@ -91,19 +100,21 @@ def main():
     ae.pack(dev)
     prob.pack(dev)
     pt = patches.reshape(B * S, K, 3)
-    for _ in range(2):
-        ae.encode(pt)
-    t = ops.StageTimer()
-    ops.set_timer(t)
-    for _ in range(args.iters):
-        lq = ae.encode(pt)[2]
-    st = t.totals_ms()
-    ops.set_timer(None)
-    for name, flop in (("sa_forward", 84.7e6), ("pn_forward", 96.7e6)):
-        row(name, st[name][0] / st[name][1], "mfma", B * S * flop, "TFLOP/s", MFMA_F32_PEAK,
-            "fp32 matrix cores; flop per patch from the layer shapes of AE.py:16-17")
-    row("ae_decode (head + main)", timed(lambda: ae.decode(lq), args.iters), "mfma", B * S * 41.4e6, "TFLOP/s", MFMA_F32_PEAK,
-        "fp32 matrix cores; AE.py:19-27")
+    for mode, peak in (("f32", MFMA_F32_PEAK), ("bf16x3", MFMA_B3_PEAK)):
+        for _ in range(2):
+            ae.encode(pt, sa_matmul=mode, pn_matmul=mode)
+        t = ops.StageTimer()
+        ops.set_timer(t)
+        for _ in range(args.iters):
+            lq = ae.encode(pt, sa_matmul=mode, pn_matmul=mode)[2]
+        st = t.totals_ms()
+        ops.set_timer(None)
+        for name, flop in (("sa_forward", 84.7e6), ("pn_forward", 96.7e6), ("sa_pn_forward", 181.3e6)):
+            if name in st:
+                row(f"{name} [{mode}]", st[name][0] / st[name][1], "mfma", B * S * flop, "TFLOP/s", round(peak, 1),
+                    "flop per patch from the layer shapes of AE.py:16-17" + ("; fused kernel, feature map kept in the CU" if name == "sa_pn_forward" else ""))
+        row(f"ae_decode (head + main) [{mode}]", timed(lambda: ae.decode(lq, matmul=mode), args.iters), "mfma", B * S * 41.4e6, "TFLOP/s",
+            round(peak, 1), "AE.py:19-27")
     ms = timed(lambda: prob.run(centres, ("cdf_int",)), args.iters)
     row("prob_forward", ms, "mfma", B * 0.063e9, "TFLOP/s", MFMA_F32_PEAK, "one workgroup per cloud, NT=1: latency/L2 bound")
     cdf = prob.run(centres, ("cdf_int",))["cdf_int"]
