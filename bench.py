@@ -464,9 +464,11 @@ def bench_pppf(args, rk):
         rf = None
         if flop:
             ach = flop * B * S * args.steps / dt / 1e12
-            rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": ach / F32_MATRIX_PEAK_TFLOPS, "traffic": None, "flop_per_patch": flop,
-                  "note": "whole-forward wall time, not a single kernel: layer-by-layer generic kernels (csrc/linear.hip)"}
+            peak = F32_MATRIX_PEAK_TFLOPS if args.matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS
+            rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                  "frac": ach / peak, "traffic": None, "flop_per_patch": flop, "arithmetic": args.matmul,
+                  "note": "whole-forward wall time, not a single kernel: layer-by-layer generic kernels (csrc/linear.hip), bound by "
+                          "their activation round trips through HBM rather than by the matrix pipe (DESIGN.md section 7)"}
         print(json.dumps({
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -518,7 +520,7 @@ def bench_pppe_train(args, rk):
                   "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): small, launch-bound layers"}
         print(json.dumps({
             "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": rk.world * Bt * args.steps / dt,
-            "unit": "clouds/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "unit": "clouds/s", "points_per_s": rk.world * Bt * N_POINTS * args.steps / dt, "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
