@@ -99,7 +99,7 @@ __device__ __forceinline__ uint4 b3_load_async(const uint4 *p)    // placed exac
 
 // grid: x = patch block (8 n-tiles = 128 patches), y = point p.  4 waves, wave w owns n-tiles 2w, 2w+1.
 // B3 = false: exact fp32 MFMA GEMM (the product path).  B3 = true (the bf16x3 mode): the K = 1024 GEMM runs as six
-// v_mfma_f32_16x16x32_bf16 passes over pre-split operands (blob3 / h2p hold bf16 planes); the inv_mlp tail is unchanged.
+// v_mfma_f32_16x16x32_bf16 passes over pre-split operands (blob3 / h2p hold bf16 planes) and inv_mlp as a bf16x3 chain on registers.
 template <bool B3>
 __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restrict__ h2p, const float *__restrict__ latent_q,
                                                           int P, int d, int k, int ntiles, const float *__restrict__ blob,
