@@ -274,6 +274,25 @@ PCCX_API int pccx_pack_linear_b3(const float *wp_dev, int N, int K, float *wplan
 PCCX_API int pccx_linear_b3(const float *x, int M, int K, int ldx, const float *wplanes, const float *bias,
                             int N, int relu, float *out, int ldo, void *stream);
 
+/* The wide stacks of the PointNet++ families kept in "planes" between layers (csrc/planes.hip): the activation of M rows x K
+ * channels is stored as the three bf16 planes of the next layer's MFMA B operand, [K/32 block][16-row tile][plane][64 lanes] x 16 B,
+ * pccx_planes_floats(M, K) floats.
+ *   pccx_group_planes : gather + concat + split = index_points(features, idx) ++ index_points(xyz, idx) of
+ *       pointnet_sa_module.py:73-83 (idx -1 -> row 0, :27), written as planes.  Row r reads source row
+ *       (r / rows_per_batch) * n_src + idx[r] of f0 (C0 channels, row stride ld0) then f1 (C1, ld1); idx NULL: row r itself
+ *       (fp32 rows -> planes).  Either source may be absent (C = 0).
+ *   pccx_pack_planes_gemm : pccx_pack_linear_b3's planes reordered into per-m-block streams (pccx_planes_gemm_weight_floats).
+ *   pccx_planes_gemm  : one Conv1x1 / Linear (+ folded BatchNorm) (+ ReLU, bit 0 of relu) on planes.  epilogue 0: out = planes of
+ *       the N output channels; 1: out = fp32 rows (M, ldo); 2: out (M / group, ldo) = max over each `group` consecutive rows
+ *       (torch.max over nsample, pointnet_sa_module.py:91; group in {32, 64, 128} dividing M). */
+PCCX_API size_t pccx_planes_floats(int64_t M, int K);
+PCCX_API int pccx_group_planes(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
+                               int64_t rows_per_batch, int64_t n_src, float *planes, void *stream);
+PCCX_API size_t pccx_planes_gemm_weight_floats(int N, int K);
+PCCX_API int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream);
+PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                              int epilogue, int group, float *out, int ldo, void *stream);
+
 /* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
  * x (G,Kn,C) -> out (G,C). */
 PCCX_API int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream);

@@ -38,7 +38,31 @@ class FoldedLinear:
         wp = torch.zeros(_lib.load().pccx_packed_linear_floats(self.N, self.K), dtype=torch.float32)
         _lib.call("pccx_pack_linear", W.data_ptr(), self.N, self.K, wp.data_ptr())
         self.wp, self.b = wp.to(device), b.contiguous().to(device)
-        self.matmul, self.wp3 = matmul, None
+        self.matmul, self.wp3, self.ws3 = matmul, None, None
+
+    def mode(self):
+        from . import DEFAULT_MATMUL
+        return self.matmul or DEFAULT_MATMUL
+
+    def _planes3(self):
+        if self.wp3 is None:
+            self.wp3 = torch.empty(_lib.load().pccx_packed_linear_b3_floats(self.N, self.K), device=self.wp.device, dtype=torch.float32)
+            _lib.call("pccx_pack_linear_b3", self.wp.data_ptr(), self.N, self.K, self.wp3.data_ptr(), _stream())
+        return self.wp3
+
+    def planes(self, pin, M, epilogue=0, group=0):
+        """The layer on an activation kept in planes (csrc/planes.hip; bf16x3 only): pin = planes of the (M, K) input.
+        epilogue 0 -> planes of the (M, N) output, 1 -> fp32 rows (M, N), 2 -> (M // group, N) max over `group` consecutive rows."""
+        if self.ws3 is None:
+            self.ws3 = torch.empty(_lib.load().pccx_planes_gemm_weight_floats(self.N, self.K), device=self.wp.device, dtype=torch.float32)
+            _lib.call("pccx_pack_planes_gemm", self._planes3().data_ptr(), self.N, self.K, self.ws3.data_ptr(), _stream())
+        if epilogue == 0:
+            out = torch.empty(_lib.load().pccx_planes_floats(M, self.N), device=pin.device, dtype=torch.float32)
+        else:
+            out = torch.empty(M if epilogue == 1 else M // group, self.N, device=pin.device, dtype=torch.float32)
+        _lib.call("pccx_planes_gemm", pin.data_ptr(), M, self.K, self.ws3.data_ptr(), self.b.data_ptr(), self.N, self.relu, epilogue,
+                  group, out.data_ptr(), self.N, _stream())
+        return out
 
     def __call__(self, x):
         """x (M,K) f32 contiguous on the GPU -> (M,N)."""
@@ -46,10 +70,7 @@ class FoldedLinear:
         M = x.shape[0]
         out = torch.empty(M, self.N, device=x.device, dtype=torch.float32)
         if (self.matmul or DEFAULT_MATMUL) == "bf16x3":
-            if self.wp3 is None:
-                self.wp3 = torch.empty(_lib.load().pccx_packed_linear_b3_floats(self.N, self.K), device=self.wp.device, dtype=torch.float32)
-                _lib.call("pccx_pack_linear_b3", self.wp.data_ptr(), self.N, self.K, self.wp3.data_ptr(), _stream())
-            _lib.call("pccx_linear_b3", x.data_ptr(), M, self.K, x.stride(0), self.wp3.data_ptr(), self.b.data_ptr(), self.N,
+            _lib.call("pccx_linear_b3", x.data_ptr(), M, self.K, x.stride(0), self._planes3().data_ptr(), self.b.data_ptr(), self.N,
                       self.relu, out.data_ptr(), self.N, _stream())
             return out
         _lib.call("pccx_linear", x.data_ptr(), M, self.K, x.stride(0), self.wp.data_ptr(), self.b.data_ptr(), self.N,
@@ -72,6 +93,44 @@ def cat_rows(parts):
         buf[:, off:off + c].copy_(p.reshape(rows, c))
         off += c
     return buf[:, :C]
+
+
+def group_planes(feats, xyz, idx):
+    """index_points(feats, idx) ++ index_points(xyz, idx) (pointnet_sa_module.py:73-83; -1 -> row 0) as the planes of the first
+    layer's operand.  feats (B,N,C) channels-last or None, xyz (B,N,3) or None, idx (B,M,ns) int64.  Returns (planes, rows)."""
+    B, Mq, ns = idx.shape
+    rows = B * Mq * ns
+    f0 = feats.contiguous() if feats is not None else None
+    f1 = xyz.contiguous() if xyz is not None else None
+    C0 = int(f0.shape[-1]) if f0 is not None else 0
+    C1 = int(f1.shape[-1]) if f1 is not None else 0
+    n_src = int((f0 if f0 is not None else f1).shape[1])
+    idx = idx.contiguous()
+    out = torch.empty(_lib.load().pccx_planes_floats(rows, C0 + C1), device=idx.device, dtype=torch.float32)
+    _lib.call("pccx_group_planes", f0.data_ptr() if f0 is not None else None, C0, C0, f1.data_ptr() if f1 is not None else None, C1, C1,
+              idx.data_ptr(), rows, Mq * ns, n_src, out.data_ptr(), _stream())
+    return out, rows
+
+
+def rows_planes(x):
+    """fp32 rows (M, K) (row stride >= K) -> planes."""
+    M, K = x.shape
+    out = torch.empty(_lib.load().pccx_planes_floats(M, K), device=x.device, dtype=torch.float32)
+    _lib.call("pccx_group_planes", x.data_ptr(), K, x.stride(0), None, 0, 0, None, M, 1, 1, out.data_ptr(), _stream())
+    return out
+
+
+def run_stack(stack, x):
+    """A Conv/Linear stack on fp32 rows x (M, K): layer by layer on rows (f32), or through planes (bf16x3)."""
+    if stack and stack[0].mode() == "bf16x3" and x.shape[0] > 0:
+        M = x.shape[0]
+        pl = rows_planes(x)
+        for layer in stack[:-1]:
+            pl = layer.planes(pl, M, 0)
+        return stack[-1].planes(pl, M, 1)
+    for layer in stack:
+        x = layer(x)
+    return x
 
 
 def group_max(x):
@@ -138,6 +197,12 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
         B = xyz.shape[0]
         new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)                   # :66-68 (start index 0)
         idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
+        if stack[0].mode() == "bf16x3" and self.nsample in (32, 64, 128) and B > 0:
+            # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue
+            pl, rows = group_planes(feats, xyz, idx)                                # :73-83 features first, xyz last, not centred
+            for layer in stack[:-1]:
+                pl = layer.planes(pl, rows, 0)                                      # :90 Conv-BN-ReLU
+            return new_xyz, stack[-1].planes(pl, rows, 2, self.nsample).view(B, self.npoint, -1)   # :91
         grouped = ops.index_points(xyz, idx)                                        # :81 (not centred)
         x = cat_rows([ops.index_points(feats, idx), grouped] if feats is not None else [grouped])   # :83 features first, xyz last
         for layer in stack:
@@ -203,11 +268,9 @@ class PPPF_AE(_Packable):
         P = self.decoder.num_points
         rep = lat_dec[:, None, :].expand(B, P, self.dim)
         x = cat_rows([pk["grid"][None].expand(B, P, 2), rep])                                             # :99-101
-        for layer in pk["mlp1"]:
-            x = layer(x)                                                            # :104 coarse
+        x = run_stack(pk["mlp1"], x)                                                # :104 coarse
         x = cat_rows([x.view(B, P, 3), rep])                                                                # :106
-        for layer in pk["mlp2"]:
-            x = layer(x)                                                            # :107 fine
+        x = run_stack(pk["mlp2"], x)                                                # :107 fine
         return x.view(B, P, 3), latent, q
 
 

@@ -143,3 +143,49 @@ def test_generic_linear_ragged_shapes(matmul_mode):
         np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
     x = rng.standard_normal((7, 33, 20)).astype(np.float32)
     assert np.array_equal(families.group_max(torch.from_numpy(x).cuda()).cpu().numpy(), x.max(1))
+
+
+@pytest.mark.gpu
+def test_planes_layers_ragged_shapes():
+    """csrc/planes.hip against float64 matmuls at the tolerances of the generic layer test: rows -> planes -> layer(s) -> rows for
+    ragged M / K / N (K, N not multiples of 32 / 16, a single row, M not a multiple of 128), a two-layer chain kept in planes,
+    the gather + concat front end with -1 indices (pointnet_sa_module.py:27,73-83) and the max-over-nsample epilogue (:91)."""
+    from pccx import families
+    rng = np.random.default_rng(5)
+
+    def layer(N, K, relu):
+        W = rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K)
+        b = rng.standard_normal(N).astype(np.float32)
+        return families.FoldedLinear(torch.from_numpy(W), torch.from_numpy(b), relu, matmul="bf16x3"), W.astype(np.float64), b.astype(np.float64)
+
+    for M, K, N, relu in [(1, 3, 3, True), (130, 3, 64, True), (257, 131, 128, False), (33, 1027, 128, True), (200, 64, 1024, False),
+                          (1000, 259, 7, True), (4096, 512, 512, True)]:
+        lyr, W, b = layer(N, K, relu)
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        got = lyr.planes(families.rows_planes(torch.from_numpy(x).cuda()), M, 1).cpu().numpy()
+        want = x.astype(np.float64) @ W.T + b
+        if relu:
+            want = np.maximum(want, 0)
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5, err_msg=str((M, K, N)))
+    # chain of two layers through planes (odd number of 16-channel tiles in the middle: 48 channels)
+    l0, W0, b0 = layer(48, 35, True)
+    l1, W1, b1 = layer(40, 48, False)
+    x = rng.standard_normal((300, 35)).astype(np.float32)
+    got = families.run_stack([l0, l1], torch.from_numpy(x).cuda()).cpu().numpy()
+    want = np.maximum(x.astype(np.float64) @ W0.T + b0, 0) @ W1.T + b1
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    # gather + concat + layer + max over nsample
+    for ns, C in [(32, 0), (64, 5), (128, 128)]:
+        B, Nsrc, Mq = 3, 50, 7
+        xyz = rng.standard_normal((B, Nsrc, 3)).astype(np.float32)
+        feats = rng.standard_normal((B, Nsrc, C)).astype(np.float32) if C else None
+        idx = rng.integers(-1, Nsrc, (B, Mq, ns))
+        lyr, W, b = layer(70, C + 3, True)
+        pl, rows = families.group_planes(torch.from_numpy(feats).cuda() if C else None, torch.from_numpy(xyz).cuda(), torch.from_numpy(idx).cuda())
+        assert rows == B * Mq * ns
+        got = lyr.planes(pl, rows, 2, ns).cpu().numpy()
+        j = np.where(idx < 0, 0, idx)
+        bi = np.arange(B)[:, None, None]
+        g = np.concatenate(([feats[bi, j]] if C else []) + [xyz[bi, j]], axis=-1).astype(np.float64)       # (B,Mq,ns,C+3)
+        want = np.maximum(g @ W.T + b, 0).max(axis=2).reshape(B * Mq, -1)
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5, err_msg=str((ns, C)))
