@@ -68,6 +68,21 @@ def committed_traffic(stage, batch):
     return None, None
 
 
+def committed_pmc(stage):
+    """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over the cycles of all SIMDs) and the clock the chip held during the
+    stage's kernel (GRBM_GUI_ACTIVE / 8 / duration), from the same committed PMC passes -- NOT measured in this run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))["kernels"][STAGE_KERNEL[stage]]
+            if "mfma_pipe_busy" in t:
+                return {"mfma_pipe_busy": round(t["mfma_pipe_busy"], 4), "clock_ghz_under_load": round(t.get("clock_ghz_under_load", 0.0), 3) or None,
+                        "peak_quoted_at_ghz": 2.4, "source": "committed PMC pass " + os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def seeded_state_dict(module, seed, gain=1.0, last_gain=None):
     """Same deterministic fill as oracle.ref_model.seeded_state_dict (kept local: the product side
     of bench.py must not import the oracle)."""
@@ -247,7 +262,8 @@ def roofline_of(stages, steps, P, matmul, batch):
     traffic, src = committed_traffic(dom, batch)
     rf = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
           "traffic": traffic, "traffic_source": src, "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P,
-          "arithmetic": matmul, "note": note, "window": "resident leg (single stream; HIP events per stage)"}
+          "arithmetic": matmul, "note": note, "window": "resident leg (single stream; HIP events per stage)",
+          "pmc": committed_pmc(dom)}
     tfl = {k: STAGE_FLOP[k] * P / (stages[k][0] * 1e-3) / 1e12 for k in STAGE_FLOP if k in stages}
     return rf, per_step_ms, tfl
 

@@ -292,6 +292,14 @@ PCCX_API size_t pccx_planes_gemm_weight_floats(int N, int K);
 PCCX_API int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream);
 PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
                               int epilogue, int group, float *out, int ldo, void *stream);
+/* A whole Conv-BN-ReLU x 4 + max-over-nsample stack (pointnet_sa_module.py:90-91) in one kernel, the activations between the layers
+ * staying in registers: out (M / group, ldo) from the planes of the gathered input.  wstream = the four layers'
+ * pccx_pack_planes_gemm streams back to back; b0..b3 the (folded) biases.  Supported width patterns: (<=32, 33..64, 33..64, 65..128)
+ * and (97..128, 97..128, 97..128, 129..256) -- sa1 and sa2 of PPPF_AE.py:29-34; anything else returns PCCX_ERR_ARG and the caller
+ * runs pccx_planes_gemm layer by layer. */
+PCCX_API int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
+                                const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
+                                int ldo, void *stream);
 
 /* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
  * x (G,Kn,C) -> out (G,C). */

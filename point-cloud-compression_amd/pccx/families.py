@@ -50,12 +50,16 @@ class FoldedLinear:
             _lib.call("pccx_pack_linear_b3", self.wp.data_ptr(), self.N, self.K, self.wp3.data_ptr(), _stream())
         return self.wp3
 
-    def planes(self, pin, M, epilogue=0, group=0):
-        """The layer on an activation kept in planes (csrc/planes.hip; bf16x3 only): pin = planes of the (M, K) input.
-        epilogue 0 -> planes of the (M, N) output, 1 -> fp32 rows (M, N), 2 -> (M // group, N) max over `group` consecutive rows."""
+    def _stream3(self):
         if self.ws3 is None:
             self.ws3 = torch.empty(_lib.load().pccx_planes_gemm_weight_floats(self.N, self.K), device=self.wp.device, dtype=torch.float32)
             _lib.call("pccx_pack_planes_gemm", self._planes3().data_ptr(), self.N, self.K, self.ws3.data_ptr(), _stream())
+        return self.ws3
+
+    def planes(self, pin, M, epilogue=0, group=0):
+        """The layer on an activation kept in planes (csrc/planes.hip; bf16x3 only): pin = planes of the (M, K) input.
+        epilogue 0 -> planes of the (M, N) output, 1 -> fp32 rows (M, N), 2 -> (M // group, N) max over `group` consecutive rows."""
+        self._stream3()
         if epilogue == 0:
             out = torch.empty(_lib.load().pccx_planes_floats(M, self.N), device=pin.device, dtype=torch.float32)
         else:
@@ -118,6 +122,33 @@ def rows_planes(x):
     out = torch.empty(_lib.load().pccx_planes_floats(M, K), device=x.device, dtype=torch.float32)
     _lib.call("pccx_group_planes", x.data_ptr(), K, x.stride(0), None, 0, 0, None, M, 1, 1, out.data_ptr(), _stream())
     return out
+
+
+def chain4_fits(stack):
+    """The width patterns pccx_planes_chain4 is built for (sa1 / sa2 of PPPF_AE.py:29-34), every layer with ReLU."""
+    if len(stack) != 4 or not all(l.relu for l in stack) or any(stack[i + 1].K != stack[i].N for i in range(3)):
+        return False
+    n = [l.N for l in stack]
+    return (n[0] <= 32 and 32 < n[1] <= 64 and 32 < n[2] <= 64 and 64 < n[3] <= 128) or \
+           (all(96 < v <= 128 for v in n[:3]) and 128 < n[3] <= 256)
+
+
+def stack_max_planes(stack, pl, rows, group, cache):
+    """Conv-BN-ReLU stack + max over `group` consecutive rows on planes: one kernel when the stack fits pccx_planes_chain4, else
+    layer by layer with the max in the last layer's epilogue.  cache: a dict owned by the caller (holds the concatenated stream)."""
+    if chain4_fits(stack):
+        if "ws" not in cache:
+            cache["ws"] = torch.cat([l._stream3() for l in stack])
+        out = torch.empty(rows // group, stack[3].N, device=pl.device, dtype=torch.float32)
+        a = []
+        for l in stack:
+            a += [l.b.data_ptr(), l.N]
+        _lib.call("pccx_planes_chain4", pl.data_ptr(), rows, stack[0].K, cache["ws"].data_ptr(), *a, group, out.data_ptr(), stack[3].N,
+                  _stream())
+        return out
+    for layer in stack[:-1]:
+        pl = layer.planes(pl, rows, 0)
+    return stack[-1].planes(pl, rows, 2, group)
 
 
 def run_stack(stack, x):
@@ -200,9 +231,10 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
         if stack[0].mode() == "bf16x3" and self.nsample in (32, 64, 128) and B > 0:
             # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue
             pl, rows = group_planes(feats, xyz, idx)                                # :73-83 features first, xyz last, not centred
-            for layer in stack[:-1]:
-                pl = layer.planes(pl, rows, 0)                                      # :90 Conv-BN-ReLU
-            return new_xyz, stack[-1].planes(pl, rows, 2, self.nsample).view(B, self.npoint, -1)   # :91
+            if getattr(self, "_chain_of", None) is not stack:                       # new pack -> new stream
+                self._chain_of, self._chain_cache = stack, {}
+            out = stack_max_planes(stack, pl, rows, self.nsample, self._chain_cache)            # :90-91 Conv-BN-ReLU stack, max
+            return new_xyz, out.view(B, self.npoint, -1)
         grouped = ops.index_points(xyz, idx)                                        # :81 (not centred)
         x = cat_rows([ops.index_points(feats, idx), grouped] if feats is not None else [grouped])   # :83 features first, xyz last
         for layer in stack:

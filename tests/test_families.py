@@ -189,3 +189,36 @@ def test_planes_layers_ragged_shapes():
         g = np.concatenate(([feats[bi, j]] if C else []) + [xyz[bi, j]], axis=-1).astype(np.float64)       # (B,Mq,ns,C+3)
         want = np.maximum(g @ W.T + b, 0).max(axis=2).reshape(B * Mq, -1)
         np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5, err_msg=str((ns, C)))
+
+
+@pytest.mark.gpu
+def test_planes_chain4_matches_layer_by_layer_and_float64():
+    """pccx_planes_chain4 (four layers + max in one kernel, activations in registers) on the two width patterns of PPPF_AE.py:29-34
+    and ragged variants of them: equal to the float64 stack at the layer tolerance, and BIT-identical to the same stack run layer by
+    layer through pccx_planes_gemm (same products in the same order; only where the activation lives differs)."""
+    from pccx import families
+    rng = np.random.default_rng(9)
+    for K0, widths, ns, groups in [(3, (3, 64, 64, 128), 32, 37), (131, (128, 128, 128, 256), 64, 21), (7, (20, 40, 64, 100), 32, 5),
+                                   (70, (100, 128, 97, 200), 128, 3)]:
+        stack, Ws = [], []
+        k = K0
+        for nw in widths:
+            W = rng.standard_normal((nw, k)).astype(np.float32) / np.sqrt(k)
+            b = rng.standard_normal(nw).astype(np.float32) * 0.1
+            stack.append(families.FoldedLinear(torch.from_numpy(W), torch.from_numpy(b), True, matmul="bf16x3"))
+            Ws.append((W.astype(np.float64), b.astype(np.float64)))
+            k = nw
+        assert families.chain4_fits(stack)
+        rows = groups * ns
+        x = rng.standard_normal((rows, K0)).astype(np.float32)
+        pl = families.rows_planes(torch.from_numpy(x).cuda())
+        got = families.stack_max_planes(stack, pl, rows, ns, {}).cpu().numpy()
+        p2 = pl
+        for layer in stack[:-1]:
+            p2 = layer.planes(p2, rows, 0)
+        ref = stack[-1].planes(p2, rows, 2, ns).cpu().numpy()
+        assert np.array_equal(got, ref), (K0, widths)
+        h = x.astype(np.float64)
+        for W, b in Ws:
+            h = np.maximum(h @ W.T + b, 0)
+        np.testing.assert_allclose(got, h.reshape(groups, ns, -1).max(1), atol=3e-5, rtol=2e-5)

@@ -1,3 +1,10 @@
+// EXPERIMENT RECORD (not built): planes_gemm_kernel generalised to 8-wave workgroups (256 rows per workgroup, the weight stream fetched
+// from L2 once per 256 rows instead of once per 128; PCCX_PG_WAVES=4|8) and to a ring depth of 6 (-DPG_NB=6, DMA five chunks ahead).
+// Measured with tools/experiments/pg_bench.py on the PPPF layer shapes (2048 patches), ms per layer, 4 waves / 8 waves:
+//   512->1024 + max over 128: 36.3 / 37.8      256->256: 6.48 / 6.79      128->128: 4.78 / 4.93      128->256 + max: 6.35 / 7.04
+// ring depth 6 against 4: the same within 0.5 % in every shape.  Neither the latency of the weight stream nor its L2 traffic is what
+// holds the layer at 0.58 of the nominal bf16x3 peak: by the PMC pass of the decoder kernel built the same way the matrix pipe is busy
+// 75 % of the cycles and the clock under this load is 2.0 GHz against the 2.4 GHz the peak is quoted at.  Not kept.
 // planes.hip -- the wide Conv1x1 / Linear stacks of the PointNet++ families (pointnet_sa_module.py:38-93, PPPF_AE.py:64-107)
 // in the bf16x3 arithmetic, with the activations kept between layers as the three bf16 planes of the NEXT layer's MFMA B
 // operand instead of fp32 rows:
@@ -17,12 +24,15 @@
 //                         max over groups of `group` consecutive rows (torch.max over nsample, pointnet_sa_module.py:91).
 // MFMA-bound for K, N >= 256; narrower layers are bound by the 6 bytes per activation they read and write.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "mfma_chain.h"
 
 #define PG_CHUNK 12                      // ring chunk: 4 m-tiles x 3 planes (1 KiB fragments)
-#define PG_NB 4                          // ring depth (DMA three chunks ahead)
+#ifndef PG_NB
+#define PG_NB 4                          // ring depth (DMA PG_NB - 1 chunks ahead)
+#endif
 
 static inline int pg_kt32(int K) { return ((K + 15) / 16 + 1) / 2; }
 static inline int pg_mb(int N) { return (N + 15) / 16 <= 4 ? 4 : 8; }
@@ -138,27 +148,34 @@ __device__ __forceinline__ uint4 pg_load_async(const uint4 *p)    // placed exac
 
 enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
 
-template <int MB, int EPI>
-__global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__restrict__ bin, long long M, long long ntiles, int KT32,
+template <int MB, int EPI, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void planes_gemm_kernel(const uint4 *__restrict__ bin, long long M, long long ntiles, int KT32,
                                                              const float *__restrict__ wstream, int MBS, const float *__restrict__ bias,
                                                              int N, int relu, int group, float *__restrict__ out, int ldo)
 {
-    constexpr int HALVES = MB / 4;                             // ring chunks per k-step
+    // NWV = 4: 128 rows per workgroup, ring chunk = 4 m-tiles x 3 planes, two workgroups per CU.
+    // NWV = 8: 256 rows per workgroup, ring chunk = 8 m-tiles x 3 planes (one k-step), one workgroup per CU: the weight
+    //          stream is fetched from L2 once per 256 rows instead of once per 128.
+    static_assert(NWV == 4 || (NWV == 8 && MB == 8), "8-wave form: MB = 8 only");
+    constexpr int CH = NWV == 8 ? 2 * PG_CHUNK : PG_CHUNK;    // fragments per ring chunk
+    constexpr int MQ = CH / PG_CHUNK;                          // groups of 4 m-tiles per chunk
+    constexpr int HALVES = MB / (4 * MQ);                      // ring chunks per k-step
+    constexpr int TPB = 2 * NWV;                               // row tiles per workgroup
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     // Block order: XCD-aware.  Consecutive workgroup ids go round the 8 XCDs, so the MBS m-blocks of one 128-row block are
     // given to the SAME XCD one after the other: the row block's B planes are fetched into that XCD's L2 once, and every L2
     // holds the layer's whole weight stream (<= 3 MB).
-    const long long nblk = (ntiles + 7) / 8;
+    const long long nblk = (ntiles + TPB - 1) / TPB;
     const long long s = blockIdx.x >> 3;
     const long long blk = (s / MBS) * 8 + (blockIdx.x & 7);
     const int mb = (int)(s % MBS);
     if (blk >= nblk) return;                                  // whole workgroup, before any barrier
-    const long long tile0 = blk * 8 + 2 * w;
-    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * PG_CHUNK * 64];
+    const long long tile0 = blk * TPB + 2 * w;
+    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * CH * 64];
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int nch = HALVES * KT32;
-    const WStreamT<PG_CHUNK, PG_NB> ws{wstream + (size_t)mb * nch * PG_CHUNK * 256, swt, nch, lane, wu, false};
+    const WStreamT<CH, PG_NB, NWV> ws{wstream + (size_t)mb * nch * CH * 256, swt, nch, lane, wu, false};
     // DMA of chunk c (a chunk past the end re-reads chunk 0 into a free buffer, so every boundary issues the same loads and
     // the counted waits below hold to the last k-step)
     auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % PG_NB); };
@@ -196,34 +213,37 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                 const int c = HALVES * t + half;
                 if (half == 0) {
                     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_NB == 4 ? 12 : 15) : "memory");
                     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
                 } else {
-                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG_NB == 4 ? 18 : 30) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
-                bf16x8 a[4][3];
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
-                __builtin_amdgcn_sched_barrier(0);
                 // six products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int mqq = 0; mqq < MQ; ++mqq) {
+                    bf16x8 a[4][3];
 #pragma unroll
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[((mqq * 4 + mq) * 3 + pl) * 64]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[nt][4 * (half * MQ + mqq) + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * (half * MQ + mqq) + mq], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
         load_b(bs[0], 0);
@@ -281,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
         // max over groups of `group` rows (32, 64 or 128; M is a multiple of it, so no group holds padded rows).  In the wave:
         // the two tiles elementwise, then the 16 rows of the tile by DPP; across the waves of a group through LDS.
         __syncthreads();                                   // every wave is done with the ring
-        float *smax = (float *)swt;                        // [4 waves][16 * MB channels]
+        float *smax = (float *)swt;                        // [NWV waves][16 * MB channels]
 #pragma unroll
         for (int mt = 0; mt < MB; ++mt)
 #pragma unroll
@@ -291,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                 if (n == 0) smax[w * (16 * MB) + 16 * mt + 4 * g + r] = v;
             }
         __syncthreads();
-        const int gpb = 128 / group, wpg = group / 32;     // groups per block, waves per group
+        const int gpb = 32 * NWV / group, wpg = group / 32; // groups per block, waves per group
         const long long G = M / group;
-        for (int e = tid; e < gpb * 16 * MB; e += 256) {
+        for (int e = tid; e < gpb * 16 * MB; e += 64 * NWV) {
             const int gi = e / (16 * MB), c = e % (16 * MB);
             float v = smax[(gi * wpg) * (16 * MB) + c];
             for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * (16 * MB) + c]);
@@ -317,261 +337,35 @@ extern "C" int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const 
     PCCX_CHECK_ARG(epilogue == PG_EPI_PLANES || ldo >= N, "pccx_planes_gemm: ldo=%d < N=%d", ldo, N);
     PCCX_CHECK_ARG(epilogue != PG_EPI_MAX || ((group == 32 || group == 64 || group == 128) && M % group == 0),
                    "pccx_planes_gemm: group max needs group in {32,64,128} dividing M (group=%d M=%lld)", group, (long long)M);
-    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
+    const long long ntiles = (M + 15) / 16;
     const int MT = (N + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB, KT32 = pg_kt32(K);
+    // 8-wave workgroups (256 rows) when the layer is wide and long enough to be bound by the operand traffic from L2
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("PCCX_PG_WAVES"); force = e ? atoi(e) : 0; }
+    const int nwv = force ? force : ((MB == 8 && K >= 64 && M >= 65536) ? 8 : 4);
+    const long long nblk = (ntiles + 2 * nwv - 1) / (2 * nwv);
     const long long blocks = (nblk + 7) / 8 * 8 * MBS;
     PCCX_CHECK_ARG(blocks <= 0x7fffffffLL, "pccx_planes_gemm: M=%lld too large", (long long)M);
+    PCCX_CHECK_ARG(nwv == 4 || (nwv == 8 && MB == 8), "pccx_planes_gemm: PCCX_PG_WAVES=%d does not fit this layer", nwv);
     hipStream_t st = (hipStream_t)stream;
     relu &= 1;
-#define PG_LAUNCH(MB_, E_)                                                                                                      \
-    hipLaunchKernelGGL((planes_gemm_kernel<MB_, E_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)planes_in, (long long)M, \
-                       ntiles, KT32, wstream, MBS, bias, N, relu, group, out, ldo)
-    if (MB == 8) {
-        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(8, PG_EPI_PLANES);
-        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(8, PG_EPI_ROWS);
-        else PG_LAUNCH(8, PG_EPI_MAX);
+#define PG_LAUNCH(MB_, E_, W_)                                                                                                  \
+    hipLaunchKernelGGL((planes_gemm_kernel<MB_, E_, W_>), dim3((unsigned)blocks), dim3(64 * W_), 0, st, (const uint4 *)planes_in,     \
+                       (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, group, out, ldo)
+    if (MB == 8 && nwv == 8) {
+        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(8, PG_EPI_PLANES, 8);
+        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(8, PG_EPI_ROWS, 8);
+        else PG_LAUNCH(8, PG_EPI_MAX, 8);
+    } else if (MB == 8) {
+        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(8, PG_EPI_PLANES, 4);
+        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(8, PG_EPI_ROWS, 4);
+        else PG_LAUNCH(8, PG_EPI_MAX, 4);
     } else {
-        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(4, PG_EPI_PLANES);
-        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(4, PG_EPI_ROWS);
-        else PG_LAUNCH(4, PG_EPI_MAX);
+        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(4, PG_EPI_PLANES, 4);
+        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(4, PG_EPI_ROWS, 4);
+        else PG_LAUNCH(4, PG_EPI_MAX, 4);
     }
 #undef PG_LAUNCH
-    PCCX_CHECK_LAUNCH();
-    return PCCX_OK;
-}
-
-// ---- four-layer stack in one kernel ------------------------------------------------------------------------------
-// Conv-BN-ReLU x 4 + max over nsample (pointnet_sa_module.py:90-91) for stacks whose first three widths are <= 128: layer 0 is the
-// GEMM above on the planes of the gathered input; its accumulators (128 rows x <= 128 channels per workgroup, 2 row tiles x <= 8
-// m-tiles per wave) are split in registers into the next layer's B planes (the chain of mfma_chain.h), and so on; the last layer
-// runs in passes of 128 output channels, each reduced over the groups of `group` rows as in the epilogue above.  One weight stream
-// for the whole stack (the four layers' pccx_pack_planes_gemm streams back to back) goes through the LDS-DMA ring; no activation
-// of the stack exists in HBM.
-//   MQ0 / MQ1 / MQ2 : output m-quads (4 m-tiles) of layers 0..2 (1 or 2);  KT1..KT3 : K/32 blocks of the inputs of layers 1..3;
-//   NP : passes (of 8 m-tiles) of the last layer.
-template <int KT, int MQ, class WS>
-__device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, const bf16x8 (&in)[2][KT][3], f32x4 (&acc)[2][4 * MQ])
-{
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int mqq = 0; mqq < MQ; ++mqq) {
-            // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (6 loads) may stay in flight
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __syncthreads();
-            {
-                const int nx = c + PG_NB - 1;
-                ws.issue(nx < nch ? nx : 0, nx % PG_NB);
-            }
-            const f32x4 *buf = ws.chunk(c);
-            bf16x8 a[4][3];
-#pragma unroll
-            for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[nt][4 * mqq + mq] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], in[nt][kt][PB[q]], acc[nt][4 * mqq + mq], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            ++c;
-        }
-}
-
-template <int NTILES>
-__device__ __forceinline__ void pg_bias_init(f32x4 (&acc)[2][NTILES], const float *__restrict__ bias, int N, int m0, int g)
-{
-#pragma unroll
-    for (int mt = 0; mt < NTILES; ++mt) {
-        f32x4 b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = 16 * (m0 + mt) + 4 * g + r;
-            b[r] = (bias && ch < N) ? bias[ch] : 0.f;
-        }
-        acc[0][mt] = b; acc[1][mt] = b;
-    }
-}
-
-// relu + split of a layer's accumulators into the next layer's planes (k-tile j = C tiles 2j, 2j+1; a missing odd tile is zero)
-template <int NTILES, int KT>
-__device__ __forceinline__ void pg_to_planes(const f32x4 (&acc)[2][NTILES], bf16x8 (&pl)[2][KT][3])
-{
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int j = 0; j < KT; ++j)
-            b3_split8(relu4(acc[nt][2 * j]), 2 * j + 1 < NTILES ? relu4(acc[nt][2 * j + 1]) : zero, pl[nt][j]);
-}
-
-template <int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP>
-__global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__restrict__ bin, long long M, long long ntiles, int KT0,
-                                                               const float *__restrict__ wstream, const float *__restrict__ b0, int N0,
-                                                               const float *__restrict__ b1, int N1, const float *__restrict__ b2, int N2,
-                                                               const float *__restrict__ b3, int N3, int group, float *__restrict__ out,
-                                                               int ldo)
-{
-    static_assert(2 * KT1 <= 4 * MQ0 + 1 && 2 * KT2 <= 4 * MQ1 + 1 && 2 * KT3 <= 4 * MQ2 + 1, "a layer's K blocks come from the previous layer's tiles");
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane >> 4, n = lane & 15;
-    const long long blk = blockIdx.x;
-    const long long tile0 = blk * 8 + 2 * w;
-    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * PG_CHUNK * 64];
-    __shared__ float smax[4 * 128];
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    const int nch = MQ0 * KT0 + KT1 * MQ1 + KT2 * MQ2 + NP * KT3 * 2;
-    const WStreamT<PG_CHUNK, PG_NB> ws{wstream, swt, nch, lane, wu, false};
-    auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % PG_NB); };
-#pragma unroll
-    for (int c = 0; c < PG_NB - 1; ++c) dma(c);
-
-    const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
-    // ---- layer 0: as planes_gemm_kernel (HALVES = MQ0)
-    f32x4 acc0[2][4 * MQ0];
-    pg_bias_init<4 * MQ0>(acc0, b0, N0, 0, g);
-    {
-        uint4 bs[3][2][3];
-        auto load_b = [&](uint4 (&dst)[2][3], int t) {
-            const int tc = t < KT0 ? t : KT0 - 1;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    dst[nt][pl] = pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
-        };
-        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
-#pragma unroll
-            for (int half = 0; half < MQ0; ++half) {
-                const int c = MQ0 * t + half;
-                if (half == 0) {
-                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    __syncthreads();
-                    dma(c + PG_NB - 1);
-                    load_b(bload, t + 2);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                    __syncthreads();
-                    dma(c + PG_NB - 1);
-                }
-                const f32x4 *buf = ws.chunk(c);
-                bf16x8 a[4][3];
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
-                __builtin_amdgcn_sched_barrier(0);
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc0[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc0[nt][4 * half + mq], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        load_b(bs[0], 0);
-        load_b(bs[1], 1);
-        kstep(0, bs[0], bs[2], true);
-        if (KT0 > 1) kstep(1, bs[1], bs[0], false);
-#pragma unroll 1
-        for (int t = 2; t < KT0; t += 3) {
-            kstep(t, bs[2], bs[1], false);
-            if (t + 1 < KT0) kstep(t + 1, bs[0], bs[2], false);
-            if (t + 2 < KT0) kstep(t + 2, bs[1], bs[0], false);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads land before their
-    }                                                                     // registers are reused; the ring's DMAs with them
-    int c = MQ0 * KT0;
-    // ---- layers 1, 2: registers to registers
-    bf16x8 i1[2][KT1][3];
-    pg_to_planes<4 * MQ0, KT1>(acc0, i1);
-    f32x4 acc1[2][4 * MQ1];
-    pg_bias_init<4 * MQ1>(acc1, b1, N1, 0, g);
-    pg_chain_layer<KT1, MQ1>(ws, c, nch, i1, acc1);
-    bf16x8 i2[2][KT2][3];
-    pg_to_planes<4 * MQ1, KT2>(acc1, i2);
-    f32x4 acc2[2][4 * MQ2];
-    pg_bias_init<4 * MQ2>(acc2, b2, N2, 0, g);
-    pg_chain_layer<KT2, MQ2>(ws, c, nch, i2, acc2);
-    bf16x8 i3[2][KT3][3];
-    pg_to_planes<4 * MQ2, KT3>(acc2, i3);
-    // ---- last layer in passes of 8 m-tiles, each reduced over the row groups
-    const int gpb = 128 / group, wpg = group / 32;
-    const long long G = M / group;
-#pragma unroll 1
-    for (int ps = 0; ps < NP; ++ps) {
-        f32x4 acc3[2][8];
-        pg_bias_init<8>(acc3, b3, N3, 8 * ps, g);
-        pg_chain_layer<KT3, 2>(ws, c, nch, i3, acc3);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(acc3[0][mt][r], acc3[1][mt][r]);
-                v = row16_max(v);
-                if (n == 0) smax[w * 128 + 16 * mt + 4 * g + r] = v;
-            }
-        __syncthreads();
-        for (int e = tid; e < gpb * 128; e += 256) {
-            const int gi = e >> 7, ch = e & 127;
-            float v = smax[(gi * wpg) * 128 + ch];
-            for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * 128 + ch]);
-            v = fmaxf(v, 0.f);                               // max(relu(x)) = relu(max(x))
-            const long long grp = blk * gpb + gi;
-            const int co = 128 * ps + ch;
-            if (grp < G && co < N3) out[(size_t)grp * ldo + co] = v;
-        }
-        // the next pass writes smax only after its first ring boundary (a barrier every thread reaches after these reads)
-    }
-    ws.drain();
-}
-
-// out (M / group, ldo) = max over each `group` consecutive rows of relu(L3(relu(L2(relu(L1(relu(L0(x)))))))) for x given as planes.
-// wstream: the four layers' pccx_pack_planes_gemm streams back to back.  Supported stacks (PCCX_ERR_ARG otherwise; callers fall
-// back to pccx_planes_gemm layer by layer): widths (N0..N3) with N0, N1, N2 <= 128 in the two shapes of PPPF_AE.py:29-34,
-// (<=64, <=64, <=64, <=128) and (<=128 x3, <=256), each layer's input being the previous layer's output.
-extern "C" int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
-                                  const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
-                                  int ldo, void *stream)
-{
-    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(planes_in && wstream && out, "pccx_planes_chain4: null pointer");
-    PCCX_CHECK_ARG(M > 0 && K0 >= 1 && N0 >= 1 && N1 >= 1 && N2 >= 1 && N3 >= 1 && ldo >= N3, "pccx_planes_chain4: bad shape");
-    PCCX_CHECK_ARG((group == 32 || group == 64 || group == 128) && M % group == 0,
-                   "pccx_planes_chain4: group in {32,64,128} dividing M (group=%d M=%lld)", group, (long long)M);
-    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
-    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "pccx_planes_chain4: M too large");
-    const int KT0 = pg_kt32(K0);
-    hipStream_t st = (hipStream_t)stream;
-    auto mq = [](int N) { return pg_mb(N) / 4; };
-    auto kt = [](int N) { return pg_kt32(N); };
-#define PG_CHAIN(MQ0, KT1, MQ1, KT2, MQ2, KT3, NP)                                                                               \
-    hipLaunchKernelGGL((planes_chain4_kernel<MQ0, KT1, MQ1, KT2, MQ2, KT3, NP>), dim3((unsigned)nblk), dim3(256), 0, st,           \
-                       (const uint4 *)planes_in, (long long)M, ntiles, KT0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo)
-    if (N0 <= 64 && N1 <= 64 && N2 <= 64 && N3 > 64 && N3 <= 128 && mq(N0) == 1 && kt(N0) <= 1 && kt(N1) <= 2 && kt(N2) <= 2 && N0 <= 32) {
-        // (3, 64, 64, 128): layer 1 reads one K block, layers 2 and 3 two
-        PCCX_CHECK_ARG(kt(N1) == 2 && kt(N2) == 2, "pccx_planes_chain4: unsupported widths %d %d %d %d", N0, N1, N2, N3);
-        PG_CHAIN(1, 1, 1, 2, 1, 2, 1);
-    } else if (N0 > 64 && N0 <= 128 && N1 > 96 && N1 <= 128 && N2 > 96 && N2 <= 128 && N3 > 128 && N3 <= 256 && N0 > 96) {
-        // (128, 128, 128, 256): four K blocks into every chained layer, two passes of the last
-        PG_CHAIN(2, 4, 2, 4, 2, 4, 2);
-    } else {
-        pccx_set_error("pccx_planes_chain4: unsupported widths %d %d %d %d", N0, N1, N2, N3);
-        return PCCX_ERR_ARG;
-    }
-#undef PG_CHAIN
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -1,3 +1,7 @@
+// EXPERIMENT RECORD (not built): planes_gemm_kernel with the A fragments of chunk c+1 read from the ring under chunk c's MFMAs
+// (two register sets, 246-251 VGPRs).  Measured on the PPPF workload (2048 patches): the 512->1024 layer 36.6 -> 35.6 ms, every other
+// MB = 8 layer unchanged -- LDS read latency is not what holds the kernel at 0.57 of the bf16x3 peak; the MB = 4 form indexes the two
+// sets with a run-time parity, which the compiler turns into scratch arrays (3x slower).  Not kept.
 // planes.hip -- the wide Conv1x1 / Linear stacks of the PointNet++ families (pointnet_sa_module.py:38-93, PPPF_AE.py:64-107)
 // in the bf16x3 arithmetic, with the activations kept between layers as the three bf16 planes of the NEXT layer's MFMA B
 // operand instead of fp32 rows:
@@ -178,9 +182,13 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
     }
     const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
     {
-        // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [3], B(t+2) [6];  boundary(2t+1): DMA(2t+4) [3]
-        //                                          HALVES = 1:  boundary(t):  DMA(t+3) [3],  B(t+2) [6]
-        // loads complete in order, so boundary(c) may leave in flight everything issued after the youngest load it needs.
+        // Chunk c (4 m-tiles x 3 planes) is consumed from REGISTERS: its A fragments are read from the ring one chunk ahead, under
+        // the previous chunk's MFMAs, so no MFMA waits on LDS latency.  Iteration c: wait for the DMA of chunk c+1 and for this
+        // wave's reads of chunk c (lgkmcnt), barrier (now buffer c % 4 is free), DMA chunk c+4 into it, read chunk c+1 into the
+        // other register set, run chunk c's 48 MFMAs.  B planes: three rotating register sets, loaded two k-steps ahead.
+        // VMEM issue order per wave:  HALVES = 2:  iteration 2t: DMA(2t+4) [3], B(t+2) [6];  iteration 2t+1: DMA(2t+5) [3]
+        //                             HALVES = 1:  iteration t:  DMA(t+4) [3],  B(t+2) [6]
+        // loads complete in order, so an iteration may leave in flight everything issued after the youngest load it needs.
         uint4 bs[3][2][3];
         auto load_b = [&](uint4 (&dst)[2][3], int t) {
             const int tc = t < KT32 ? t : KT32 - 1;
@@ -190,28 +198,27 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                 for (int pl = 0; pl < 3; ++pl)
                     dst[nt][pl] = pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
         };
-        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
+        bf16x8 a[2][4][3];
+        auto read_a = [&](bf16x8 (&dst)[4][3], int c) {
+            const f32x4 *buf = ws.chunk(c);
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) dst[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+        };
+        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3]) {
 #pragma unroll
             for (int half = 0; half < HALVES; ++half) {
                 const int c = HALVES * t + half;
                 if (half == 0) {
-                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    __syncthreads();
-                    dma(c + PG_NB - 1);
-                    load_b(bload, t + 2);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                    __syncthreads();
-                    dma(c + PG_NB - 1);
-                }
-                const f32x4 *buf = ws.chunk(c);
-                bf16x8 a[4][3];
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                    if (HALVES == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+                } else
+                    asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                dma(c + PG_NB);
+                if (half == 0) load_b(bload, t + 2);
+                read_a(a[(c + 1) & 1], c + 1);              // past the end: a stale buffer, never used
                 __builtin_amdgcn_sched_barrier(0);
                 // six products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -222,21 +229,25 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
                             acc[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq], 0, 0, 0);
+                                a[c & 1][mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        dma(PG_NB - 1);                                   // the ring starts full: chunks 0..3
         load_b(bs[0], 0);
         load_b(bs[1], 1);
-        kstep(0, bs[0], bs[2], true);                     // waits for everything issued so far
-        if (KT32 > 1) kstep(1, bs[1], bs[0], false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_a(a[0], 0);
+        kstep(0, bs[0], bs[2]);
+        if (KT32 > 1) kstep(1, bs[1], bs[0]);
 #pragma unroll 1
         for (int t = 2; t < KT32; t += 3) {               // three k-steps per trip: static register sets
-            kstep(t, bs[2], bs[1], false);
-            if (t + 1 < KT32) kstep(t + 1, bs[0], bs[2], false);
-            if (t + 2 < KT32) kstep(t + 2, bs[1], bs[0], false);
+            kstep(t, bs[2], bs[1]);
+            if (t + 1 < KT32) kstep(t + 1, bs[0], bs[2]);
+            if (t + 2 < KT32) kstep(t + 2, bs[1], bs[0]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads and DMAs
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the last (clamped, unused) B loads, DMAs and reads
     }
 
     if constexpr (EPI == PG_EPI_PLANES) {
@@ -336,242 +347,6 @@ extern "C" int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const 
         else PG_LAUNCH(4, PG_EPI_MAX);
     }
 #undef PG_LAUNCH
-    PCCX_CHECK_LAUNCH();
-    return PCCX_OK;
-}
-
-// ---- four-layer stack in one kernel ------------------------------------------------------------------------------
-// Conv-BN-ReLU x 4 + max over nsample (pointnet_sa_module.py:90-91) for stacks whose first three widths are <= 128: layer 0 is the
-// GEMM above on the planes of the gathered input; its accumulators (128 rows x <= 128 channels per workgroup, 2 row tiles x <= 8
-// m-tiles per wave) are split in registers into the next layer's B planes (the chain of mfma_chain.h), and so on; the last layer
-// runs in passes of 128 output channels, each reduced over the groups of `group` rows as in the epilogue above.  One weight stream
-// for the whole stack (the four layers' pccx_pack_planes_gemm streams back to back) goes through the LDS-DMA ring; no activation
-// of the stack exists in HBM.
-//   MQ0 / MQ1 / MQ2 : output m-quads (4 m-tiles) of layers 0..2 (1 or 2);  KT1..KT3 : K/32 blocks of the inputs of layers 1..3;
-//   NP : passes (of 8 m-tiles) of the last layer.
-template <int KT, int MQ, class WS>
-__device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, const bf16x8 (&in)[2][KT][3], f32x4 (&acc)[2][4 * MQ])
-{
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int mqq = 0; mqq < MQ; ++mqq) {
-            // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (6 loads) may stay in flight
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __syncthreads();
-            {
-                const int nx = c + PG_NB - 1;
-                ws.issue(nx < nch ? nx : 0, nx % PG_NB);
-            }
-            const f32x4 *buf = ws.chunk(c);
-            bf16x8 a[4][3];
-#pragma unroll
-            for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[nt][4 * mqq + mq] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], in[nt][kt][PB[q]], acc[nt][4 * mqq + mq], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            ++c;
-        }
-}
-
-template <int NTILES>
-__device__ __forceinline__ void pg_bias_init(f32x4 (&acc)[2][NTILES], const float *__restrict__ bias, int N, int m0, int g)
-{
-#pragma unroll
-    for (int mt = 0; mt < NTILES; ++mt) {
-        f32x4 b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = 16 * (m0 + mt) + 4 * g + r;
-            b[r] = (bias && ch < N) ? bias[ch] : 0.f;
-        }
-        acc[0][mt] = b; acc[1][mt] = b;
-    }
-}
-
-// relu + split of a layer's accumulators into the next layer's planes (k-tile j = C tiles 2j, 2j+1; a missing odd tile is zero)
-template <int NTILES, int KT>
-__device__ __forceinline__ void pg_to_planes(const f32x4 (&acc)[2][NTILES], bf16x8 (&pl)[2][KT][3])
-{
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int j = 0; j < KT; ++j)
-            b3_split8(relu4(acc[nt][2 * j]), 2 * j + 1 < NTILES ? relu4(acc[nt][2 * j + 1]) : zero, pl[nt][j]);
-}
-
-template <int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP>
-__global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__restrict__ bin, long long M, long long ntiles, int KT0,
-                                                               const float *__restrict__ wstream, const float *__restrict__ b0, int N0,
-                                                               const float *__restrict__ b1, int N1, const float *__restrict__ b2, int N2,
-                                                               const float *__restrict__ b3, int N3, int group, float *__restrict__ out,
-                                                               int ldo)
-{
-    static_assert(2 * KT1 <= 4 * MQ0 + 1 && 2 * KT2 <= 4 * MQ1 + 1 && 2 * KT3 <= 4 * MQ2 + 1, "a layer's K blocks come from the previous layer's tiles");
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane >> 4, n = lane & 15;
-    const long long blk = blockIdx.x;
-    const long long tile0 = blk * 8 + 2 * w;
-    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * PG_CHUNK * 64];
-    __shared__ float smax[4 * 128];
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    const int nch = MQ0 * KT0 + KT1 * MQ1 + KT2 * MQ2 + NP * KT3 * 2;
-    const WStreamT<PG_CHUNK, PG_NB> ws{wstream, swt, nch, lane, wu, false};
-    auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % PG_NB); };
-#pragma unroll
-    for (int c = 0; c < PG_NB - 1; ++c) dma(c);
-
-    const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
-    // ---- layer 0: as planes_gemm_kernel (HALVES = MQ0)
-    f32x4 acc0[2][4 * MQ0];
-    pg_bias_init<4 * MQ0>(acc0, b0, N0, 0, g);
-    {
-        uint4 bs[3][2][3];
-        auto load_b = [&](uint4 (&dst)[2][3], int t) {
-            const int tc = t < KT0 ? t : KT0 - 1;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    dst[nt][pl] = pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
-        };
-        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
-#pragma unroll
-            for (int half = 0; half < MQ0; ++half) {
-                const int c = MQ0 * t + half;
-                if (half == 0) {
-                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    __syncthreads();
-                    dma(c + PG_NB - 1);
-                    load_b(bload, t + 2);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                    __syncthreads();
-                    dma(c + PG_NB - 1);
-                }
-                const f32x4 *buf = ws.chunk(c);
-                bf16x8 a[4][3];
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
-                __builtin_amdgcn_sched_barrier(0);
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int mq = 0; mq < 4; ++mq)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc0[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc0[nt][4 * half + mq], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        load_b(bs[0], 0);
-        load_b(bs[1], 1);
-        kstep(0, bs[0], bs[2], true);
-        if (KT0 > 1) kstep(1, bs[1], bs[0], false);
-#pragma unroll 1
-        for (int t = 2; t < KT0; t += 3) {
-            kstep(t, bs[2], bs[1], false);
-            if (t + 1 < KT0) kstep(t + 1, bs[0], bs[2], false);
-            if (t + 2 < KT0) kstep(t + 2, bs[1], bs[0], false);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads land before their
-    }                                                                     // registers are reused; the ring's DMAs with them
-    int c = MQ0 * KT0;
-    // ---- layers 1, 2: registers to registers
-    bf16x8 i1[2][KT1][3];
-    pg_to_planes<4 * MQ0, KT1>(acc0, i1);
-    f32x4 acc1[2][4 * MQ1];
-    pg_bias_init<4 * MQ1>(acc1, b1, N1, 0, g);
-    pg_chain_layer<KT1, MQ1>(ws, c, nch, i1, acc1);
-    bf16x8 i2[2][KT2][3];
-    pg_to_planes<4 * MQ1, KT2>(acc1, i2);
-    f32x4 acc2[2][4 * MQ2];
-    pg_bias_init<4 * MQ2>(acc2, b2, N2, 0, g);
-    pg_chain_layer<KT2, MQ2>(ws, c, nch, i2, acc2);
-    bf16x8 i3[2][KT3][3];
-    pg_to_planes<4 * MQ2, KT3>(acc2, i3);
-    // ---- last layer in passes of 8 m-tiles, each reduced over the row groups
-    const int gpb = 128 / group, wpg = group / 32;
-    const long long G = M / group;
-#pragma unroll 1
-    for (int ps = 0; ps < NP; ++ps) {
-        f32x4 acc3[2][8];
-        pg_bias_init<8>(acc3, b3, N3, 8 * ps, g);
-        pg_chain_layer<KT3, 2>(ws, c, nch, i3, acc3);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(acc3[0][mt][r], acc3[1][mt][r]);
-                v = row16_max(v);
-                if (n == 0) smax[w * 128 + 16 * mt + 4 * g + r] = v;
-            }
-        __syncthreads();
-        for (int e = tid; e < gpb * 128; e += 256) {
-            const int gi = e >> 7, ch = e & 127;
-            float v = smax[(gi * wpg) * 128 + ch];
-            for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * 128 + ch]);
-            v = fmaxf(v, 0.f);                               // max(relu(x)) = relu(max(x))
-            const long long grp = blk * gpb + gi;
-            const int co = 128 * ps + ch;
-            if (grp < G && co < N3) out[(size_t)grp * ldo + co] = v;
-        }
-        // the next pass writes smax only after its first ring boundary (a barrier every thread reaches after these reads)
-    }
-    ws.drain();
-}
-
-// out (M / group, ldo) = max over each `group` consecutive rows of relu(L3(relu(L2(relu(L1(relu(L0(x)))))))) for x given as planes.
-// wstream: the four layers' pccx_pack_planes_gemm streams back to back.  Supported stacks (PCCX_ERR_ARG otherwise; callers fall
-// back to pccx_planes_gemm layer by layer): widths (N0..N3) with N0, N1, N2 <= 128 in the two shapes of PPPF_AE.py:29-34,
-// (<=64, <=64, <=64, <=128) and (<=128 x3, <=256), each layer's input being the previous layer's output.
-extern "C" int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
-                                  const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
-                                  int ldo, void *stream)
-{
-    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(planes_in && wstream && out, "pccx_planes_chain4: null pointer");
-    PCCX_CHECK_ARG(M > 0 && K0 >= 1 && N0 >= 1 && N1 >= 1 && N2 >= 1 && N3 >= 1 && ldo >= N3, "pccx_planes_chain4: bad shape");
-    PCCX_CHECK_ARG((group == 32 || group == 64 || group == 128) && M % group == 0,
-                   "pccx_planes_chain4: group in {32,64,128} dividing M (group=%d M=%lld)", group, (long long)M);
-    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
-    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "pccx_planes_chain4: M too large");
-    const int KT0 = pg_kt32(K0);
-    hipStream_t st = (hipStream_t)stream;
-    auto mq = [](int N) { return pg_mb(N) / 4; };
-    auto kt = [](int N) { return pg_kt32(N); };
-#define PG_CHAIN(MQ0, KT1, MQ1, KT2, MQ2, KT3, NP)                                                                               \
-    hipLaunchKernelGGL((planes_chain4_kernel<MQ0, KT1, MQ1, KT2, MQ2, KT3, NP>), dim3((unsigned)nblk), dim3(256), 0, st,           \
-                       (const uint4 *)planes_in, (long long)M, ntiles, KT0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo)
-    if (N0 <= 64 && N1 <= 64 && N2 <= 64 && N3 > 64 && N3 <= 128 && mq(N0) == 1 && kt(N0) <= 1 && kt(N1) <= 2 && kt(N2) <= 2 && N0 <= 32) {
-        // (3, 64, 64, 128): layer 1 reads one K block, layers 2 and 3 two
-        PCCX_CHECK_ARG(kt(N1) == 2 && kt(N2) == 2, "pccx_planes_chain4: unsupported widths %d %d %d %d", N0, N1, N2, N3);
-        PG_CHAIN(1, 1, 1, 2, 1, 2, 1);
-    } else if (N0 > 64 && N0 <= 128 && N1 > 96 && N1 <= 128 && N2 > 96 && N2 <= 128 && N3 > 128 && N3 <= 256 && N0 > 96) {
-        // (128, 128, 128, 256): four K blocks into every chained layer, two passes of the last
-        PG_CHAIN(2, 4, 2, 4, 2, 4, 2);
-    } else {
-        pccx_set_error("pccx_planes_chain4: unsupported widths %d %d %d %d", N0, N1, N2, N3);
-        return PCCX_ERR_ARG;
-    }
-#undef PG_CHAIN
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

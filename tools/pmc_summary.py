@@ -39,6 +39,7 @@ def load(d):
             key = (r["Dispatch_Id"], r["Counter_Name"])
             per_dispatch[key] += float(r["Counter_Value"])          # rows may be split per XCD / dimension
             names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+            per_dispatch[(r["Dispatch_Id"], "_duration_ns")] = float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         for (disp, ctr), v in per_dispatch.items():
             acc[names[disp]][ctr].append(v)
     return acc
@@ -60,7 +61,8 @@ def main():
             if kern not in mine:
                 continue
             for ctr, vals in sorted(acc[kern].items()):
-                rows.append((pname, kern, ctr, sum(vals) / len(vals), len(vals)))
+                if not ctr.startswith("_"):
+                    rows.append((pname, kern, ctr, sum(vals) / len(vals), len(vals)))
     # derived: MFMA-pipe utilisation.  SQ_VALU_MFMA_BUSY_CYCLES sums busy cycles over the 1024 SIMDs, GRBM_GUI_ACTIVE
     # sums active cycles over the 8 XCDs, so utilisation = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024); the clock under load is
     # GUI_ACTIVE / 8 / kernel duration.
@@ -71,12 +73,18 @@ def main():
             gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
             if mf > 0:
                 rows.append(("derived", kern, "MFMA_pipe_utilisation", mf / (gui * 128.0), len(c["GRBM_GUI_ACTIVE"])))
+        if c.get("GRBM_GUI_ACTIVE") and c.get("_duration_ns"):
+            # clock the chip held during the dispatch (it lowers its clock under load: MI355X_MICROARCH.md, DVFS): cycles / ns
+            clk = [a / 8.0 / d for a, d in zip(c["GRBM_GUI_ACTIVE"], c["_duration_ns"]) if d >= 1e6]     # reads high below ~0.3 ms
+            if clk:
+                rows.append(("derived", kern, "clock_GHz_under_load", sum(clk) / len(clk), len(clk)))
     out = os.path.join(ROOT, "profiles", args.tag + "_pmc_summary.csv")
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["pass", "kernel", "counter", "mean_per_launch", "launches"])
         w.writerows(rows)
 
+    derived = {(k, c): v for (pn, k, c, v, _) in rows if pn == "derived"}
     kernels = {}
     for kern in mine:
         fs = passes["fetch"].get(kern, {}).get("FETCH_SIZE")
@@ -89,6 +97,10 @@ def main():
         if t.get("TCC_HIT_sum") and t.get("TCC_MISS_sum"):
             h, m = sum(t["TCC_HIT_sum"]), sum(t["TCC_MISS_sum"])
             ent["l2_hit_rate"] = h / (h + m) if h + m else None
+        if (kern, "MFMA_pipe_utilisation") in derived:
+            ent["mfma_pipe_busy"] = derived[(kern, "MFMA_pipe_utilisation")]
+        if (kern, "clock_GHz_under_load") in derived:
+            ent["clock_ghz_under_load"] = derived[(kern, "clock_GHz_under_load")]
         kernels[kern] = ent
     note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate passes, bench.py --steps 1 --warmup 1 "
             "--batch 256 --cpu-clouds 0 --one-mode (tools/pmc_summary.py, tag %s). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE "
