@@ -270,6 +270,71 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
     }
 }
 
+// Small clouds (N <= 512: the patches of the PointNet++ families, pointnet_sa_module.py:66-68): one WAVE per cloud, up to 8 points
+// per lane in registers, no workgroup barrier in the round -- argmax by DPP, the winner's coordinates from the wave's LDS copy.
+// Same arithmetic and the same first-maximum rule as fps_kernel (point i = lane + 64 j: ascending j in the lane, lower index on ties
+// across lanes), so the indices are identical.
+template <int PPL>
+__global__ __launch_bounds__(256) void fps_wave_kernel(const float *__restrict__ xyz, int B, int N, int npoint,
+                                                       const int32_t *__restrict__ start, int64_t *__restrict__ out)
+{
+    __shared__ float sxyz[4][3 * 64 * PPL];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= B) return;                                     // whole wave; no barriers below
+    const float *p = xyz + (size_t)b * N * 3;
+    float *sx = sxyz[w];
+    for (int i = lane; i < 3 * N; i += 64) sx[i] = p[i];
+    constexpr int PP = PPL / 2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 px[PP], py[PP], pz[PP], md[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = lane + (2 * j + e) * 64;
+            if (i < N) {
+                px[j][e] = p[3 * i]; py[j][e] = p[3 * i + 1]; pz[j][e] = p[3 * i + 2];
+                md[j][e] = 1e10f;
+            } else {
+                px[j][e] = py[j][e] = pz[j][e] = 0.f;
+                md[j][e] = -INFINITY;
+            }
+        }
+    int far = start ? start[b] : 0;
+    if (far < 0 || far >= N) far = 0;
+    far = __builtin_amdgcn_readfirstlane(far);
+    __builtin_amdgcn_s_waitcnt(0);                           // the wave's own LDS stores (one wave: no barrier needed)
+    for (int s = 0; s < npoint; ++s) {
+        if (lane == 0) out[(size_t)b * npoint + s] = far;
+        const float cx = sx[3 * far], cy = sx[3 * far + 1], cz = sx[3 * far + 2];
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const f32x2 dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            f32x2 d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (d[e] < md[j][e]) md[j][e] = d[e];
+                if (md[j][e] > best) { best = md[j][e]; bi = lane + (2 * j + e) * 64; }
+            }
+        }
+        wave_argmax(best, bi);
+        far = __builtin_amdgcn_readfirstlane(bi);
+    }
+}
+
+template <int PPL>
+static int launch_fps_wave(const float *xyz, int B, int N, int npoint, const int32_t *start, int64_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(fps_wave_kernel<PPL>, dim3((B + 3) / 4), dim3(256), 0, st, xyz, B, N, npoint, start, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // N > 16384: running min-distance lives in a global workspace (L2-resident), same selection rule.
 __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int N, int npoint,
                                                        const int32_t *__restrict__ start, int64_t *__restrict__ out,
@@ -325,6 +390,9 @@ extern "C" int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_
     PCCX_CHECK_ARG(xyz && idx_out, "pccx_fps: null pointer");
     PCCX_CHECK_ARG(B >= 0 && N >= 1 && npoint >= 0, "pccx_fps: bad shape B=%d N=%d npoint=%d", B, N, npoint);
     hipStream_t st = (hipStream_t)stream;
+    if (N <= 128) return launch_fps_wave<2>(xyz, B, N, npoint, start_idx, idx_out, st);
+    if (N <= 256) return launch_fps_wave<4>(xyz, B, N, npoint, start_idx, idx_out, st);
+    if (N <= 512) return launch_fps_wave<8>(xyz, B, N, npoint, start_idx, idx_out, st);
     if (N <= 1024) return launch_fps<1>(xyz, B, N, npoint, start_idx, idx_out, st);
     if (N <= 2048) return launch_fps<2>(xyz, B, N, npoint, start_idx, idx_out, st);
     if (N <= 4096) return launch_fps<4>(xyz, B, N, npoint, start_idx, idx_out, st);

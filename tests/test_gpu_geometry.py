@@ -52,11 +52,12 @@ def test_fps_golden_indices():
         assert np.array_equal(g[0].cpu().numpy(), fp[f"gather_{i}"])
 
 
-@pytest.mark.parametrize("N,S", [(1, 1), (7, 7), (64, 10), (1000, 33), (1024, 64), (1025, 5), (3000, 100),
+@pytest.mark.parametrize("N,S", [(1, 1), (7, 7), (64, 10), (128, 128), (129, 40), (256, 256), (257, 32), (512, 512), (513, 9), (1000, 33),
+                                 (1024, 64), (1025, 5), (3000, 100),
                                  (8192, 64), (10000, 17), (16384, 8), (20000, 9)])
 def test_fps_ragged_sizes_vs_oracle(N, S):
     rng = np.random.default_rng(N * 31 + S)
-    B = 3
+    B = 3 if N > 512 or N < 64 else 7               # N <= 512: one wave per cloud, four clouds per workgroup (ragged last workgroup)
     pcs = rng.random((B, N, 3)).astype(np.float32)
     if N >= 64:
         pcs[1, 5] = pcs[1, 50]                      # duplicate points: argmax ties -> first index
