@@ -483,8 +483,11 @@ def bench_pppf(args, rk):
             peak = F32_MATRIX_PEAK_TFLOPS if args.matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS
             rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                   "frac": ach / peak, "traffic": None, "flop_per_patch": flop, "arithmetic": args.matmul,
-                  "note": "whole-forward wall time, not a single kernel: layer-by-layer generic kernels (csrc/linear.hip), bound by "
-                          "their activation round trips through HBM rather than by the matrix pipe (DESIGN.md section 7)"}
+                  "note": ("whole-forward wall time, not a single kernel.  bf16x3: activations stay in operand planes between layers, sa1 / sa2 "
+                           "are one kernel each (csrc/planes.hip), the widest layer (512->1024 + max over 128) alone is a third of the step"
+                           if args.matmul != "f32" else
+                           "whole-forward wall time, not a single kernel: layer-by-layer generic kernels (csrc/linear.hip), bound by "
+                           "their activation round trips through HBM rather than by the matrix pipe") + " (DESIGN.md section 7)"}
         print(json.dumps({
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,

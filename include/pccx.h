@@ -300,6 +300,12 @@ PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const fl
 PCCX_API int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
                                 const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
                                 int ldo, void *stream);
+/* The same stack with the gather inside the kernel: row r of the input is row (r / rows_per_batch) * n_src + max(idx[r], 0) of src,
+ * fp32 rows of ldp = 32 * ceil(K0 / 32) floats (the K0 channels [features, xyz] zero padded; 16-byte aligned).  The grouped tensor of
+ * pointnet_sa_module.py:73-83 is never materialised. */
+PCCX_API int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                       int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
+                                       const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream);
 
 /* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
  * x (G,Kn,C) -> out (G,C). */

@@ -411,8 +411,10 @@ __device__ __forceinline__ void pg_to_planes(const f32x4 (&acc)[2][NTILES], bf16
             b3_split8(relu4(acc[nt][2 * j]), 2 * j + 1 < NTILES ? relu4(acc[nt][2 * j + 1]) : zero, pl[nt][j]);
 }
 
-template <int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP>
-__global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__restrict__ bin, long long M, long long ntiles, int KT0,
+template <int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP, bool GATHER>
+__global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__restrict__ bin, const int64_t *__restrict__ idx,
+                                                               long long rows_per_batch, long long n_src, int ldp, long long M,
+                                                               long long ntiles, int KT0,
                                                                const float *__restrict__ wstream, const float *__restrict__ b0, int N0,
                                                                const float *__restrict__ b1, int N1, const float *__restrict__ b2, int N2,
                                                                const float *__restrict__ b3, int N3, int group, float *__restrict__ out,
@@ -433,32 +435,56 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
     for (int c = 0; c < PG_NB - 1; ++c) dma(c);
 
     const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
-    // ---- layer 0: as planes_gemm_kernel (HALVES = MQ0)
+    // ---- layer 0: as planes_gemm_kernel (HALVES = MQ0).  GATHER: the B operand is not read as planes but gathered here --
+    // bin = fp32 source rows (n_src per batch, ldp = 32 * KT0 floats each, zero padded), row r reads source row
+    // (r / rows_per_batch) * n_src + max(idx[r], 0) (pointnet_sa_module.py:27,73-83) -- and split in registers at use.
     f32x4 acc0[2][4 * MQ0];
     pg_bias_init<4 * MQ0>(acc0, b0, N0, 0, g);
     {
-        uint4 bs[3][2][3];
-        auto load_b = [&](uint4 (&dst)[2][3], int t) {
+        constexpr int NBL = GATHER ? 4 : 6;                  // B loads per k-step
+        constexpr int NBV = GATHER ? 2 : 3;
+        uint4 bs[3][2][NBV];
+        const uint4 *gsrc[2] = {nullptr, nullptr};
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                long long r = (nt ? t1 : t0) * 16 + n;
+                if (r >= M) r = M - 1;
+                const long long j = idx[r];
+                gsrc[nt] = (const uint4 *)((const float *)bin + (size_t)((r / rows_per_batch) * n_src + (j < 0 ? 0 : j)) * ldp + 4 * g);
+            }
+        }
+        auto load_b = [&](uint4 (&dst)[2][NBV], int t) {
             const int tc = t < KT0 ? t : KT0 - 1;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    dst[nt][pl] = pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+                for (int pl = 0; pl < NBV; ++pl)
+                    dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
+                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
         };
-        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
+        auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
+            bf16x8 bc[2][3];
 #pragma unroll
             for (int half = 0; half < MQ0; ++half) {
                 const int c = MQ0 * t + half;
                 if (half == 0) {
                     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NBL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if constexpr (GATHER)
+                            b3_split8(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), bc[nt]);
+                        else
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) bc[nt][pl] = __builtin_bit_cast(bf16x8, braw[nt][pl < NBV ? pl : 0]);
+                    }
                 } else {
-                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                 }
@@ -476,8 +502,8 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc0[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc0[nt][4 * half + mq], 0, 0, 0);
+                            acc0[nt][4 * half + mq] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], bc[nt][PB[q]], acc0[nt][4 * half + mq], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -538,40 +564,63 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
     ws.drain();
 }
 
-// out (M / group, ldo) = max over each `group` consecutive rows of relu(L3(relu(L2(relu(L1(relu(L0(x)))))))) for x given as planes.
+// out (M / group, ldo) = max over each `group` consecutive rows of relu(L3(relu(L2(relu(L1(relu(L0(x)))))))).
 // wstream: the four layers' pccx_pack_planes_gemm streams back to back.  Supported stacks (PCCX_ERR_ARG otherwise; callers fall
-// back to pccx_planes_gemm layer by layer): widths (N0..N3) with N0, N1, N2 <= 128 in the two shapes of PPPF_AE.py:29-34,
-// (<=64, <=64, <=64, <=128) and (<=128 x3, <=256), each layer's input being the previous layer's output.
-extern "C" int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
-                                  const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
-                                  int ldo, void *stream)
+// back to pccx_planes_gemm layer by layer): widths (N0..N3) in the two shapes of PPPF_AE.py:29-34, (<=32, 33..64, 33..64, 65..128)
+// and (97..128 x3, 129..256), each layer's input being the previous layer's output.
+//   pccx_planes_chain4        : x given as planes (pccx_group_planes / a previous layer);
+//   pccx_planes_chain4_gather : x gathered in the kernel from fp32 rows src (n_src rows per batch of ldp = 32 * ceil(K0 / 32) floats,
+//                               the K0 channels zero padded) by idx (M entries, -1 -> row 0): the grouped tensor of
+//                               pointnet_sa_module.py:73-83 never exists in memory in any form.
+static int planes_chain4_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K0,
+                                const float *wstream, const float *b0, int N0, const float *b1, int N1, const float *b2, int N2,
+                                const float *b3, int N3, int group, float *out, int ldo, void *stream, const char *who)
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(planes_in && wstream && out, "pccx_planes_chain4: null pointer");
-    PCCX_CHECK_ARG(M > 0 && K0 >= 1 && N0 >= 1 && N1 >= 1 && N2 >= 1 && N3 >= 1 && ldo >= N3, "pccx_planes_chain4: bad shape");
-    PCCX_CHECK_ARG((group == 32 || group == 64 || group == 128) && M % group == 0,
-                   "pccx_planes_chain4: group in {32,64,128} dividing M (group=%d M=%lld)", group, (long long)M);
+    PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
+    PCCX_CHECK_ARG(M > 0 && K0 >= 1 && N0 >= 1 && N1 >= 1 && N2 >= 1 && N3 >= 1 && ldo >= N3, "%s: bad shape", who);
+    PCCX_CHECK_ARG((group == 32 || group == 64 || group == 128) && M % group == 0, "%s: group in {32,64,128} dividing M (group=%d M=%lld)",
+                   who, group, (long long)M);
     const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
-    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "pccx_planes_chain4: M too large");
+    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "%s: M too large", who);
     const int KT0 = pg_kt32(K0);
+    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1 && ldp == 32 * KT0 && (uintptr_t)x % 16 == 0),
+                   "%s: source rows must be 16-byte aligned with a stride of %d floats (got %d)", who, 32 * KT0, ldp);
     hipStream_t st = (hipStream_t)stream;
-    auto mq = [](int N) { return pg_mb(N) / 4; };
     auto kt = [](int N) { return pg_kt32(N); };
-#define PG_CHAIN(MQ0, KT1, MQ1, KT2, MQ2, KT3, NP)                                                                               \
-    hipLaunchKernelGGL((planes_chain4_kernel<MQ0, KT1, MQ1, KT2, MQ2, KT3, NP>), dim3((unsigned)nblk), dim3(256), 0, st,           \
-                       (const uint4 *)planes_in, (long long)M, ntiles, KT0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo)
-    if (N0 <= 64 && N1 <= 64 && N2 <= 64 && N3 > 64 && N3 <= 128 && mq(N0) == 1 && kt(N0) <= 1 && kt(N1) <= 2 && kt(N2) <= 2 && N0 <= 32) {
+#define PG_CHAIN(G_, MQ0, KT1, MQ1, KT2, MQ2, KT3, NP)                                                                           \
+    hipLaunchKernelGGL((planes_chain4_kernel<MQ0, KT1, MQ1, KT2, MQ2, KT3, NP, G_>), dim3((unsigned)nblk), dim3(256), 0, st,       \
+                       (const uint4 *)x, idx, (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT0, wstream, b0, \
+                       N0, b1, N1, b2, N2, b3, N3, group, out, ldo)
+    if (N0 <= 32 && N1 > 32 && N1 <= 64 && N2 > 32 && N2 <= 64 && N3 > 64 && N3 <= 128) {
         // (3, 64, 64, 128): layer 1 reads one K block, layers 2 and 3 two
-        PCCX_CHECK_ARG(kt(N1) == 2 && kt(N2) == 2, "pccx_planes_chain4: unsupported widths %d %d %d %d", N0, N1, N2, N3);
-        PG_CHAIN(1, 1, 1, 2, 1, 2, 1);
-    } else if (N0 > 64 && N0 <= 128 && N1 > 96 && N1 <= 128 && N2 > 96 && N2 <= 128 && N3 > 128 && N3 <= 256 && N0 > 96) {
+        PCCX_CHECK_ARG(kt(N0) == 1 && kt(N1) == 2 && kt(N2) == 2, "%s: unsupported widths %d %d %d %d", who, N0, N1, N2, N3);
+        if (idx) PG_CHAIN(true, 1, 1, 1, 2, 1, 2, 1); else PG_CHAIN(false, 1, 1, 1, 2, 1, 2, 1);
+    } else if (N0 > 96 && N0 <= 128 && N1 > 96 && N1 <= 128 && N2 > 96 && N2 <= 128 && N3 > 128 && N3 <= 256) {
         // (128, 128, 128, 256): four K blocks into every chained layer, two passes of the last
-        PG_CHAIN(2, 4, 2, 4, 2, 4, 2);
+        if (idx) PG_CHAIN(true, 2, 4, 2, 4, 2, 4, 2); else PG_CHAIN(false, 2, 4, 2, 4, 2, 4, 2);
     } else {
-        pccx_set_error("pccx_planes_chain4: unsupported widths %d %d %d %d", N0, N1, N2, N3);
+        pccx_set_error("%s: unsupported widths %d %d %d %d", who, N0, N1, N2, N3);
         return PCCX_ERR_ARG;
     }
 #undef PG_CHAIN
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
+}
+
+extern "C" int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
+                                  const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
+                                  int ldo, void *stream)
+{
+    return planes_chain4_launch(planes_in, nullptr, 1, 1, 0, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo, stream,
+                                "pccx_planes_chain4");
+}
+
+extern "C" int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                         int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
+                                         const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_chain4_gather: null indices");
+    return planes_chain4_launch(src, idx, rows_per_batch, n_src, ldp, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo,
+                                stream, "pccx_planes_chain4_gather");
 }

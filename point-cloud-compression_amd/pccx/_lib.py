@@ -71,6 +71,8 @@ _SIGNATURES = {
     "pccx_pack_planes_gemm": [_P, C.c_int, C.c_int, _P, _P],
     "pccx_planes_gemm": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_planes_chain4": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P],
+    "pccx_planes_chain4_gather": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
+                                  C.c_int, _P, C.c_int, _P],
     "pccx_sigmoid_spread": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_round": [_P, C.c_int64, _P, _P],
     "pccx_pack_linear_device": [_P, C.c_int, C.c_int, C.c_int, _P, _P],

@@ -133,18 +133,44 @@ def chain4_fits(stack):
            (all(96 < v <= 128 for v in n[:3]) and 128 < n[3] <= 256)
 
 
+def _chain_args(stack, cache):
+    if "ws" not in cache:
+        cache["ws"] = torch.cat([l._stream3() for l in stack])
+    a = []
+    for l in stack:
+        a += [l.b.data_ptr(), l.N]
+    return cache["ws"], a
+
+
+def stack_max_gather(stack, feats, xyz, idx, cache):
+    """index_points(feats, idx) ++ index_points(xyz, idx) -> Conv-BN-ReLU x 4 -> max over nsample (pointnet_sa_module.py:73-91) in one
+    kernel for the stacks chain4_fits() accepts: the gather happens inside the kernel from the (B, N, C+3) rows zero padded to a
+    multiple of 32 channels, so the grouped tensor never exists.  idx (B, M, ns) int64, -1 -> row 0.  Returns (B * M, N3)."""
+    B, Mq, ns = idx.shape
+    parts = [p for p in (feats, xyz) if p is not None]
+    C = sum(int(p.shape[-1]) for p in parts)
+    n_src = int(parts[0].shape[1])
+    ldp = (C + 31) // 32 * 32
+    src = torch.zeros(B, n_src, ldp, device=idx.device, dtype=torch.float32)
+    off = 0
+    for p in parts:
+        src[..., off:off + p.shape[-1]] = p
+        off += int(p.shape[-1])
+    ws, a = _chain_args(stack, cache)
+    out = torch.empty(B * Mq, stack[3].N, device=idx.device, dtype=torch.float32)
+    idx = idx.contiguous()
+    _lib.call("pccx_planes_chain4_gather", src.data_ptr(), ldp, idx.data_ptr(), Mq * ns, n_src, B * Mq * ns, C, ws.data_ptr(), *a, ns,
+              out.data_ptr(), stack[3].N, _stream())
+    return out
+
+
 def stack_max_planes(stack, pl, rows, group, cache):
     """Conv-BN-ReLU stack + max over `group` consecutive rows on planes: one kernel when the stack fits pccx_planes_chain4, else
     layer by layer with the max in the last layer's epilogue.  cache: a dict owned by the caller (holds the concatenated stream)."""
     if chain4_fits(stack):
-        if "ws" not in cache:
-            cache["ws"] = torch.cat([l._stream3() for l in stack])
+        ws, a = _chain_args(stack, cache)
         out = torch.empty(rows // group, stack[3].N, device=pl.device, dtype=torch.float32)
-        a = []
-        for l in stack:
-            a += [l.b.data_ptr(), l.N]
-        _lib.call("pccx_planes_chain4", pl.data_ptr(), rows, stack[0].K, cache["ws"].data_ptr(), *a, group, out.data_ptr(), stack[3].N,
-                  _stream())
+        _lib.call("pccx_planes_chain4", pl.data_ptr(), rows, stack[0].K, ws.data_ptr(), *a, group, out.data_ptr(), stack[3].N, _stream())
         return out
     for layer in stack[:-1]:
         pl = layer.planes(pl, rows, 0)
@@ -230,9 +256,11 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
         idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
         if stack[0].mode() == "bf16x3" and self.nsample in (32, 64, 128) and B > 0:
             # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue
-            pl, rows = group_planes(feats, xyz, idx)                                # :73-83 features first, xyz last, not centred
             if getattr(self, "_chain_of", None) is not stack:                       # new pack -> new stream
                 self._chain_of, self._chain_cache = stack, {}
+            if chain4_fits(stack):                                                  # :73-91 in one kernel
+                return new_xyz, stack_max_gather(stack, feats, xyz, idx, self._chain_cache).view(B, self.npoint, -1)
+            pl, rows = group_planes(feats, xyz, idx)                                # :73-83 features first, xyz last, not centred
             out = stack_max_planes(stack, pl, rows, self.nsample, self._chain_cache)            # :90-91 Conv-BN-ReLU stack, max
             return new_xyz, out.view(B, self.npoint, -1)
         grouped = ops.index_points(xyz, idx)                                        # :81 (not centred)

@@ -222,3 +222,16 @@ def test_planes_chain4_matches_layer_by_layer_and_float64():
         for W, b in Ws:
             h = np.maximum(h @ W.T + b, 0)
         np.testing.assert_allclose(got, h.reshape(groups, ns, -1).max(1), atol=3e-5, rtol=2e-5)
+        # the same stack with the gather inside the kernel (pointnet_sa_module.py:73-83; -1 -> row 0): bit-identical to
+        # gather -> planes -> chain
+        if K0 >= 4:
+            Bq, Nsrc = 3, 40
+            Mq = groups // Bq
+            feats = rng.standard_normal((Bq, Nsrc, K0 - 3)).astype(np.float32)
+            xyz = rng.standard_normal((Bq, Nsrc, 3)).astype(np.float32)
+            idx = torch.from_numpy(rng.integers(-1, Nsrc, (Bq, Mq, ns))).cuda()
+            f, z = torch.from_numpy(feats).cuda(), torch.from_numpy(xyz).cuda()
+            pl2, rows2 = families.group_planes(f, z, idx)
+            want = families.stack_max_planes(stack, pl2, rows2, ns, {}).cpu().numpy()
+            got2 = families.stack_max_gather(stack, f, z, idx, {}).cpu().numpy()
+            assert np.array_equal(got2, want), (K0, widths)
