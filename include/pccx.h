@@ -292,6 +292,11 @@ PCCX_API size_t pccx_planes_gemm_weight_floats(int N, int K);
 PCCX_API int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream);
 PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
                               int epilogue, int group, float *out, int ldo, void *stream);
+/* pccx_planes_gemm with the gather inside the kernel: row r of the input = row (r / rows_per_batch) * n_src + max(idx[r], 0) of src,
+ * fp32 rows of ldp = 32 * ceil(K / 32) floats ([features, xyz] zero padded, 16-byte aligned). */
+PCCX_API int pccx_planes_gemm_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                     int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
+                                     float *out, int ldo, void *stream);
 /* A whole Conv-BN-ReLU x 4 + max-over-nsample stack (pointnet_sa_module.py:90-91) in one kernel, the activations between the layers
  * staying in registers: out (M / group, ldo) from the planes of the gathered input.  wstream = the four layers'
  * pccx_pack_planes_gemm streams back to back; b0..b3 the (folded) biases.  Supported width patterns: (<=32, 33..64, 33..64, 65..128)

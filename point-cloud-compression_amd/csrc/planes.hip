@@ -138,8 +138,10 @@ __device__ __forceinline__ uint4 pg_load_async(const uint4 *p)    // placed exac
 
 enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
 
-template <int MB, int EPI>
-__global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__restrict__ bin, long long M, long long ntiles, int KT32,
+template <int MB, int EPI, bool GATHER>
+__global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__restrict__ bin, const int64_t *__restrict__ idx,
+                                                             long long rows_per_batch, long long n_src, int ldp, long long M,
+                                                             long long ntiles, int KT32,
                                                              const float *__restrict__ wstream, int MBS, const float *__restrict__ bias,
                                                              int N, int relu, int group, float *__restrict__ out, int ldo)
 {
@@ -181,28 +183,51 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
         // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [3], B(t+2) [6];  boundary(2t+1): DMA(2t+4) [3]
         //                                          HALVES = 1:  boundary(t):  DMA(t+3) [3],  B(t+2) [6]
         // loads complete in order, so boundary(c) may leave in flight everything issued after the youngest load it needs.
-        uint4 bs[3][2][3];
-        auto load_b = [&](uint4 (&dst)[2][3], int t) {
+        // GATHER: bin = fp32 source rows (n_src per batch, ldp = 32 * KT32 floats, zero padded); row r reads source row
+        // (r / rows_per_batch) * n_src + max(idx[r], 0) and is split in registers at use (4 loads per k-step instead of 6).
+        constexpr int NBL = GATHER ? 4 : 6, NBV = GATHER ? 2 : 3;
+        uint4 bs[3][2][NBV];
+        const uint4 *gsrc[2] = {nullptr, nullptr};
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                long long r = (nt ? t1 : t0) * 16 + n;
+                if (r >= M) r = M - 1;
+                const long long j = idx[r];
+                gsrc[nt] = (const uint4 *)((const float *)bin + (size_t)((r / rows_per_batch) * n_src + (j < 0 ? 0 : j)) * ldp + 4 * g);
+            }
+        }
+        auto load_b = [&](uint4 (&dst)[2][NBV], int t) {
             const int tc = t < KT32 ? t : KT32 - 1;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    dst[nt][pl] = pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+                for (int pl = 0; pl < NBV; ++pl)
+                    dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
+                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
         };
-        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
+        auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
+            bf16x8 bc[2][3];
 #pragma unroll
             for (int half = 0; half < HALVES; ++half) {
                 const int c = HALVES * t + half;
                 if (half == 0) {
                     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NBL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if constexpr (GATHER)
+                            b3_split8(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), bc[nt]);
+                        else
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) bc[nt][pl] = __builtin_bit_cast(bf16x8, braw[nt][pl < NBV ? pl : 0]);
+                    }
                 } else {
-                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                 }
@@ -221,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq], 0, 0, 0);
+                            acc[nt][4 * half + mq] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], bc[nt][PB[q]], acc[nt][4 * half + mq], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -307,37 +332,59 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 
 // out: epilogue 0 -> planes of the N output channels (pccx_planes_floats(M, N) floats); 1 -> fp32 rows (M, ldo);
 // 2 -> fp32 (M / group, ldo), the max over each `group` consecutive rows (group in {32, 64, 128}, M % group == 0).
-extern "C" int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
-                                int epilogue, int group, float *out, int ldo, void *stream)
+static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K,
+                              const float *wstream, const float *bias, int N, int relu, int epilogue, int group, float *out, int ldo,
+                              void *stream, const char *who)
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(planes_in && wstream && out, "pccx_planes_gemm: null pointer");
-    PCCX_CHECK_ARG(M > 0 && K >= 1 && N >= 1, "pccx_planes_gemm: bad shape M=%lld K=%d N=%d", (long long)M, K, N);
-    PCCX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "pccx_planes_gemm: epilogue %d", epilogue);
-    PCCX_CHECK_ARG(epilogue == PG_EPI_PLANES || ldo >= N, "pccx_planes_gemm: ldo=%d < N=%d", ldo, N);
+    PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
+    PCCX_CHECK_ARG(M > 0 && K >= 1 && N >= 1, "%s: bad shape M=%lld K=%d N=%d", who, (long long)M, K, N);
+    PCCX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "%s: epilogue %d", who, epilogue);
+    PCCX_CHECK_ARG(epilogue == PG_EPI_PLANES || ldo >= N, "%s: ldo=%d < N=%d", who, ldo, N);
     PCCX_CHECK_ARG(epilogue != PG_EPI_MAX || ((group == 32 || group == 64 || group == 128) && M % group == 0),
-                   "pccx_planes_gemm: group max needs group in {32,64,128} dividing M (group=%d M=%lld)", group, (long long)M);
+                   "%s: group max needs group in {32,64,128} dividing M (group=%d M=%lld)", who, group, (long long)M);
     const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
     const int MT = (N + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB, KT32 = pg_kt32(K);
     const long long blocks = (nblk + 7) / 8 * 8 * MBS;
-    PCCX_CHECK_ARG(blocks <= 0x7fffffffLL, "pccx_planes_gemm: M=%lld too large", (long long)M);
+    PCCX_CHECK_ARG(blocks <= 0x7fffffffLL, "%s: M=%lld too large", who, (long long)M);
+    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1 && ldp == 32 * KT32 && (uintptr_t)x % 16 == 0),
+                   "%s: source rows must be 16-byte aligned with a stride of %d floats (got %d)", who, 32 * KT32, ldp);
     hipStream_t st = (hipStream_t)stream;
     relu &= 1;
-#define PG_LAUNCH(MB_, E_)                                                                                                      \
-    hipLaunchKernelGGL((planes_gemm_kernel<MB_, E_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)planes_in, (long long)M, \
-                       ntiles, KT32, wstream, MBS, bias, N, relu, group, out, ldo)
-    if (MB == 8) {
-        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(8, PG_EPI_PLANES);
-        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(8, PG_EPI_ROWS);
-        else PG_LAUNCH(8, PG_EPI_MAX);
-    } else {
-        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(4, PG_EPI_PLANES);
-        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(4, PG_EPI_ROWS);
-        else PG_LAUNCH(4, PG_EPI_MAX);
-    }
+#define PG_LAUNCH(MB_, E_, G_)                                                                                                  \
+    hipLaunchKernelGGL((planes_gemm_kernel<MB_, E_, G_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx,       \
+                       (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, \
+                       group, out, ldo)
+#define PG_LAUNCH_E(MB_, G_)                                                                                                    \
+    do {                                                                                                                        \
+        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(MB_, PG_EPI_PLANES, G_);                                                       \
+        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(MB_, PG_EPI_ROWS, G_);                                                      \
+        else PG_LAUNCH(MB_, PG_EPI_MAX, G_);                                                                                    \
+    } while (0)
+    if (MB == 8) { if (idx) PG_LAUNCH_E(8, true); else PG_LAUNCH_E(8, false); }
+    else { if (idx) PG_LAUNCH_E(4, true); else PG_LAUNCH_E(4, false); }
+#undef PG_LAUNCH_E
 #undef PG_LAUNCH
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
+}
+
+extern "C" int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                                int epilogue, int group, float *out, int ldo, void *stream)
+{
+    return planes_gemm_launch(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                              "pccx_planes_gemm");
+}
+
+// The same layer with its input gathered in the kernel (see pccx_planes_chain4_gather): src = fp32 rows of ldp = 32 * ceil(K / 32)
+// floats, row r of the layer's input = source row (r / rows_per_batch) * n_src + max(idx[r], 0).
+extern "C" int pccx_planes_gemm_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                       int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
+                                       float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_gemm_gather: null indices");
+    return planes_gemm_launch(src, idx, rows_per_batch, n_src, ldp, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                              "pccx_planes_gemm_gather");
 }
 
 // ---- four-layer stack in one kernel ------------------------------------------------------------------------------

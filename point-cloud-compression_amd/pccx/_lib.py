@@ -70,6 +70,8 @@ _SIGNATURES = {
     "pccx_planes_gemm_weight_floats": [C.c_int, C.c_int],
     "pccx_pack_planes_gemm": [_P, C.c_int, C.c_int, _P, _P],
     "pccx_planes_gemm": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
+    "pccx_planes_gemm_gather": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
+                                _P],
     "pccx_planes_chain4": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_planes_chain4_gather": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
                                   C.c_int, _P, C.c_int, _P],

@@ -56,6 +56,19 @@ class FoldedLinear:
             _lib.call("pccx_pack_planes_gemm", self._planes3().data_ptr(), self.N, self.K, self.ws3.data_ptr(), _stream())
         return self.ws3
 
+    def planes_gather(self, src, C, idx, epilogue=0, group=0):
+        """planes() on rows gathered inside the kernel: src (B, N, ldp) from padded_rows(), idx (B, M, ns) int64 (-1 -> row 0)."""
+        B, Mq, ns = idx.shape
+        rows = B * Mq * ns
+        self._stream3()
+        if epilogue == 0:
+            out = torch.empty(_lib.load().pccx_planes_floats(rows, self.N), device=src.device, dtype=torch.float32)
+        else:
+            out = torch.empty(rows if epilogue == 1 else rows // group, self.N, device=src.device, dtype=torch.float32)
+        _lib.call("pccx_planes_gemm_gather", src.data_ptr(), src.shape[2], idx.data_ptr(), Mq * ns, src.shape[1], rows, C,
+                  self.ws3.data_ptr(), self.b.data_ptr(), self.N, self.relu, epilogue, group, out.data_ptr(), self.N, _stream())
+        return out
+
     def planes(self, pin, M, epilogue=0, group=0):
         """The layer on an activation kept in planes (csrc/planes.hip; bf16x3 only): pin = planes of the (M, K) input.
         epilogue 0 -> planes of the (M, N) output, 1 -> fp32 rows (M, N), 2 -> (M // group, N) max over `group` consecutive rows."""
@@ -142,26 +155,41 @@ def _chain_args(stack, cache):
     return cache["ws"], a
 
 
+def padded_rows(feats, xyz):
+    """[features, xyz] of every source point as fp32 rows zero padded to a multiple of 32 channels: what the gathering kernels read.
+    Returns (src (B, N, ldp), C)."""
+    parts = [p for p in (feats, xyz) if p is not None]
+    C = sum(int(p.shape[-1]) for p in parts)
+    B, n_src = int(parts[0].shape[0]), int(parts[0].shape[1])
+    src = torch.zeros(B, n_src, (C + 31) // 32 * 32, device=parts[0].device, dtype=torch.float32)
+    off = 0
+    for p in parts:
+        src[..., off:off + p.shape[-1]] = p
+        off += int(p.shape[-1])
+    return src, C
+
+
 def stack_max_gather(stack, feats, xyz, idx, cache):
     """index_points(feats, idx) ++ index_points(xyz, idx) -> Conv-BN-ReLU x 4 -> max over nsample (pointnet_sa_module.py:73-91) in one
     kernel for the stacks chain4_fits() accepts: the gather happens inside the kernel from the (B, N, C+3) rows zero padded to a
     multiple of 32 channels, so the grouped tensor never exists.  idx (B, M, ns) int64, -1 -> row 0.  Returns (B * M, N3)."""
     B, Mq, ns = idx.shape
-    parts = [p for p in (feats, xyz) if p is not None]
-    C = sum(int(p.shape[-1]) for p in parts)
-    n_src = int(parts[0].shape[1])
-    ldp = (C + 31) // 32 * 32
-    src = torch.zeros(B, n_src, ldp, device=idx.device, dtype=torch.float32)
-    off = 0
-    for p in parts:
-        src[..., off:off + p.shape[-1]] = p
-        off += int(p.shape[-1])
-    ws, a = _chain_args(stack, cache)
-    out = torch.empty(B * Mq, stack[3].N, device=idx.device, dtype=torch.float32)
+    src, C = padded_rows(feats, xyz)
     idx = idx.contiguous()
-    _lib.call("pccx_planes_chain4_gather", src.data_ptr(), ldp, idx.data_ptr(), Mq * ns, n_src, B * Mq * ns, C, ws.data_ptr(), *a, ns,
-              out.data_ptr(), stack[3].N, _stream())
-    return out
+    rows = B * Mq * ns
+    if chain4_fits(stack):
+        ws, a = _chain_args(stack, cache)
+        out = torch.empty(B * Mq, stack[3].N, device=idx.device, dtype=torch.float32)
+        _lib.call("pccx_planes_chain4_gather", src.data_ptr(), src.shape[2], idx.data_ptr(), Mq * ns, src.shape[1], rows, C, ws.data_ptr(),
+                  *a, ns, out.data_ptr(), stack[3].N, _stream())
+        return out
+    # layer by layer: the first layer gathers, the last reduces
+    pl = stack[0].planes_gather(src, C, idx) if len(stack) > 1 else None
+    for layer in stack[1:-1]:
+        pl = layer.planes(pl, rows, 0)
+    if len(stack) > 1:
+        return stack[-1].planes(pl, rows, 2, ns)
+    return stack[0].planes_gather(src, C, idx, 2, ns)
 
 
 def stack_max_planes(stack, pl, rows, group, cache):
@@ -258,11 +286,8 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
             # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue
             if getattr(self, "_chain_of", None) is not stack:                       # new pack -> new stream
                 self._chain_of, self._chain_cache = stack, {}
-            if chain4_fits(stack):                                                  # :73-91 in one kernel
-                return new_xyz, stack_max_gather(stack, feats, xyz, idx, self._chain_cache).view(B, self.npoint, -1)
-            pl, rows = group_planes(feats, xyz, idx)                                # :73-83 features first, xyz last, not centred
-            out = stack_max_planes(stack, pl, rows, self.nsample, self._chain_cache)            # :90-91 Conv-BN-ReLU stack, max
-            return new_xyz, out.view(B, self.npoint, -1)
+            # :73-91 gather (features first, xyz last, not centred) inside the first kernel, max over nsample in the last
+            return new_xyz, stack_max_gather(stack, feats, xyz, idx, self._chain_cache).view(B, self.npoint, -1)
         grouped = ops.index_points(xyz, idx)                                        # :81 (not centred)
         x = cat_rows([ops.index_points(feats, idx), grouped] if feats is not None else [grouped])   # :83 features first, xyz last
         for layer in stack:

@@ -189,6 +189,12 @@ def test_planes_layers_ragged_shapes():
         g = np.concatenate(([feats[bi, j]] if C else []) + [xyz[bi, j]], axis=-1).astype(np.float64)       # (B,Mq,ns,C+3)
         want = np.maximum(g @ W.T + b, 0).max(axis=2).reshape(B * Mq, -1)
         np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5, err_msg=str((ns, C)))
+        # the same through the gathering form of the layer kernel (and of a two-layer stack): bit-identical
+        f_, z_, i_ = torch.from_numpy(feats).cuda() if C else None, torch.from_numpy(xyz).cuda(), torch.from_numpy(idx).cuda()
+        assert np.array_equal(families.stack_max_gather([lyr], f_, z_, i_, {}).cpu().numpy(), got)
+        l2, _, _ = layer(33, 70, True)
+        two = families.stack_max_gather([lyr, l2], f_, z_, i_, {}).cpu().numpy()
+        assert np.array_equal(two, l2.planes(lyr.planes(pl, rows, 0), rows, 2, ns).cpu().numpy())
 
 
 @pytest.mark.gpu
