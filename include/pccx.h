@@ -288,6 +288,10 @@ PCCX_API int pccx_linear_b3(const float *x, int M, int K, int ldx, const float *
 PCCX_API size_t pccx_planes_floats(int64_t M, int K);
 PCCX_API int pccx_group_planes(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
                                int64_t rows_per_batch, int64_t n_src, float *planes, void *stream);
+/* torch.cat([a, b.unsqueeze(1).repeat(1, P, 1)], -1) written directly as planes (FoldingNet's inputs, PPPF_AE.py:99-106): row r =
+ * the C0 channels of f0 row (mod0 > 0 ? r % mod0 : r) then the C1 channels of f1 row r / div1. */
+PCCX_API int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
+                              float *planes, void *stream);
 PCCX_API size_t pccx_planes_gemm_weight_floats(int N, int K);
 PCCX_API int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream);
 PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,

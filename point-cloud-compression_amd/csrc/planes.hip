@@ -39,7 +39,7 @@ extern "C" size_t pccx_planes_floats(int64_t M, int K)
 __global__ __launch_bounds__(256) void group_planes_kernel(const float *__restrict__ f0, int C0, int ld0, const float *__restrict__ f1,
                                                            int C1, int ld1, const int64_t *__restrict__ idx, long long M,
                                                            long long rows_per_batch, long long n_src, int KT32, long long ntiles,
-                                                           uint4 *__restrict__ planes)
+                                                           uint4 *__restrict__ planes, long long mod0, long long div1)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void group_planes_kernel(const float *__restri
         const long long j = idx[r];
         s = (r / rows_per_batch) * n_src + (j < 0 ? 0 : j);
     }
-    const float *p0 = f0 ? f0 + (size_t)s * ld0 : nullptr;
-    const float *p1 = f1 ? f1 + (size_t)s * ld1 : nullptr;
+    // without indices the two sources may be rows of different tables: f0 row r % mod0 (mod0 > 0), f1 row r / div1
+    const float *p0 = f0 ? f0 + (size_t)(mod0 > 0 ? s % mod0 : s) * ld0 : nullptr;
+    const float *p1 = f1 ? f1 + (size_t)(s / div1) * ld1 : nullptr;
     const bool vec0 = p0 && (ld0 % 4 == 0) && ((uintptr_t)f0 % 16 == 0);
     const int C = C0 + C1;
     for (int t = 0; t < KT32; ++t) {
@@ -90,7 +91,25 @@ extern "C" int pccx_group_planes(const float *f0, int C0, int ld0, const float *
     PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_group_planes: M too large");
     hipLaunchKernelGGL(group_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, C0 ? f0 : nullptr, C0,
                        ld0, C1 ? f1 : nullptr, C1, ld1, idx, (long long)M, (long long)(idx ? rows_per_batch : 1),
-                       (long long)(idx ? n_src : 1), pg_kt32(C0 + C1), ntiles, (uint4 *)planes);
+                       (long long)(idx ? n_src : 1), pg_kt32(C0 + C1), ntiles, (uint4 *)planes, 0LL, 1LL);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// torch.cat([a, b.unsqueeze(1).repeat(1, P, 1)], -1) as planes (the inputs of FoldingNet's two stacks, PPPF_AE.py:99-106): row r has
+// the C0 channels of f0 row (mod0 > 0 ? r % mod0 : r) followed by the C1 channels of f1 row r / div1.  Nothing is concatenated or
+// repeated in memory.
+extern "C" int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
+                                float *planes, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(planes && f0 && f1 && M > 0, "pccx_fold_planes: null pointer or negative M");
+    PCCX_CHECK_ARG(C0 >= 1 && C1 >= 1 && ld0 >= C0 && ld1 >= C1 && mod0 >= 0 && div1 >= 1, "pccx_fold_planes: bad arguments");
+    const long long ntiles = (M + 15) / 16;
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_fold_planes: M too large");
+    hipLaunchKernelGGL(group_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f0, C0, ld0, f1, C1, ld1,
+                       (const int64_t *)nullptr, (long long)M, 1LL, 1LL, pg_kt32(C0 + C1), ntiles, (uint4 *)planes, (long long)mod0,
+                       (long long)div1);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

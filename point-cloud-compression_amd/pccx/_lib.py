@@ -67,6 +67,7 @@ _SIGNATURES = {
     "pccx_group_max": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_planes_floats": [C.c_int64, C.c_int],
     "pccx_group_planes": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P],
+    "pccx_fold_planes": [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, _P],
     "pccx_planes_gemm_weight_floats": [C.c_int, C.c_int],
     "pccx_pack_planes_gemm": [_P, C.c_int, C.c_int, _P, _P],
     "pccx_planes_gemm": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],

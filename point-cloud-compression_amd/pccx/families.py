@@ -205,14 +205,27 @@ def stack_max_planes(stack, pl, rows, group, cache):
     return stack[-1].planes(pl, rows, 2, group)
 
 
+def fold_planes(a, mod0, b, div1, M):
+    """torch.cat([a rows, b rows repeated], -1) as planes without building it: row r = a[r % mod0 if mod0 else r] ++ b[r // div1]
+    (PPPF_AE.py:99-106).  a (.., C0), b (.., C1) fp32 rows."""
+    a, b = a.contiguous(), b.contiguous()
+    C0, C1 = int(a.shape[-1]), int(b.shape[-1])
+    out = torch.empty(_lib.load().pccx_planes_floats(M, C0 + C1), device=a.device, dtype=torch.float32)
+    _lib.call("pccx_fold_planes", a.data_ptr(), C0, C0, mod0, b.data_ptr(), C1, C1, div1, M, out.data_ptr(), _stream())
+    return out
+
+
+def run_stack_planes(stack, pl, M):
+    """A Conv/Linear stack on an input given as planes -> fp32 rows (M, N_last)."""
+    for layer in stack[:-1]:
+        pl = layer.planes(pl, M, 0)
+    return stack[-1].planes(pl, M, 1)
+
+
 def run_stack(stack, x):
     """A Conv/Linear stack on fp32 rows x (M, K): layer by layer on rows (f32), or through planes (bf16x3)."""
     if stack and stack[0].mode() == "bf16x3" and x.shape[0] > 0:
-        M = x.shape[0]
-        pl = rows_planes(x)
-        for layer in stack[:-1]:
-            pl = layer.planes(pl, M, 0)
-        return stack[-1].planes(pl, M, 1)
+        return run_stack_planes(stack, rows_planes(x), x.shape[0])
     for layer in stack:
         x = layer(x)
     return x
@@ -351,6 +364,12 @@ class PPPF_AE(_Packable):
         q = round_(pk["enc"](latent))                                               # :139-142
         lat_dec = pk["dec"](q)                                                      # :145
         P = self.decoder.num_points
+        if pk["mlp1"][0].mode() == "bf16x3" and B > 0:
+            # the folding inputs [grid | latent] and [coarse | latent] (:99-106) go straight to operand planes: nothing is
+            # concatenated or repeated in memory
+            x = run_stack_planes(pk["mlp1"], fold_planes(pk["grid"], P, lat_dec, P, B * P), B * P)          # :104 coarse
+            x = run_stack_planes(pk["mlp2"], fold_planes(x, 0, lat_dec, P, B * P), B * P)                   # :107 fine
+            return x.view(B, P, 3), latent, q
         rep = lat_dec[:, None, :].expand(B, P, self.dim)
         x = cat_rows([pk["grid"][None].expand(B, P, 2), rep])                                             # :99-101
         x = run_stack(pk["mlp1"], x)                                                # :104 coarse

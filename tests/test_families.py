@@ -167,6 +167,15 @@ def test_planes_layers_ragged_shapes():
         if relu:
             want = np.maximum(want, 0)
         np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5, err_msg=str((M, K, N)))
+    # [a | b repeated] straight to planes (PPPF_AE.py:99-106) == the concatenated rows converted
+    a, b2 = rng.standard_normal((10, 2)).astype(np.float32), rng.standard_normal((7, 37)).astype(np.float32)
+    cat = np.concatenate([np.tile(a, (7, 1)), np.repeat(b2, 10, axis=0)], axis=1)
+    got = families.fold_planes(torch.from_numpy(a).cuda(), 10, torch.from_numpy(b2).cuda(), 10, 70)
+    assert torch.equal(got, families.rows_planes(torch.from_numpy(cat).cuda()))
+    a3 = rng.standard_normal((70, 3)).astype(np.float32)
+    cat = np.concatenate([a3, np.repeat(b2, 10, axis=0)], axis=1)
+    got = families.fold_planes(torch.from_numpy(a3).cuda(), 0, torch.from_numpy(b2).cuda(), 10, 70)
+    assert torch.equal(got, families.rows_planes(torch.from_numpy(cat).cuda()))
     # chain of two layers through planes (odd number of 16-channel tiles in the middle: 48 channels)
     l0, W0, b0 = layer(48, 35, True)
     l1, W1, b1 = layer(40, 48, False)
