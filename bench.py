@@ -420,23 +420,22 @@ def bench_s3dis(args, rk):
     keep = {}
 
     def step(i):
-        for ri, pc in enumerate(rooms):
-            parts, nb, order, n_last = large.compress_large(cd, pc, seed=11, rank=rk.rank, world=rk.world, batch=args.batch)
-            keep[ri] = (parts, large.decompress_large(cd, parts, nb, order, pc.shape[0]))
+        # the blocks of all rooms in common batches (large.compress_large_many): full launches instead of one short one per room
+        parts, metas = large.compress_large_many(cd, rooms, seed=11, rank=rk.rank, world=rk.world, batch=args.batch)
+        keep["parts"], keep["metas"] = parts, metas
+        keep["out"] = large.decompress_large_many(cd, parts, metas)
     for _ in range(args.warmup):
         step(0)
     dt = timed(rk, step, args.steps, torch.cuda.synchronize)
     # quality, outside the timed region: bits of this rank's blocks and their block-level D1 (a block's decoded rows are a set;
     # with world > 1 a rank holds only its own blocks' rows, so the per-room D1 is replaced by the mean over blocks)
     bits = psnr_sum = blocks = pts = 0.0
-    for ri, pc in enumerate(rooms):
-        parts, _ = keep[ri]
-        blk, _, _ = large.split_blocks(pc)
-        for ids, c in parts:
-            bits += float(c.bits().sum())
-            psnr_sum += float(codec.d1_psnr(blk[ids], cd.decompress(c)).sum())
-            blocks += len(ids)
-            pts += len(ids) * blk.shape[1]
+    flat = torch.cat([large.split_blocks(pc)[0] for pc in rooms])
+    for ids, c in keep["parts"]:
+        bits += float(c.bits().sum())
+        psnr_sum += float(codec.d1_psnr(flat[ids], cd.decompress(c)).sum())
+        blocks += len(ids)
+        pts += len(ids) * flat.shape[1]
     summ = rk.summaries([bits, pts, psnr_sum, 0.0, blocks, dt])
     if rk.rank == 0:
         print(json.dumps({

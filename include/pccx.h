@@ -62,6 +62,9 @@ PCCX_API int pccx_fps(const float *xyz, int B, int N, int npoint, const int32_t 
  * xyz: (n,3) f32; keys: (n) int64. */
 PCCX_API int pccx_morton_keys(const float *xyz, int64_t n, const float *lo_host, float extent, int64_t *keys,
                               void *stream);
+/* The same keys over the cloud's own bounding box, found on the device (bbox_workspace: 6 int32 on the device, scratch): no
+ * host round trip, so the block partition of a large cloud can be queued without a synchronisation. */
+PCCX_API int pccx_morton_keys_auto(const float *xyz, int64_t n, int64_t *keys, int32_t *bbox_workspace, void *stream);
 
 /* pn_kit.index_points (pn_kit.py:332-360) / pytorch3d knn_gather (pointnet_sa_module.py:28):
  * out[b,m,:] = points[b, idx[b,m], :].  points: (B,N,C); idx: (B,M) int64 (negative -> row 0,

@@ -430,6 +430,74 @@ __global__ void morton_keys_kernel(const float *__restrict__ xyz, long long n, f
     }
 }
 
+// The same keys with the bounding box found on the device (no host round trip): ordered-int atomics into bbox[0..5]
+// (min x, y, z, max x, y, z), then lo = min, extent = max over the axes of (max - min) in fp32, exactly what the host path passes.
+__device__ __forceinline__ int pccx_ordered_int(float f)
+{
+    const int b = __float_as_int(f);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float pccx_ordered_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+__global__ void bbox_init_kernel(int *__restrict__ bbox)
+{
+    if (threadIdx.x < 3) bbox[threadIdx.x] = 0x7fffffff;
+    else if (threadIdx.x < 6) bbox[threadIdx.x] = (int)0x80000000;
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float *__restrict__ xyz, long long n, int *__restrict__ bbox)
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * i + a];
+            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(bbox + a, pccx_ordered_int(lo[a]));
+            atomicMax(bbox + 3 + a, pccx_ordered_int(hi[a]));
+        }
+    }
+}
+
+__global__ void morton_keys_auto_kernel(const float *__restrict__ xyz, long long n, const int *__restrict__ bbox,
+                                        int64_t *__restrict__ keys)
+{
+    const float lox = pccx_ordered_float(bbox[0]), loy = pccx_ordered_float(bbox[1]), loz = pccx_ordered_float(bbox[2]);
+    float ext = fmaxf(fmaxf(__fsub_rn(pccx_ordered_float(bbox[3]), lox), __fsub_rn(pccx_ordered_float(bbox[4]), loy)),
+                      __fsub_rn(pccx_ordered_float(bbox[5]), loz));
+    ext = fmaxf(ext, 1e-30f);
+    const float inv = __fdiv_rn(2097151.f, ext);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float fx = fminf(fmaxf((xyz[3 * i] - lox) * inv, 0.f), 2097151.f);
+        const float fy = fminf(fmaxf((xyz[3 * i + 1] - loy) * inv, 0.f), 2097151.f);
+        const float fz = fminf(fmaxf((xyz[3 * i + 2] - loz) * inv, 0.f), 2097151.f);
+        keys[i] = (int64_t)((spread3_21((unsigned)fx) << 2) | (spread3_21((unsigned)fy) << 1) | spread3_21((unsigned)fz));
+    }
+}
+
+extern "C" int pccx_morton_keys_auto(const float *xyz, int64_t n, int64_t *keys, int32_t *bbox_workspace, void *stream)
+{
+    if (n == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(xyz && keys && bbox_workspace && n > 0, "pccx_morton_keys_auto: bad arguments");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bbox_workspace);
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz, (long long)n, bbox_workspace);
+    hipLaunchKernelGGL(morton_keys_auto_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xyz, (long long)n, bbox_workspace, keys);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 extern "C" int pccx_morton_keys(const float *xyz, int64_t n, const float *lo_host, float extent, int64_t *keys, void *stream)
 {
     if (n == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null

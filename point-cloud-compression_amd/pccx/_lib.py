@@ -18,6 +18,7 @@ _SIGNATURES = {
     "pccx_denormalize": [_P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P],
     "pccx_fps": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],
     "pccx_morton_keys": [_P, C.c_int64, _P, C.c_float, _P, _P],
+    "pccx_morton_keys_auto": [_P, C.c_int64, _P, _P, _P],
     "pccx_gather": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_knn": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P],
     "pccx_ball_query": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P],

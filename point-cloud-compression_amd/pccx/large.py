@@ -19,6 +19,16 @@ from .ops import _f32c, _stream
 def morton_keys(pc):
     """pc (N,3) f32 on the GPU -> (N,) int64 keys over pc's bounding box."""
     pc = _f32c(pc, "morton_keys")
+    keys = torch.empty(pc.shape[0], device=pc.device, dtype=torch.int64)
+    bbox = torch.empty(6, device=pc.device, dtype=torch.int32)
+    _lib.call("pccx_morton_keys_auto", pc.data_ptr(), pc.shape[0], keys.data_ptr(), bbox.data_ptr(), _stream())   # bounding box on the device
+    return keys
+
+
+def morton_keys_host_bbox(pc):
+    """The same keys with the bounding box reduced by torch and passed from the host (pccx_morton_keys): the definition
+    morton_keys() is tested against."""
+    pc = _f32c(pc, "morton_keys")
     lo = pc.amin(dim=0).cpu().numpy().astype(np.float32)
     ext = float((pc.amax(dim=0).cpu().numpy() - lo).max())
     keys = torch.empty(pc.shape[0], device=pc.device, dtype=torch.int64)
@@ -81,3 +91,45 @@ def decompress_large(codec, parts, n_blocks, order, n_points, block=8192, out=No
             raise ValueError(f"decoded blocks have {rec.shape[1]} points, expected {block} (S*k must equal the block size)")
         unsplit_blocks(rec, ids, order, n_points, block, out)
     return out
+
+
+def compress_large_many(codec, clouds, seed=11, rank=0, world=1, block=8192, batch=256):
+    """Several large clouds at once: every cloud is cut as compress_large cuts it, but the blocks of ALL clouds form one
+    sequence (global block g = blocks of cloud 0, then cloud 1, ...) that is sharded g mod world and compressed in batches of
+    ``batch`` blocks regardless of cloud boundaries -- full launches instead of one short launch per room.  A block's FPS start
+    index is dist.fps_start_index(seed + cloud, block-in-cloud, block), i.e. what compress_large(seed=seed + cloud) would draw, so a
+    block's files do not depend on how the clouds were batched.  Returns (parts, metas): parts = list of (global block ids,
+    Compressed batch), metas = per cloud (first global block, number of blocks, order, n_points)."""
+    from . import dist
+    metas, all_blocks, first = [], [], 0
+    for pc in clouds:
+        blocks, order, _ = split_blocks(pc, block)
+        metas.append((first, int(blocks.shape[0]), order, int(pc.shape[0])))
+        all_blocks.append(blocks)
+        first += int(blocks.shape[0])
+    flat = torch.cat(all_blocks) if all_blocks else torch.empty(0, block, 3)
+    where = [(ci, j) for ci, (_, nb, _, _) in enumerate(metas) for j in range(nb)]
+    mine = dist.shard_indices(first, rank, world)
+    parts = []
+    for i in range(0, len(mine), batch):
+        ids = mine[i:i + batch]
+        starts = [dist.fps_start_index(seed + where[g][0], where[g][1], block) for g in ids]
+        parts.append((ids, codec.compress(flat[ids], starts)))
+    return parts, metas
+
+
+def decompress_large_many(codec, parts, metas, block=8192, outs=None, S=64):
+    """Decode compress_large_many's batches and put every block back into its cloud (unsplit_blocks).  Returns the list of clouds;
+    with world > 1 a rank fills the rows of its own blocks only."""
+    if outs is None:
+        dev = parts[0][1].s_bytes.device if parts else "cuda"
+        outs = [torch.zeros(n, 3, device=dev, dtype=torch.float32) for (_, _, _, n) in metas]
+    for ids, comp in parts:
+        rec = codec.decompress(comp, S=S)
+        if rec.shape[1] != block:
+            raise ValueError(f"decoded blocks have {rec.shape[1]} points, expected {block} (S*k must equal the block size)")
+        for ci, (first, nb, order, n) in enumerate(metas):
+            sel = [slot for slot, g in enumerate(ids) if first <= g < first + nb]
+            if sel:
+                unsplit_blocks(rec[sel], [ids[slot] - first for slot in sel], order, n, block, outs[ci])
+    return outs

@@ -212,6 +212,7 @@ def test_large_cloud_block_partition_and_sharding(nets):
     nb = (N + 8191) // 8192
     assert blocks.shape == (nb, 8192, 3) and n_last == N - (nb - 1) * 8192
     assert torch.equal(torch.sort(order).values, torch.arange(N, device=pc.device))        # a permutation
+    assert torch.equal(large.morton_keys(pc), large.morton_keys_host_bbox(pc))              # bounding box on the device == by torch
     assert torch.equal(blocks.view(-1, 3)[:N], pc[order])
     ext = (blocks.amax(1) - blocks.amin(1)).amax(1)
     assert float(ext.median()) < 0.6 * float((pc.amax(0) - pc.amin(0)).max())            # compact blocks
@@ -224,6 +225,38 @@ def test_large_cloud_block_partition_and_sharding(nets):
             assert out.shape == (len(ids), 64 * k, 3) and torch.isfinite(out).all()
             seen += ids
     assert sorted(seen) == list(range(nb))
+
+
+def test_several_large_clouds_batched_across_cloud_boundaries(nets):
+    """compress_large_many: the blocks of several clouds in common batches.  Every block's three files equal those of
+    compress_large on its own cloud (seed + cloud index), whatever the batching and the 2-way sharding; the decoded clouds
+    equal decompress_large's."""
+    from pccx import large
+    ae, prob, _, _ = nets
+    rng = np.random.default_rng(7)
+    clouds = [torch.from_numpy((rng.random((n, 3)) * np.float32(s_)).astype(np.float32)).cuda() for n, s_ in ((20000, 3.0), (9000, 1.0), (30001, 5.0))]
+    cd = codec.Codec(ae, prob, K=K, octree_mode="reference")
+    want_files, want_out = {}, []
+    for ci, pc in enumerate(clouds):
+        parts, nb, order, _ = large.compress_large(cd, pc, seed=11 + ci, batch=3)
+        for ids, comp in parts:
+            for slot, j in enumerate(ids):
+                want_files[(ci, j)] = comp.files(slot)
+        want_out.append(large.decompress_large(cd, parts, nb, order, pc.shape[0]))
+    got_files = {}
+    outs = None
+    for rank in range(2):
+        parts, metas = large.compress_large_many(cd, clouds, seed=11, rank=rank, world=2, batch=4)
+        for ids, comp in parts:
+            for slot, g in enumerate(ids):
+                ci = max(c for c, m in enumerate(metas) if m[0] <= g)
+                got_files[(ci, g - metas[ci][0])] = comp.files(slot)
+        outs = large.decompress_large_many(cd, parts, metas, outs=outs)
+    assert got_files.keys() == want_files.keys()
+    for key in want_files:
+        assert got_files[key] == want_files[key], key
+    for a, b in zip(outs, want_out):
+        assert torch.equal(a, b)
 
 
 def test_room_scale_cloud_blocks_round_trip_and_block_oracle_parity(nets):
