@@ -609,13 +609,14 @@ extern "C" int pccx_ball_query_grid(const float *q, int B, int M, const float *r
 // work is VALU-bound (8 flops/pair).
 // ------------------------------------------------------------------------------------------
 #define NND_TILE 1024
-#define NND_XPT 4
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Two reference points per step: the three differences, squares and the two adds run as packed fp32
 // (v_pk_add_f32 / v_pk_mul_f32, no contraction: the file is built with -ffp-contract=off), the same
 // operation sequence per pair as pccx_sqdist.  Without the argmin the update is one v_min3_f32.
-template <bool WANT_NN>
+// XPT queries per thread: 4 (1024 per workgroup) for the evaluation batches; 1 when the batch is too small to fill the chip that way
+// (the training step's 4 clouds: 32 workgroups become 128).  A query's scan over Y is the same sequence either way.
+template <bool WANT_NN, int XPT>
 __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, int Q,
                                                       float *__restrict__ d2, int32_t *__restrict__ nn)
 {
@@ -623,11 +624,11 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
     const int b = blockIdx.y, tid = threadIdx.x;
     const float *xp = X + (size_t)b * P * 3;
     const float *yp = Y + (size_t)b * Q * 3;
-    float x[NND_XPT][3], best[NND_XPT];
-    int bi[NND_XPT];
+    float x[XPT][3], best[XPT];
+    int bi[XPT];
 #pragma unroll
-    for (int j = 0; j < NND_XPT; ++j) {
-        int i = blockIdx.x * (256 * NND_XPT) + j * 256 + tid;
+    for (int j = 0; j < XPT; ++j) {
+        int i = blockIdx.x * (256 * XPT) + j * 256 + tid;
         int ii = i < P ? i : P - 1;
         x[j][0] = xp[3 * ii]; x[j][1] = xp[3 * ii + 1]; x[j][2] = xp[3 * ii + 2];
         best[j] = INFINITY; bi[j] = -1;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
         for (int t = 0; t < cnt2; t += 2) {
             const f32x2 yx = *(const f32x2 *)&tyx[t], yy = *(const f32x2 *)&tyy[t], yz = *(const f32x2 *)&tyz[t];
 #pragma unroll
-            for (int j = 0; j < NND_XPT; ++j) {
+            for (int j = 0; j < XPT; ++j) {
                 const f32x2 dx = x[j][0] - yx, dy = x[j][1] - yy, dz = x[j][2] - yz;
                 f32x2 d = dx * dx;
                 d = d + dy * dy;
@@ -658,8 +659,8 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
         }
     }
 #pragma unroll
-    for (int j = 0; j < NND_XPT; ++j) {
-        int i = blockIdx.x * (256 * NND_XPT) + j * 256 + tid;
+    for (int j = 0; j < XPT; ++j) {
+        int i = blockIdx.x * (256 * XPT) + j * 256 + tid;
         if (i < P) {
             d2[(size_t)b * P + i] = best[j];
             if (WANT_NN) nn[(size_t)b * P + i] = bi[j];
@@ -673,11 +674,17 @@ extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q,
     PCCX_CHECK_ARG(X && Y && d2, "pccx_nn_dist: null pointer");
     PCCX_CHECK_ARG(B >= 0 && P >= 1 && Q >= 1, "pccx_nn_dist: bad shape");
     PCCX_CHECK_ARG(B <= 65535, "pccx_nn_dist: B=%d > 65535 unsupported", B);
-    int gx = (P + 256 * NND_XPT - 1) / (256 * NND_XPT);
-    if (nn)
-        hipLaunchKernelGGL(nn_dist_kernel<true>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
-    else
-        hipLaunchKernelGGL(nn_dist_kernel<false>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, d2, nn);
+    const bool small = (long long)B * ((P + 1023) / 1024) < 512;
+    const int xpt = small ? 1 : 4;
+    const int gx = (P + 256 * xpt - 1) / (256 * xpt);
+    hipStream_t st = (hipStream_t)stream;
+    if (nn) {
+        if (small) hipLaunchKernelGGL((nn_dist_kernel<true, 1>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
+        else hipLaunchKernelGGL((nn_dist_kernel<true, 4>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
+    } else {
+        if (small) hipLaunchKernelGGL((nn_dist_kernel<false, 1>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
+        else hipLaunchKernelGGL((nn_dist_kernel<false, 4>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
+    }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
