@@ -151,7 +151,7 @@ def cpu_baseline(max_clouds, budget_s):
             per.append((8 * (len(o["s"]) + len(o["p"]) + len(o["c"])), ref_pipeline.d1_psnr(pc, rec)))   # eval.py:189; outside the windows
             n += 1
         bits, psnr = sum(p[0] for p in per), sum(p[1] for p in per)
-        same = per[:32] if n >= 32 else None       # the GPU leg's 32 distinct clouds are exactly seeds 11..42 with these FPS starts
+        same = per[:32] if n >= 32 else None       # the GPU leg's 32 base shapes are exactly seeds 11..42 with these FPS starts
         q32 = {"bpp": sum(p[0] for p in same) / (32 * N_POINTS), "d1_psnr_db": sum(p[1] for p in same) / 32} if same else None
         return n, tot, bits / (n * N_POINTS), psnr / n, q32
 
@@ -162,7 +162,7 @@ def cpu_baseline(max_clouds, budget_s):
             "sample": f"{n} synthetic 8192-pt clouds (the first {n} of the GPU leg's seeds), compress+decompress windows of "
                       f"compress.py:85-154 / decompress.py:77-118, CPU restatement of the reference loop (torch CPU fp32 + C oracle)",
             "ms_per_cloud": 1e3 * tot / n, "bpp": bpp, "d1_psnr_db": psnr,
-            "same_clouds_as_gpu": q32,      # bpp / D1-PSNR on the first 32 clouds = the 32 distinct clouds of the GPU leg at N = 1
+            "same_clouds_as_gpu": q32,      # bpp / D1-PSNR on the first 32 clouds = the 32 base shapes of the GPU leg at N = 1 (its "base_shapes")
             "one_thread": {"value": n1 * N_POINTS / tot1, "unit": "points/s", "cores": 1, "sample": f"{n1} clouds", "ms_per_cloud": 1e3 * tot1 / n1}}
 
 
@@ -277,6 +277,13 @@ def bench_ipdae(args, rk):
     # shard by file: global cloud i -> rank i % world; 32 distinct shapes per rank, tiled to the batch
     base = np.stack([synth.cad_cloud(11 + rk.rank + rk.world * i, N_POINTS) for i in range(min(B, 32))])
     clouds = torch.from_numpy(np.concatenate([base] * ((B + base.shape[0] - 1) // base.shape[0]))[:B]).to(dev)
+    # every cloud of the batch distinct: copy c of the 32 shapes is turned by c * 2 pi / 37 about the vertical axis through the
+    # cube's centre and scaled by 1 - c / 256 (the first 32 stay as generated: the CPU leg's clouds)
+    cidx = torch.arange(B, device=dev) // base.shape[0]
+    ang = cidx.to(torch.float32) * (2.0 * 3.141592653589793 / 37.0)
+    ca, sa_, sc = torch.cos(ang)[:, None], torch.sin(ang)[:, None], (1.0 - cidx.to(torch.float32) / 256.0)[:, None]
+    x0, y0 = clouds[..., 0] - 0.5, clouds[..., 1] - 0.5
+    clouds = torch.stack([(ca * x0 - sa_ * y0) * sc + 0.5, (sa_ * x0 + ca * y0) * sc + 0.5, (clouds[..., 2] - 0.5) * sc + 0.5], dim=-1).contiguous()
     starts = torch.from_numpy((np.arange(B) * 97 + rk.rank) % N_POINTS).to(dev)
     P = B * S_PATCH
     sync = torch.cuda.synchronize
@@ -302,6 +309,9 @@ def bench_ipdae(args, rk):
         stages = {k: (ms / n, n) for k, (ms, n) in timer.totals_ms().items()}
         r = {"dt_res": dt_res, "stages": stages, "bits": float(comp.bits().sum()), "psnr_sum": float(codec.d1_psnr(clouds, out).sum()),
              "chamfer_sum": float(codec.normalized_chamfer(clouds, out).sum())}
+        nb_ = min(B, int(base.shape[0]))            # the unturned base shapes = the CPU leg's first clouds (cpu_baseline.same_clouds_as_gpu)
+        r["base_shapes"] = {"clouds": nb_, "bpp": float(comp.bits()[:nb_].sum()) / (nb_ * N_POINTS),
+                            "d1_psnr_db": float(codec.d1_psnr(clouds[:nb_], out[:nb_]).sum()) / nb_}
 
         # ---- host-to-host leg (the reference's window): two streams, pinned double buffers ---------------------
         if mode == args.matmul:
@@ -379,13 +389,14 @@ def bench_ipdae(args, rk):
             "value_resident": rk.world * pts / main["dt_res"], "ms_per_step_resident": 1e3 * main["dt_res"] / args.steps,
             "host_window_checks": {k: main[k] for k in ("host_equals_resident", "host_bytes_equal_resident", "d2h_bytes_per_step")},
             "config": {"workload": "IPDAE K=256 d=16 L=7, 8192-pt CAD-like synthetic clouds (configs[1])",
-                       "clouds_per_gpu_per_step": B, "distinct_clouds_per_gpu": int(base.shape[0]), "points_per_cloud": N_POINTS,
+                       "clouds_per_gpu_per_step": B, "distinct_clouds_per_gpu": B, "base_shapes_per_gpu": int(base.shape[0]), "points_per_cloud": N_POINTS,
                        "patches_per_cloud": S_PATCH, "octree_mode": args.octree_mode, "sharding": f"file-sharded x{rk.world}",
                        "weights": "seeded random", "matmul": args.matmul},
             "roofline": rf,
             "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
             "mfma_stage_tflops": tfl,
             "bpp": summ["bpp"], "d1_psnr_db": summ["d1_psnr_db"], "chamfer": summ["chamfer"], "summary_files": summ["files"],
+            "base_shapes": main["base_shapes"],
         }
         for mode, r in res_by_mode.items():
             if mode == args.matmul:
