@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256, 2) void dec_head_kernel(const float *__restric
     }
 }
 
+#ifndef DEC_GROUP
 #define DEC_GROUP 64                       // patch blocks per group of the block order (dec_main_kernel)
+#endif
 
 
 // ---- bf16x3 operands: x = hi + mid + lo exactly, each a bf16 (round to nearest even)

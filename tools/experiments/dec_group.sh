@@ -1,0 +1,16 @@
+# Compares decoder block-group sizes (DEC_GROUP of decoder.hip) on the default bench; libraries libpccx_g32.so / libpccx_g16.so
+# must have been built beside libpccx.so (-DDEC_GROUP=32 / 16).  Restores the base library at the end.
+set -o pipefail
+O=$GRAFT_REPO_ROOT/gpurun_out/dg; mkdir -p $O
+L=$GRAFT_REPO_ROOT/point-cloud-compression_amd/pccx/lib
+cp $L/libpccx.so /tmp/base.so
+for v in base g32 g16 base; do
+  if [ $v = base ]; then cp /tmp/base.so $L/libpccx.so; else cp $L/libpccx_$v.so $L/libpccx.so; fi
+  timeout -k 10 200 python3 bench.py --one-mode --cpu-clouds 0 --steps 5 --warmup 2 > $O/$v.json 2> $O/$v.err || { cp /tmp/base.so $L/libpccx.so; exit 1; }
+  python3 - <<PY
+import json
+d=json.loads([l for l in open("$O/$v.json") if l.startswith("{")][-1])
+print("$v", round(d["value"]/1e6,2), d["stage_ms_per_step"]["ae_decode"], flush=True)
+PY
+done
+cp /tmp/base.so $L/libpccx.so
