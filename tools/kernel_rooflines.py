@@ -126,6 +126,41 @@ def main():
     ms = timed(lambda: models.range_decode(cdf, by, nb, L), args.iters)
     rows.append({"kernel": "range_decode", "ms_per_launch": round(ms, 4), "bound": "latency", "achieved": round(B * S * d / ms / 1e6, 2),
                  "unit": "G symbols/s", "note": "serial per cloud: %.0f ns per symbol per stream" % (ms * 1e6 / (S * d))})
+    # ---- the PointNet++ stacks of PPPF_AE (configs[2]) on operand planes (csrc/planes.hip), 2048 patches of 512 points
+    from pccx import families
+    rng = np.random.default_rng(3)
+    PB = 2048
+    pp = torch.from_numpy(rng.random((PB, 512, 3)).astype(np.float32)).to(dev)
+    ms = timed(lambda: ops.sample_farthest_points(pp, 512), args.iters)
+    row("fps one wave per cloud, 512 of 512 points x 2048 patches", ms, "lds", PB * 512 * 512 * 20, "GB/s", HBM_PEAK,
+        "pointnet_sa_module.py:66-68 on K=512 patches: 512 dependent rounds per patch, no workgroup barrier")
+
+    def stack(widths, k0):
+        out, kk = [], k0
+        for nw in widths:
+            W = torch.from_numpy((rng.standard_normal((nw, kk)) / np.sqrt(kk)).astype(np.float32))
+            out.append(families.FoldedLinear(W, torch.zeros(nw), True, matmul="bf16x3"))
+            kk = nw
+        return out
+    for name, k0, widths, npoint, ns, nsrc in (("sa1 3-3-64-64-128, 32 samples", 3, (3, 64, 64, 128), 512, 32, 512),
+                                                ("sa2 131-128-128-128-256, 64 samples", 131, (128, 128, 128, 256), 128, 64, 512)):
+        st = stack(widths, k0)
+        feats = torch.randn(PB, nsrc, k0 - 3, device=dev) if k0 > 3 else None
+        xyz_s = torch.rand(PB, nsrc, 3, device=dev)
+        idx = torch.randint(0, nsrc, (PB, npoint, ns), device=dev)
+        cache = {}
+        ms = timed(lambda: families.stack_max_gather(st, feats, xyz_s, idx, cache), args.iters)
+        fl = 2.0 * PB * npoint * ns * sum(l.N * l.K for l in st)
+        row(f"planes_chain4 (gather inside) {name}", ms, "mfma", fl, "TFLOP/s", round(MFMA_B3_PEAK, 1),
+            "pointnet_sa_module.py:73-91 in one kernel; algorithmic flops of the unpadded layers")
+    M3 = PB * 32 * 128
+    for K_, N_, epi, grp in ((512, 1024, 2, 128), (256, 512, 0, 0), (256, 256, 0, 0)):
+        lyr = stack((N_,), K_)[0]
+        pin = torch.empty(families._lib.load().pccx_planes_floats(M3, K_), device=dev, dtype=torch.float32).normal_()
+        ms = timed(lambda: lyr.planes(pin, M3, epi, grp), args.iters)
+        row(f"planes_gemm {K_}->{N_} on {M3} rows" + (" + max over 128" if epi == 2 else ""), ms, "mfma", 2.0 * M3 * K_ * N_, "TFLOP/s",
+            round(MFMA_B3_PEAK, 1), "sa3 of PPPF_AE.py:32-34; 6 B per activation in" + ("" if epi == 2 else " and out"))
+        del pin
     print(json.dumps({"device": torch.cuda.get_device_name(0), "clouds_per_launch": B, "points_per_cloud": N, "rows": rows}, indent=1))
 
 
