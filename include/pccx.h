@@ -304,6 +304,16 @@ PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const fl
 PCCX_API int pccx_planes_gemm_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
                                      int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
                                      float *out, int ldo, void *stream);
+/* Three wide Conv-BN-ReLU layers (widths 241..256, 241..256, 497..512: the first three of sa3, PPPF_AE.py:32-34) in one kernel, one
+ * 16-row tile per wave, activations in registers, the input rows gathered inside (as pccx_planes_gemm_gather; idx NULL: row r itself);
+ * the output is the operand planes of the layer that follows.  K0 of 8 or 9 blocks of 32 channels (<= 288).  The weight stream is
+ * built by pccx_pack_planes_chain_wide from the three layers' pccx_pack_linear_b3 planes. */
+PCCX_API size_t pccx_planes_chain_wide_weight_floats(int K0);
+PCCX_API int pccx_pack_planes_chain_wide(const float *wp3_l0, const float *wp3_l1, const float *wp3_l2, int K0, int N0, int N1, int N2,
+                                         float *wstream_dev, void *stream);
+PCCX_API int pccx_planes_chain_wide(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                    int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1, const float *b2,
+                                    int N2, float *out_planes, void *stream);
 /* A whole Conv-BN-ReLU x 4 + max-over-nsample stack (pointnet_sa_module.py:90-91) in one kernel, the activations between the layers
  * staying in registers: out (M / group, ldo) from the planes of the gathered input.  wstream = the four layers'
  * pccx_pack_planes_gemm streams back to back; b0..b3 the (folded) biases.  Supported width patterns: (<=32, 33..64, 33..64, 65..128)

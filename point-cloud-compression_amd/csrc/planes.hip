@@ -17,6 +17,7 @@
 //                         max over groups of `group` consecutive rows (torch.max over nsample, pointnet_sa_module.py:91).
 // MFMA-bound for K, N >= 256; narrower layers are bound by the 6 bytes per activation they read and write.
 #include <math.h>
+#include <type_traits>
 
 #include "common.h"
 #include "mfma_chain.h"
@@ -689,4 +690,150 @@ extern "C" int pccx_planes_chain4_gather(const float *src, int ldp, const int64_
     PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_chain4_gather: null indices");
     return planes_chain4_launch(src, idx, rows_per_batch, n_src, ldp, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo,
                                 stream, "pccx_planes_chain4_gather");
+}
+
+// ---- three wide layers in one kernel -----------------------------------------------------------------------------
+// The first three layers of sa3 (PPPF_AE.py:32-34: 259 -> 256 -> 256 -> 512) are too wide for the two-tiles-per-wave chain above
+// (256 channels x 32 rows of accumulators and operand planes do not fit 256 registers), so they run as pn_forward_b3_kernel does:
+// ONE 16-row tile per wave, eight waves per workgroup sharing the weight stream of the three layers through a double-buffered
+// LDS-DMA ring (dense_b3_stream), every activation between the layers in registers; the last layer runs in two passes of 256
+// output channels whose epilogue writes the operand planes of the layer that follows (512 -> 1024 + max: planes_gemm_kernel).
+// The input rows are gathered in the kernel (fp32 source rows of 32 * KT0 floats, zero padded; idx -1 -> row 0).
+#define PW_CHUNK 24
+// a layer = one dense_b3_stream call per K block (the unroller gives up on a whole wide layer in one call)
+template <int KT, class WS>
+__device__ __forceinline__ void pw_layer(const WS &ws, int &f, const bf16x8 (&in)[1][KT][3], f32x4 (&acc)[1][16])
+{
+#pragma clang loop unroll(full)
+    for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 pl[1][1][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pl[0][0][p] = in[0][kt][p];
+        dense_b3_stream<1, 16, 1>(ws, f, pl, acc);
+    }
+}
+template <int KT0>
+__global__ __launch_bounds__(512, 1) void planes_chain_wide_kernel(const uint4 *__restrict__ src, const int64_t *__restrict__ idx,
+                                                                   long long rows_per_batch, long long n_src, int ldp, long long M,
+                                                                   long long ntiles, const float *__restrict__ wstream,
+                                                                   const float *__restrict__ b0, const float *__restrict__ b1,
+                                                                   const float *__restrict__ b2, int N0, int N1, int N2,
+                                                                   uint4 *__restrict__ out)
+{
+    constexpr int FRAGS = (KT0 * 16 + 8 * 16 + 8 * 32) * 3;
+    constexpr int NCH = (FRAGS + PW_CHUNK - 1) / PW_CHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const long long tile = (long long)blockIdx.x * 8 + w;
+    const bool valid = tile < ntiles;                         // an idle wave recomputes the last tile and discards it (barriers inside)
+    const long long tc = valid ? tile : ntiles - 1;
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * PW_CHUNK * 64];
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const WStreamT<PW_CHUNK, 2, 8> ws{wstream, swt, NCH, lane, wu, false};
+    ws.prologue();
+
+    bf16x8 in0[1][KT0][3];
+    {
+        long long r = tc * 16 + n;
+        if (r >= M) r = M - 1;
+        const long long j = idx ? idx[r] : r;
+        const long long s = idx ? (r / rows_per_batch) * n_src + (j < 0 ? 0 : j) : r;
+        const f32x4 *gp = (const f32x4 *)((const float *)src + (size_t)s * ldp + 4 * g);
+#pragma unroll
+        for (int t = 0; t < KT0; ++t) b3_split8(gp[8 * t], gp[8 * t + 4], in0[0][t]);
+    }
+    auto bias16 = [&](f32x4 (&acc)[1][16], const float *b, int N, int m0) {
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * (m0 + mt) + 4 * g + r;
+                acc[0][mt][r] = (b && ch < N) ? b[ch] : 0.f;
+            }
+    };
+    int f = 0;                                                // fragment cursor (constant-folds: the chain is fully unrolled)
+    f32x4 a0[1][16];
+    bias16(a0, b0, N0, 0);
+    pw_layer<KT0>(ws, f, in0, a0);
+    bf16x8 in1[1][8][3];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b3_split8(relu4(a0[0][2 * t]), relu4(a0[0][2 * t + 1]), in1[0][t]);
+    f32x4 a1[1][16];
+    bias16(a1, b1, N1, 0);
+    pw_layer<8>(ws, f, in1, a1);
+    bf16x8 in2[1][8][3];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b3_split8(relu4(a1[0][2 * t]), relu4(a1[0][2 * t + 1]), in2[0][t]);
+#pragma clang loop unroll(full)
+    for (int ps = 0; ps < 2; ++ps) {
+        f32x4 a2[1][16];
+        bias16(a2, b2, N2, 16 * ps);
+        pw_layer<8>(ws, f, in2, a2);
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                bf16x8 pl[3];
+                b3_split8(relu4(a2[0][2 * t]), relu4(a2[0][2 * t + 1]), pl);
+                uint4 *d = out + (((size_t)(8 * ps + t) * ntiles + tile) * 3) * 64 + lane;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+            }
+        }
+    }
+    ws.drain();
+}
+
+// The weight stream of pccx_planes_chain_wide: the three layers' pccx_pack_linear_b3 planes, the third reordered into its two
+// passes of 16 m-tiles, zero padded to whole ring chunks.
+extern "C" size_t pccx_planes_chain_wide_weight_floats(int K0)
+{
+    const size_t frags = (size_t)(pg_kt32(K0 > 0 ? K0 : 1) * 16 + 8 * 16 + 8 * 32) * 3;
+    return (frags + PW_CHUNK - 1) / PW_CHUNK * PW_CHUNK * 256;
+}
+
+extern "C" int pccx_pack_planes_chain_wide(const float *wp3_l0, const float *wp3_l1, const float *wp3_l2, int K0, int N0, int N1, int N2,
+                                           float *wstream_dev, void *stream)
+{
+    PCCX_CHECK_ARG(wp3_l0 && wp3_l1 && wp3_l2 && wstream_dev, "pccx_pack_planes_chain_wide: null pointer");
+    PCCX_CHECK_ARG(K0 >= 1 && N0 > 240 && N0 <= 256 && N1 > 240 && N1 <= 256 && N2 > 496 && N2 <= 512,
+                   "pccx_pack_planes_chain_wide: widths %d %d %d are not (241..256, 241..256, 497..512)", N0, N1, N2);
+    hipStream_t st = (hipStream_t)stream;
+    const int KT0 = pg_kt32(K0);
+    PCCX_CHECK_HIP(hipMemsetAsync(wstream_dev, 0, sizeof(float) * pccx_planes_chain_wide_weight_floats(K0), st));
+    const size_t n0 = (size_t)KT0 * 16 * 3 * 256, n1 = (size_t)8 * 16 * 3 * 256;
+    PCCX_CHECK_HIP(hipMemcpyAsync(wstream_dev, wp3_l0, sizeof(float) * n0, hipMemcpyDeviceToDevice, st));           // [t][16][3] as packed
+    PCCX_CHECK_HIP(hipMemcpyAsync(wstream_dev + n0, wp3_l1, sizeof(float) * n1, hipMemcpyDeviceToDevice, st));
+    const size_t total = (size_t)2 * 8 * 16 * 3 * 64;
+    hipLaunchKernelGGL(planes_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4 *)wp3_l2, 8, 32, 16, 2,
+                       (uint4 *)(wstream_dev + n0 + n1));                                                           // [pass][t][16][3]
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// relu(L2(relu(L1(relu(L0(x)))))) for widths (241..256, 241..256, 497..512) written as the operand planes of the next layer
+// (pccx_planes_floats(M, N2) floats).  x: fp32 source rows of ldp = 32 * ceil(K0 / 32) floats (zero padded, 16-byte aligned), row r
+// of the input = source row (r / rows_per_batch) * n_src + max(idx[r], 0), or row r itself when idx is NULL.  K0 <= 288 (nine K
+// blocks: sa3's 259 channels); other shapes return PCCX_ERR_ARG and the caller runs the layers one by one.
+extern "C" int pccx_planes_chain_wide(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                      int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1, const float *b2,
+                                      int N2, float *out_planes, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(src && wstream && out_planes && M > 0, "pccx_planes_chain_wide: null pointer");
+    const int KT0 = pg_kt32(K0);
+    PCCX_CHECK_ARG(N0 > 240 && N0 <= 256 && N1 > 240 && N1 <= 256 && N2 > 496 && N2 <= 512 && (KT0 == 8 || KT0 == 9),
+                   "pccx_planes_chain_wide: unsupported shape K0=%d widths %d %d %d", K0, N0, N1, N2);
+    PCCX_CHECK_ARG(ldp == 32 * KT0 && (uintptr_t)src % 16 == 0 && (!idx || (rows_per_batch >= 1 && n_src >= 1)),
+                   "pccx_planes_chain_wide: source rows must be 16-byte aligned with a stride of %d floats (got %d)", 32 * KT0, ldp);
+    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
+    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "pccx_planes_chain_wide: M too large");
+    hipStream_t st = (hipStream_t)stream;
+#define PW_LAUNCH(KT_)                                                                                                          \
+    hipLaunchKernelGGL((planes_chain_wide_kernel<KT_>), dim3((unsigned)nblk), dim3(512), 0, st, (const uint4 *)src, idx,           \
+                       (long long)(idx ? rows_per_batch : 1), (long long)(idx ? n_src : 1), ldp, (long long)M, ntiles, wstream, b0, b1, \
+                       b2, N0, N1, N2, (uint4 *)out_planes)
+    if (KT0 == 9) PW_LAUNCH(9); else PW_LAUNCH(8);
+#undef PW_LAUNCH
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
 }

@@ -74,6 +74,9 @@ _SIGNATURES = {
     "pccx_planes_gemm": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_planes_gemm_gather": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
                                 _P],
+    "pccx_planes_chain_wide_weight_floats": [C.c_int],
+    "pccx_pack_planes_chain_wide": [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_planes_chain_wide": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P],
     "pccx_planes_chain4": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_planes_chain4_gather": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
                                   C.c_int, _P, C.c_int, _P],
@@ -101,7 +104,7 @@ _RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_fl
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
              "pccx_packed_linear_floats": C.c_size_t, "pccx_ball_query_grid_workspace_ints": C.c_size_t, "pccx_packed_linear_b3_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t, "pccx_pn_b3_blob_floats": C.c_size_t,
              "pccx_ae_decode_b3_workspace_floats": C.c_size_t, "pccx_planes_floats": C.c_size_t,
-             "pccx_planes_gemm_weight_floats": C.c_size_t}
+             "pccx_planes_gemm_weight_floats": C.c_size_t, "pccx_planes_chain_wide_weight_floats": C.c_size_t}
 
 _lib = None
 

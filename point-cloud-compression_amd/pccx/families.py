@@ -169,6 +169,33 @@ def padded_rows(feats, xyz):
     return src, C
 
 
+def wide3_fits(stack):
+    """The first three layers fit pccx_planes_chain_wide (sa3 of PPPF_AE.py:32-34: widths 241..256, 241..256, 497..512, all ReLU, input
+    of 8 or 9 blocks of 32 channels)."""
+    if len(stack) < 3 or not all(l.relu for l in stack[:3]) or stack[1].K != stack[0].N or stack[2].K != stack[1].N:
+        return False
+    return 240 < stack[0].N <= 256 and 240 < stack[1].N <= 256 and 496 < stack[2].N <= 512 and (stack[0].K + 31) // 32 in (8, 9)
+
+
+def wide3_planes(stack, src, C, idx, cache):
+    """relu(L2(relu(L1(relu(L0(gathered rows)))))) as planes, one kernel (pccx_planes_chain_wide).  src (B, N, ldp) from padded_rows();
+    idx (B, M, ns) int64 or None (then src is (rows, ldp) and every row is its own input)."""
+    if "wide" not in cache:
+        ws = torch.empty(_lib.load().pccx_planes_chain_wide_weight_floats(stack[0].K), device=src.device, dtype=torch.float32)
+        _lib.call("pccx_pack_planes_chain_wide", stack[0]._planes3().data_ptr(), stack[1]._planes3().data_ptr(), stack[2]._planes3().data_ptr(),
+                  stack[0].K, stack[0].N, stack[1].N, stack[2].N, ws.data_ptr(), _stream())
+        cache["wide"] = ws
+    if idx is not None:
+        B, Mq, ns = idx.shape
+        rows, rpb, n_src, ip = B * Mq * ns, Mq * ns, src.shape[1], idx.data_ptr()
+    else:
+        rows, rpb, n_src, ip = src.shape[0], 1, 1, None
+    out = torch.empty(_lib.load().pccx_planes_floats(rows, stack[2].N), device=src.device, dtype=torch.float32)
+    _lib.call("pccx_planes_chain_wide", src.data_ptr(), src.shape[-1], ip, rpb, n_src, rows, C, cache["wide"].data_ptr(),
+              stack[0].b.data_ptr(), stack[0].N, stack[1].b.data_ptr(), stack[1].N, stack[2].b.data_ptr(), stack[2].N, out.data_ptr(), _stream())
+    return out
+
+
 def stack_max_gather(stack, feats, xyz, idx, cache):
     """index_points(feats, idx) ++ index_points(xyz, idx) -> Conv-BN-ReLU x 4 -> max over nsample (pointnet_sa_module.py:73-91) in one
     kernel for the stacks chain4_fits() accepts: the gather happens inside the kernel from the (B, N, C+3) rows zero padded to a
@@ -183,6 +210,9 @@ def stack_max_gather(stack, feats, xyz, idx, cache):
         _lib.call("pccx_planes_chain4_gather", src.data_ptr(), src.shape[2], idx.data_ptr(), Mq * ns, src.shape[1], rows, C, ws.data_ptr(),
                   *a, ns, out.data_ptr(), stack[3].N, _stream())
         return out
+    if len(stack) == 4 and wide3_fits(stack):
+        # three wide layers in one kernel (gather inside), then the last layer with the max in its epilogue
+        return stack[3].planes(wide3_planes(stack, src, C, idx, cache), rows, 2, ns)
     # layer by layer: the first layer gathers, the last reduces
     pl = stack[0].planes_gather(src, C, idx) if len(stack) > 1 else None
     for layer in stack[1:-1]:

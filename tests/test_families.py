@@ -250,3 +250,40 @@ def test_planes_chain4_matches_layer_by_layer_and_float64():
             want = families.stack_max_planes(stack, pl2, rows2, ns, {}).cpu().numpy()
             got2 = families.stack_max_gather(stack, f, z, idx, {}).cpu().numpy()
             assert np.array_equal(got2, want), (K0, widths)
+
+
+@pytest.mark.gpu
+def test_planes_chain_wide_matches_layer_by_layer_and_float64():
+    """pccx_planes_chain_wide (three wide layers in one kernel, one row tile per wave, gather inside) on sa3's shape
+    (PPPF_AE.py:32-34: 259 -> 256 -> 256 -> 512, then 512 -> 1024 + max over 128) and a ragged variant: bit-identical to the same
+    stack run layer by layer through pccx_planes_gemm(_gather), and equal to the float64 stack at the layer tolerance."""
+    from pccx import families
+    rng = np.random.default_rng(12)
+    for C, widths, ns, Bq, Mq, Nsrc in [(256, (256, 256, 512, 1024), 128, 2, 3, 128), (250, (241, 250, 500, 70), 32, 3, 5, 40)]:
+        stack, Ws = [], []
+        k = C + 3
+        for nw in widths:
+            W = rng.standard_normal((nw, k)).astype(np.float32) / np.sqrt(k)
+            b = rng.standard_normal(nw).astype(np.float32) * 0.1
+            stack.append(families.FoldedLinear(torch.from_numpy(W), torch.from_numpy(b), True, matmul="bf16x3"))
+            Ws.append((W.astype(np.float64), b.astype(np.float64)))
+            k = nw
+        assert families.wide3_fits(stack) and not families.chain4_fits(stack)
+        feats = rng.standard_normal((Bq, Nsrc, C)).astype(np.float32)
+        xyz = rng.standard_normal((Bq, Nsrc, 3)).astype(np.float32)
+        idx_np = rng.integers(-1, Nsrc, (Bq, Mq, ns))
+        f, z, idx = torch.from_numpy(feats).cuda(), torch.from_numpy(xyz).cuda(), torch.from_numpy(idx_np).cuda()
+        got = families.stack_max_gather(stack, f, z, idx, {}).cpu().numpy()
+        src, Cc = families.padded_rows(f, z)
+        rows = Bq * Mq * ns
+        pl = stack[0].planes_gather(src, Cc, idx)
+        for layer in stack[1:-1]:
+            pl = layer.planes(pl, rows, 0)
+        ref = stack[-1].planes(pl, rows, 2, ns).cpu().numpy()
+        assert np.array_equal(got, ref), widths
+        j = np.where(idx_np < 0, 0, idx_np)
+        bi = np.arange(Bq)[:, None, None]
+        h = np.concatenate([feats[bi, j], xyz[bi, j]], axis=-1).astype(np.float64)
+        for W, b in Ws:
+            h = np.maximum(h @ W.T + b, 0)
+        np.testing.assert_allclose(got, h.max(axis=2).reshape(Bq * Mq, -1), atol=5e-5, rtol=3e-5)
