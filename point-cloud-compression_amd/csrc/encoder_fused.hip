@@ -42,7 +42,7 @@ __host__ __device__ inline size_t fu_region_bytes()
 }
 __host__ __device__ inline size_t fu_lds_bytes(int K)
 {
-    return (size_t)(FU_W1_FRAGS + FU_W2_FRAGS) * 1024 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32 + fu_region_bytes() + 8 * 16 * 4;
+    return (size_t)(FU_W1_FRAGS + FU_W2_FRAGS) * 1024 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32 + fu_region_bytes() + 8 * 16 * 4 + 32;
 }
 
 __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *__restrict__ x, int npatches, int K, const float *__restrict__ blob,
@@ -61,11 +61,11 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
     f32x4 *swt = (f32x4 *)region;                                       // PointNet weight ring (2 x 24 KiB)
     float *stage_all = (float *)region;                                 // ... or the eight staging blocks
     float (*smax)[16] = (float (*)[16])(region + fu_region_bytes());
+    int *sa_next = (int *)(region + fu_region_bytes() + 8 * 16 * 4);     // [8]: next SetAbstraction unit of pass it
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ntiles = K >> 4;
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    float *stage = stage_all + wu * FU_STAGE_WAVE;
 
     {   // stage the SetAbstraction weights ONCE per workgroup: a workgroup walks patches blockIdx.x, + gridDim.x, ...
         const f32x4 *gw1 = (const f32x4 *)sa3, *gw2 = (const f32x4 *)sa3 + FU_W1_FRAGS * 64;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
   for (size_t P = blockIdx.x; P < (size_t)npatches; P += gridDim.x) {
     const float *xp = x + P * (size_t)K * 3;
     for (int i = tid; i < 3 * K; i += 512) sx[i] = xp[i];
+    if (tid < 8) sa_next[tid] = 0;
     __syncthreads();
 
     // ---- kNN-16 inside the patch (pn_kit.py:190), the selection of sa_forward_kernel with TWO threads per point: thread t and
@@ -175,8 +176,20 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         int g = lane >> 4, n = lane & 15;
         const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
 
-        // ---- SetAbstraction for points p0 .. p0+15, two per iteration (sa_forward_kernel<true>'s body)
-        for (int i0 = p0; i0 < p0 + 16; i0 += 2) {
+        // ---- SetAbstraction for the pass's points, two per unit (sa_forward_kernel<true>'s body).  The units are NOT tied to the
+        // wave that owns the points in the PointNet pass: every wave takes the next unit from a counter in LDS.  With a fixed
+        // eight units per wave the older wave of each SIMD wins the MFMA arbitration, finishes 2.6 units ahead and waits 24 k
+        // cycles at the barrier below while the younger one runs on alone at 42 % of the pipe (phase stamps);
+        // taken from the counter, all waves finish within one unit of each other.  The rows of a unit go to the staging block of
+        // the tile the points belong to, so the hand-over reads the same layout as before -- after a barrier now.
+        const int pass_base = it * 128;
+        const int units = ((K - pass_base < 128 ? K - pass_base : 128) + 1) >> 1;
+        for (;;) {
+            int unit = 0;
+            if (lane0 == 0) unit = atomicAdd(&sa_next[it & 7], 1);
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            if (unit >= units) break;
+            const int i0 = pass_base + 2 * unit;
             f32x4 h0[2][2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -211,17 +224,22 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {         // lane (row g, j = n) holds channel 16*(2g + s2) + n of point i0 + nt
                     const int ch = 16 * (2 * g + s2) + n;
-                    stage[(i0 + nt - p0) * FU_STAGE_STRIDE + ch] = fmaxf(__fadd_rn(mx[s2], sb2[ch]), 0.f);
+                    stage_all[(i0 + nt - pass_base) * FU_STAGE_STRIDE + ch] = fmaxf(__fadd_rn(mx[s2], sb2[ch]), 0.f);
                 }
             }
         }
 
-        // ---- hand-over: the wave's own rows, read back as PointNet's B operand and split into planes
+        __syncthreads();                                  // every row of the pass is staged
+        // ---- hand-over: the rows of this wave's tile, read back as PointNet's B operand and split into planes
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        g = lane >> 4; n = lane & 15;
         bf16x8 i0p[1][5][3];
         {
             f32x4 in[9];
+            const float *stage_t = stage_all + (valid ? p0 - pass_base : 0) * FU_STAGE_STRIDE;   // an idle wave: block 0, discarded
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) in[kt] = *(const f32x4 *)(stage + n * FU_STAGE_STRIDE + 16 * kt + 4 * g);
+            for (int kt = 0; kt < 8; ++kt) in[kt] = *(const f32x4 *)(stage_t + n * FU_STAGE_STRIDE + 16 * kt + 4 * g);
             const int p = p0 + n;
             in[8][0] = g == 0 ? sx[3 * p] : 0.f;          // channels 128,129,130 = x,y,z (g == 0, r = 0..2)
             in[8][1] = g == 0 ? sx[3 * p + 1] : 0.f;

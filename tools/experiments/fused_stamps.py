@@ -35,7 +35,7 @@ for _ in range(reps):
     ae.encode(patches)
 e1.record()
 torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 fn(out, 0)
 v = [int(x) for x in out]
 tot = sum(v[:5])
@@ -43,3 +43,8 @@ names = ["stage patch into LDS", "kNN-16 in the patch", "SetAbstraction + hand-o
 print(f"{v[7]} patches, {e0.elapsed_time(e1) / reps:.2f} ms per launch of {B} clouds (stamped build)")
 for n_, c in zip(names, v[:5]):
     print(f"{n_:30s} {c / v[7]:10.0f} ticks per patch  {100.0 * c / tot:5.1f} %")
+
+if v[6]:
+    print(f"  observed wave took {v[6] / v[7]:.2f} SetAbstraction units per patch (16 = an equal share)")
+    for n_, c in zip(["SetAbstraction units of the observed wave", "wait at the barrier after them", "hand-over", "wait at the barrier before PointNet"], v[8:12]):
+        print(f"  per pass: {n_:45s} {c / (v[7] * 2):9.0f} cycles")
