@@ -477,7 +477,13 @@ def bench_pppf(args, rk):
     model.pack(rk.dev)
     B = args.batch
     clouds = torch.from_numpy(np.stack([synth.cad_cloud(300 + rk.rank + rk.world * i, N) for i in range(min(B, 32))])).to(rk.dev)
-    clouds = clouds.repeat((B + clouds.shape[0] - 1) // clouds.shape[0], 1, 1)[:B].contiguous()
+    nbase = clouds.shape[0]
+    clouds = clouds.repeat((B + nbase - 1) // nbase, 1, 1)[:B].contiguous()
+    # every cloud distinct: copy c of the base shapes is turned by c * 2 pi / 37 about the vertical axis through the cube's centre
+    ang = (torch.arange(B, device=rk.dev) // nbase).to(torch.float32) * (2.0 * 3.141592653589793 / 37.0)
+    ca, sa_ = torch.cos(ang)[:, None], torch.sin(ang)[:, None]
+    x0, y0 = clouds[..., 0] - 0.5, clouds[..., 1] - 0.5
+    clouds = torch.stack([ca * x0 - sa_ * y0 + 0.5, sa_ * x0 + ca * y0 + 0.5, clouds[..., 2]], dim=-1).contiguous()
     cent = ops.index_points(clouds, ops.farthest_point_sample_batch(clouds, S, torch.zeros(B, dtype=torch.int32)))
     patches = ops.knn_points(cent, clouds, Kp, patch_scale=float((N / N0) ** (1 / 3))).knn.view(B * S, Kp, 3).contiguous()
     keep = {}
