@@ -213,6 +213,11 @@ def test_large_cloud_block_partition_and_sharding(nets):
     assert blocks.shape == (nb, 8192, 3) and n_last == N - (nb - 1) * 8192
     assert torch.equal(torch.sort(order).values, torch.arange(N, device=pc.device))        # a permutation
     assert torch.equal(large.morton_keys(pc), large.morton_keys_host_bbox(pc))              # bounding box on the device == by torch
+    flat = pc.clone()
+    flat[:, 2] = -3.25                                                                        # a degenerate axis, negative coordinates
+    assert torch.equal(large.morton_keys(flat), large.morton_keys_host_bbox(flat))
+    dot = torch.full((100, 3), 0.5, device="cuda")                                            # zero extent: the 1e-30 clamp on both paths
+    assert torch.equal(large.morton_keys(dot), large.morton_keys_host_bbox(dot))
     assert torch.equal(blocks.view(-1, 3)[:N], pc[order])
     ext = (blocks.amax(1) - blocks.amin(1)).amax(1)
     assert float(ext.median()) < 0.6 * float((pc.amax(0) - pc.amin(0)).max())            # compact blocks
