@@ -1,0 +1,926 @@
+// EXPERIMENT RECORD (not built): planes.hip with a register-staged weight ring in planes_gemm_kernel (template flag RS, PCCX_PG_RS=1):
+// every wave loads its three 1 KiB pieces of a chunk into registers three chunks ahead and writes them to a two-buffer LDS ring with
+// ds_write_b128 one boundary before use, instead of global_load_lds_dwordx4.  Correct (tests/test_families.py with PCCX_PG_RS=1), 234-240
+// VGPRs, no scratch.  tools/experiments/pg_bench.py, ms per layer, LDS-DMA / register-staged: 512->1024 + max 35.85 / 36.48;
+// 256->256 6.48 / 6.58; 128->128 4.78 / 4.87; 128->256 + max 6.39 / 6.53; 64->128 + max 4.45 / 4.50.  Filling LDS costs the same either
+// way: it is not the DMA instruction as such.  Not kept.
+// planes.hip -- the wide Conv1x1 / Linear stacks of the PointNet++ families (pointnet_sa_module.py:38-93, PPPF_AE.py:64-107)
+// in the bf16x3 arithmetic, with the activations kept between layers as the three bf16 planes of the NEXT layer's MFMA B
+// operand instead of fp32 rows:
+//
+//   planes[t][tile][plane][lane]   (16-byte vectors)   t = K/32 block, tile = 16 consecutive rows (points), lane (g, n):
+//                                  the eight channels 32t + 16h + 4g + r (h = 0,1; r = 0..3) of row 16*tile + n
+//
+// which is both what b3_split8 makes of two adjacent C tiles of a layer's output and what v_mfma_f32_16x16x32_bf16 takes as its
+// B operand, so a layer's epilogue writes the next layer's operand with coalesced 1 KiB stores and nothing is split twice.
+//
+//   group_planes_kernel : gather (ball-query / kNN indices, -1 -> row 0 as pointnet_sa_module.py:27) + concat [features, xyz]
+//                         + split  ->  planes of the first layer; without indices: fp32 rows -> planes.
+//   planes_gemm_kernel  : one layer.  Workgroup = 128 rows x (16*MB) output channels, 4 waves x (2 row tiles x MB m-tiles);
+//                         the weight planes of the m-block stream through a 4-deep LDS-DMA ring shared by the waves, the B
+//                         planes of the wave's two tiles are loaded two k-steps ahead into rotating register sets (the scheme
+//                         of dec_main_kernel<true>, decoder.hip).  Epilogues: planes (bias + ReLU + split), fp32 rows, or the
+//                         max over groups of `group` consecutive rows (torch.max over nsample, pointnet_sa_module.py:91).
+// MFMA-bound for K, N >= 256; narrower layers are bound by the 6 bytes per activation they read and write.
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+#include "mfma_chain.h"
+
+#define PG_CHUNK 12                      // ring chunk: 4 m-tiles x 3 planes (1 KiB fragments)
+#define PG_NB 4                          // ring depth (DMA three chunks ahead)
+
+static inline int pg_kt32(int K) { return ((K + 15) / 16 + 1) / 2; }
+static inline int pg_mb(int N) { return (N + 15) / 16 <= 4 ? 4 : 8; }
+
+extern "C" size_t pccx_planes_floats(int64_t M, int K)
+{
+    const size_t ntiles = (size_t)((M > 0 ? M : 0) + 15) / 16;
+    return (size_t)pg_kt32(K > 0 ? K : 1) * ntiles * 3 * 256;
+}
+
+// ---- gather + concat + split ------------------------------------------------------------------------------------
+// One wave per row tile.  Row r takes source row s = idx ? (r / rows_per_batch) * n_src + max(idx[r], 0) : r; its channels are
+// f0[s][0..C0) followed by f1[s][0..C1).
+__global__ __launch_bounds__(256) void group_planes_kernel(const float *__restrict__ f0, int C0, int ld0, const float *__restrict__ f1,
+                                                           int C1, int ld1, const int64_t *__restrict__ idx, long long M,
+                                                           long long rows_per_batch, long long n_src, int KT32, long long ntiles,
+                                                           uint4 *__restrict__ planes, long long mod0, long long div1)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    long long r = tile * 16 + n;
+    if (r >= M) r = M - 1;                                   // padded rows repeat the last one (never read back as results)
+    long long s = r;
+    if (idx) {
+        const long long j = idx[r];
+        s = (r / rows_per_batch) * n_src + (j < 0 ? 0 : j);
+    }
+    // without indices the two sources may be rows of different tables: f0 row r % mod0 (mod0 > 0), f1 row r / div1
+    const float *p0 = f0 ? f0 + (size_t)(mod0 > 0 ? s % mod0 : s) * ld0 : nullptr;
+    const float *p1 = f1 ? f1 + (size_t)(s / div1) * ld1 : nullptr;
+    const bool vec0 = p0 && (ld0 % 4 == 0) && ((uintptr_t)f0 % 16 == 0);
+    const int C = C0 + C1;
+    for (int t = 0; t < KT32; ++t) {
+        f32x4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 32 * t + 16 * h + 4 * g;
+            if (vec0 && c + 3 < C0) {
+                v[h] = *(const f32x4 *)(p0 + c);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cc = c + q;
+                    v[h][q] = cc < C0 ? p0[cc] : (cc < C ? p1[cc - C0] : 0.f);
+                }
+            }
+        }
+        bf16x8 pl[3];
+        b3_split8(v[0], v[1], pl);
+        uint4 *d = planes + (((size_t)t * ntiles + tile) * 3) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+    }
+}
+
+extern "C" int pccx_group_planes(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
+                                 int64_t rows_per_batch, int64_t n_src, float *planes, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(planes && M > 0, "pccx_group_planes: null output or negative M");
+    PCCX_CHECK_ARG(C0 >= 0 && C1 >= 0 && C0 + C1 >= 1 && (C0 == 0 || (f0 && ld0 >= C0)) && (C1 == 0 || (f1 && ld1 >= C1)),
+                   "pccx_group_planes: bad sources C0=%d C1=%d", C0, C1);
+    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1), "pccx_group_planes: indices need rows_per_batch and n_src");
+    const long long ntiles = (M + 15) / 16;
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_group_planes: M too large");
+    hipLaunchKernelGGL(group_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, C0 ? f0 : nullptr, C0,
+                       ld0, C1 ? f1 : nullptr, C1, ld1, idx, (long long)M, (long long)(idx ? rows_per_batch : 1),
+                       (long long)(idx ? n_src : 1), pg_kt32(C0 + C1), ntiles, (uint4 *)planes, 0LL, 1LL);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// torch.cat([a, b.unsqueeze(1).repeat(1, P, 1)], -1) as planes (the inputs of FoldingNet's two stacks, PPPF_AE.py:99-106): row r has
+// the C0 channels of f0 row (mod0 > 0 ? r % mod0 : r) followed by the C1 channels of f1 row r / div1.  Nothing is concatenated or
+// repeated in memory.
+extern "C" int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
+                                float *planes, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(planes && f0 && f1 && M > 0, "pccx_fold_planes: null pointer or negative M");
+    PCCX_CHECK_ARG(C0 >= 1 && C1 >= 1 && ld0 >= C0 && ld1 >= C1 && mod0 >= 0 && div1 >= 1, "pccx_fold_planes: bad arguments");
+    const long long ntiles = (M + 15) / 16;
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_fold_planes: M too large");
+    hipLaunchKernelGGL(group_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f0, C0, ld0, f1, C1, ld1,
+                       (const int64_t *)nullptr, (long long)M, 1LL, 1LL, pg_kt32(C0 + C1), ntiles, (uint4 *)planes, (long long)mod0,
+                       (long long)div1);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- weight stream: [m-block][t][MB m-tiles][plane] fragments out of pccx_pack_linear_b3's [t][MT][plane] ------------
+extern "C" size_t pccx_planes_gemm_weight_floats(int N, int K)
+{
+    const int MT = ((N > 0 ? N : 1) + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB;
+    return (size_t)MBS * pg_kt32(K > 0 ? K : 1) * MB * 3 * 256;
+}
+
+__global__ void planes_weight_kernel(const uint4 *__restrict__ wpl, int KT32, int MT, int MB, int MBS, uint4 *__restrict__ ws)
+{
+    const size_t total = (size_t)MBS * KT32 * MB * 3 * 64;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        size_t f = e >> 6;
+        const int p = (int)(f % 3); f /= 3;
+        const int m = (int)(f % MB); f /= MB;
+        const int t = (int)(f % KT32);
+        const int mb = (int)(f / KT32);
+        const int mt = mb * MB + m;
+        ws[e] = mt < MT ? wpl[(((size_t)t * MT + mt) * 3 + p) * 64 + lane] : make_uint4(0, 0, 0, 0);
+    }
+}
+
+extern "C" int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream)
+{
+    PCCX_CHECK_ARG(wplanes_dev && wstream_dev && N >= 1 && K >= 1, "pccx_pack_planes_gemm: bad argument");
+    const int MT = (N + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB, KT32 = pg_kt32(K);
+    const size_t total = (size_t)MBS * KT32 * MB * 3 * 64;
+    hipLaunchKernelGGL(planes_weight_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4 *)wplanes_dev, KT32, MT, MB, MBS, (uint4 *)wstream_dev);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// ---- one layer ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 pg_load_async(const uint4 *p)    // placed exactly here; completion rides on the ring's s_waitcnt
+{
+    uint4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
+
+template <int MB, int EPI, bool GATHER, bool RS = false>
+__global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__restrict__ bin, const int64_t *__restrict__ idx,
+                                                             long long rows_per_batch, long long n_src, int ldp, long long M,
+                                                             long long ntiles, int KT32,
+                                                             const float *__restrict__ wstream, int MBS, const float *__restrict__ bias,
+                                                             int N, int relu, int group, float *__restrict__ out, int ldo)
+{
+    constexpr int HALVES = MB / 4;                             // ring chunks per k-step
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    // Block order: XCD-aware.  Consecutive workgroup ids go round the 8 XCDs, so the MBS m-blocks of one 128-row block are
+    // given to the SAME XCD one after the other: the row block's B planes are fetched into that XCD's L2 once, and every L2
+    // holds the layer's whole weight stream (<= 3 MB).
+    const long long nblk = (ntiles + 7) / 8;
+    const long long s = blockIdx.x >> 3;
+    const long long blk = (s / MBS) * 8 + (blockIdx.x & 7);
+    const int mb = (int)(s % MBS);
+    if (blk >= nblk) return;                                  // whole workgroup, before any barrier
+    const long long tile0 = blk * 8 + 2 * w;
+    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * PG_CHUNK * 64];
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int nch = HALVES * KT32;
+    const WStreamT<PG_CHUNK, PG_NB> ws{wstream + (size_t)mb * nch * PG_CHUNK * 256, swt, nch, lane, wu, false};
+    // DMA of chunk c (a chunk past the end re-reads chunk 0 into a free buffer, so every boundary issues the same loads and
+    // the counted waits below hold to the last k-step)
+    auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % PG_NB); };
+    if constexpr (!RS) {
+#pragma unroll
+        for (int c = 0; c < PG_NB - 1; ++c) dma(c);
+    }
+
+    f32x4 acc[2][MB];
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt) {
+        f32x4 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * (mb * MB + mt) + 4 * g + r;
+            b[r] = (bias && c < N) ? bias[c] : 0.f;
+        }
+        acc[0][mt] = b; acc[1][mt] = b;
+    }
+    const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
+    if constexpr (RS) {
+        // EXPERIMENT (PCCX_PG_RS=1): the weight chunks are not DMA'd into LDS but loaded into registers (3 x 16 B per lane per chunk,
+        // three chunks ahead, rotating sets) and written to a two-buffer LDS ring with ds_write_b128 one boundary before use.
+        static_assert(!RS || (MB == 8 && !GATHER), "register-staged form: MB = 8, planes input");
+        const uint4 *wsrc = (const uint4 *)(wstream + (size_t)mb * nch * PG_CHUNK * 256) + (size_t)(wu * 3) * 64 + lane;
+        uint4 *lbuf = (uint4 *)swt;
+        uint4 ar[3][3], bs[3][2][3];
+        auto load_a = [&](uint4 (&dst)[3], int c) {
+            const int cc = c < nch ? c : 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dst[q] = pg_load_async(wsrc + (size_t)cc * PG_CHUNK * 64 + q * 64);
+        };
+        auto write_a = [&](const uint4 (&src)[3], int c) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) lbuf[((c & 1) * PG_CHUNK + wu * 3 + q) * 64 + lane] = src[q];
+        };
+        auto load_b = [&](uint4 (&dst)[2][3], int t) {
+            const int tc = t < KT32 ? t : KT32 - 1;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[nt][pl] = pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+        };
+        // chunk c: boundary = wait for the registers of chunk c+1 and for this wave's LDS writes of chunk c, barrier, write chunk c+1
+        // into the buffer chunk c-1 has left, load chunk c+3 into the set just written out (+ on even chunks the B planes of t+2)
+        auto chunk = [&](int c, int half, const uint4 (&bc)[2][3], const uint4 (&a_wr)[3], uint4 (&a_ld)[3], uint4 (&bload)[2][3], bool do_b, int tb) {
+            asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            write_a(a_wr, c + 1);
+            load_a(a_ld, c + 3);
+            if (do_b) load_b(bload, tb);
+            const f32x4 *buf = (const f32x4 *)lbuf + (c & 1) * PG_CHUNK * 64 + lane;
+            bf16x8 a[4][3];
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (half == 0)
+                            acc[nt][mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][mq], 0, 0, 0);
+                        else
+                            acc[nt][4 + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 + mq], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // k-step t with t % 3 == R: chunks 2t, 2t+1 -> register sets (2R) % 3, (2R + 1) % 3, (2R + 2) % 3
+#define PG_RS_KSTEP(t_, R_, BC_, BL_)                                                                                  \
+        chunk(2 * (t_), 0, BC_, ar[(2 * R_ + 1) % 3], ar[(2 * R_) % 3], BL_, true, (t_) + 2);                            \
+        chunk(2 * (t_) + 1, 1, BC_, ar[(2 * R_ + 2) % 3], ar[(2 * R_ + 1) % 3], BL_, false, 0)
+        load_a(ar[0], 0); load_a(ar[1], 1); load_a(ar[2], 2);
+        load_b(bs[0], 0);
+        load_b(bs[1], 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        write_a(ar[0], 0);
+        PG_RS_KSTEP(0, 0, bs[0], bs[2]);
+        if (KT32 > 1) { PG_RS_KSTEP(1, 1, bs[1], bs[0]); }
+#pragma unroll 1
+        for (int t = 2; t < KT32; t += 3) {
+            PG_RS_KSTEP(t, 2, bs[2], bs[1]);
+            if (t + 1 < KT32) { PG_RS_KSTEP(t + 1, 0, bs[0], bs[2]); }
+            if (t + 2 < KT32) { PG_RS_KSTEP(t + 2, 1, bs[1], bs[0]); }
+        }
+#undef PG_RS_KSTEP
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+        // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [3], B(t+2) [6];  boundary(2t+1): DMA(2t+4) [3]
+        //                                          HALVES = 1:  boundary(t):  DMA(t+3) [3],  B(t+2) [6]
+        // loads complete in order, so boundary(c) may leave in flight everything issued after the youngest load it needs.
+        // GATHER: bin = fp32 source rows (n_src per batch, ldp = 32 * KT32 floats, zero padded); row r reads source row
+        // (r / rows_per_batch) * n_src + max(idx[r], 0) and is split in registers at use (4 loads per k-step instead of 6).
+        constexpr int NBL = GATHER ? 4 : 6, NBV = GATHER ? 2 : 3;
+        uint4 bs[3][2][NBV];
+        const uint4 *gsrc[2] = {nullptr, nullptr};
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                long long r = (nt ? t1 : t0) * 16 + n;
+                if (r >= M) r = M - 1;
+                const long long j = idx[r];
+                gsrc[nt] = (const uint4 *)((const float *)bin + (size_t)((r / rows_per_batch) * n_src + (j < 0 ? 0 : j)) * ldp + 4 * g);
+            }
+        }
+        auto load_b = [&](uint4 (&dst)[2][NBV], int t) {
+            const int tc = t < KT32 ? t : KT32 - 1;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < NBV; ++pl)
+                    dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
+                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+        };
+        auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
+            bf16x8 bc[2][3];
+#pragma unroll
+            for (int half = 0; half < HALVES; ++half) {
+                const int c = HALVES * t + half;
+                if (half == 0) {
+                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NBL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NBL) : "memory");
+                    __syncthreads();
+                    dma(c + PG_NB - 1);
+                    load_b(bload, t + 2);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if constexpr (GATHER)
+                            b3_split8(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), bc[nt]);
+                        else
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) bc[nt][pl] = __builtin_bit_cast(bf16x8, braw[nt][pl < NBV ? pl : 0]);
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NBL) : "memory");
+                    __syncthreads();
+                    dma(c + PG_NB - 1);
+                }
+                const f32x4 *buf = ws.chunk(c);
+                bf16x8 a[4][3];
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+                // six products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[nt][4 * half + mq] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], bc[nt][PB[q]], acc[nt][4 * half + mq], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        load_b(bs[0], 0);
+        load_b(bs[1], 1);
+        kstep(0, bs[0], bs[2], true);                     // waits for everything issued so far
+        if (KT32 > 1) kstep(1, bs[1], bs[0], false);
+#pragma unroll 1
+        for (int t = 2; t < KT32; t += 3) {               // three k-steps per trip: static register sets
+            kstep(t, bs[2], bs[1], false);
+            if (t + 1 < KT32) kstep(t + 1, bs[0], bs[2], false);
+            if (t + 2 < KT32) kstep(t + 2, bs[1], bs[0], false);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads and DMAs
+    }
+
+    if constexpr (EPI == PG_EPI_PLANES) {
+        // next layer's operand: k-tile j of this m-block = C tiles 2j, 2j+1
+        uint4 *o = (uint4 *)out;
+        const int KTo = ((N + 15) / 16 + 1) / 2;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (tile0 + nt >= ntiles) continue;
+#pragma unroll
+            for (int j = 0; j < MB / 2; ++j) {
+                const int to = mb * (MB / 2) + j;
+                if (to >= KTo) continue;
+                bf16x8 pl[3];
+                if (relu) b3_split8(relu4(acc[nt][2 * j]), relu4(acc[nt][2 * j + 1]), pl);
+                else b3_split8(acc[nt][2 * j], acc[nt][2 * j + 1], pl);
+                uint4 *d = o + (((size_t)to * ntiles + tile0 + nt) * 3) * 64 + lane;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+            }
+        }
+    } else if constexpr (EPI == PG_EPI_ROWS) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const long long row = (tile0 + nt) * 16 + n;
+            if (tile0 + nt >= ntiles || row >= M) continue;
+#pragma unroll
+            for (int mt = 0; mt < MB; ++mt) {
+                const int c = 16 * (mb * MB + mt) + 4 * g;
+                f32x4 v = relu ? relu4(acc[nt][mt]) : acc[nt][mt];
+                float *po = out + (size_t)row * ldo + c;
+                if (c + 3 < N && ldo % 4 == 0) {
+                    *(f32x4 *)po = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < N) po[r] = v[r];
+                }
+            }
+        }
+    } else {
+        // max over groups of `group` rows (32, 64 or 128; M is a multiple of it, so no group holds padded rows).  In the wave:
+        // the two tiles elementwise, then the 16 rows of the tile by DPP; across the waves of a group through LDS.
+        __syncthreads();                                   // every wave is done with the ring
+        float *smax = (float *)swt;                        // [4 waves][16 * MB channels]
+#pragma unroll
+        for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(acc[0][mt][r], acc[1][mt][r]);
+                v = row16_max(v);
+                if (n == 0) smax[w * (16 * MB) + 16 * mt + 4 * g + r] = v;
+            }
+        __syncthreads();
+        const int gpb = 128 / group, wpg = group / 32;     // groups per block, waves per group
+        const long long G = M / group;
+        for (int e = tid; e < gpb * 16 * MB; e += 256) {
+            const int gi = e / (16 * MB), c = e % (16 * MB);
+            float v = smax[(gi * wpg) * (16 * MB) + c];
+            for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * (16 * MB) + c]);
+            if (relu) v = fmaxf(v, 0.f);                   // max(relu(x)) = relu(max(x))
+            const long long grp = blk * gpb + gi;
+            const int ch = mb * 16 * MB + c;
+            if (grp < G && ch < N) out[(size_t)grp * ldo + ch] = v;
+        }
+    }
+}
+
+// out: epilogue 0 -> planes of the N output channels (pccx_planes_floats(M, N) floats); 1 -> fp32 rows (M, ldo);
+// 2 -> fp32 (M / group, ldo), the max over each `group` consecutive rows (group in {32, 64, 128}, M % group == 0).
+static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K,
+                              const float *wstream, const float *bias, int N, int relu, int epilogue, int group, float *out, int ldo,
+                              void *stream, const char *who)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
+    PCCX_CHECK_ARG(M > 0 && K >= 1 && N >= 1, "%s: bad shape M=%lld K=%d N=%d", who, (long long)M, K, N);
+    PCCX_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "%s: epilogue %d", who, epilogue);
+    PCCX_CHECK_ARG(epilogue == PG_EPI_PLANES || ldo >= N, "%s: ldo=%d < N=%d", who, ldo, N);
+    PCCX_CHECK_ARG(epilogue != PG_EPI_MAX || ((group == 32 || group == 64 || group == 128) && M % group == 0),
+                   "%s: group max needs group in {32,64,128} dividing M (group=%d M=%lld)", who, group, (long long)M);
+    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
+    const int MT = (N + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB, KT32 = pg_kt32(K);
+    const long long blocks = (nblk + 7) / 8 * 8 * MBS;
+    PCCX_CHECK_ARG(blocks <= 0x7fffffffLL, "%s: M=%lld too large", who, (long long)M);
+    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1 && ldp == 32 * KT32 && (uintptr_t)x % 16 == 0),
+                   "%s: source rows must be 16-byte aligned with a stride of %d floats (got %d)", who, 32 * KT32, ldp);
+    hipStream_t st = (hipStream_t)stream;
+    relu &= 1;
+#define PG_LAUNCH(MB_, E_, G_)                                                                                                  \
+    hipLaunchKernelGGL((planes_gemm_kernel<MB_, E_, G_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx,       \
+                       (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, \
+                       group, out, ldo)
+#define PG_LAUNCH_E(MB_, G_)                                                                                                    \
+    do {                                                                                                                        \
+        if (epilogue == PG_EPI_PLANES) PG_LAUNCH(MB_, PG_EPI_PLANES, G_);                                                       \
+        else if (epilogue == PG_EPI_ROWS) PG_LAUNCH(MB_, PG_EPI_ROWS, G_);                                                      \
+        else PG_LAUNCH(MB_, PG_EPI_MAX, G_);                                                                                    \
+    } while (0)
+    static int rs = -1;
+    if (rs < 0) { const char *e = getenv("PCCX_PG_RS"); rs = e ? atoi(e) : 0; }
+    if (MB == 8 && !idx && rs) {
+        if (epilogue == PG_EPI_PLANES) hipLaunchKernelGGL((planes_gemm_kernel<8, PG_EPI_PLANES, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx, (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, group, out, ldo);
+        else if (epilogue == PG_EPI_ROWS) hipLaunchKernelGGL((planes_gemm_kernel<8, PG_EPI_ROWS, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx, (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, group, out, ldo);
+        else hipLaunchKernelGGL((planes_gemm_kernel<8, PG_EPI_MAX, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx, (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, group, out, ldo);
+    } else if (MB == 8) { if (idx) PG_LAUNCH_E(8, true); else PG_LAUNCH_E(8, false); }
+    else { if (idx) PG_LAUNCH_E(4, true); else PG_LAUNCH_E(4, false); }
+#undef PG_LAUNCH_E
+#undef PG_LAUNCH
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                                int epilogue, int group, float *out, int ldo, void *stream)
+{
+    return planes_gemm_launch(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                              "pccx_planes_gemm");
+}
+
+// The same layer with its input gathered in the kernel (see pccx_planes_chain4_gather): src = fp32 rows of ldp = 32 * ceil(K / 32)
+// floats, row r of the layer's input = source row (r / rows_per_batch) * n_src + max(idx[r], 0).
+extern "C" int pccx_planes_gemm_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                       int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
+                                       float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_gemm_gather: null indices");
+    return planes_gemm_launch(src, idx, rows_per_batch, n_src, ldp, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                              "pccx_planes_gemm_gather");
+}
+
+// ---- four-layer stack in one kernel ------------------------------------------------------------------------------
+// Conv-BN-ReLU x 4 + max over nsample (pointnet_sa_module.py:90-91) for stacks whose first three widths are <= 128: layer 0 is the
+// GEMM above on the planes of the gathered input; its accumulators (128 rows x <= 128 channels per workgroup, 2 row tiles x <= 8
+// m-tiles per wave) are split in registers into the next layer's B planes (the chain of mfma_chain.h), and so on; the last layer
+// runs in passes of 128 output channels, each reduced over the groups of `group` rows as in the epilogue above.  One weight stream
+// for the whole stack (the four layers' pccx_pack_planes_gemm streams back to back) goes through the LDS-DMA ring; no activation
+// of the stack exists in HBM.
+//   MQ0 / MQ1 / MQ2 : output m-quads (4 m-tiles) of layers 0..2 (1 or 2);  KT1..KT3 : K/32 blocks of the inputs of layers 1..3;
+//   NP : passes (of 8 m-tiles) of the last layer.
+template <int KT, int MQ, class WS>
+__device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, const bf16x8 (&in)[2][KT][3], f32x4 (&acc)[2][4 * MQ])
+{
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int mqq = 0; mqq < MQ; ++mqq) {
+            // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (6 loads) may stay in flight
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __syncthreads();
+            {
+                const int nx = c + PG_NB - 1;
+                ws.issue(nx < nch ? nx : 0, nx % PG_NB);
+            }
+            const f32x4 *buf = ws.chunk(c);
+            bf16x8 a[4][3];
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[nt][4 * mqq + mq] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], in[nt][kt][PB[q]], acc[nt][4 * mqq + mq], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ++c;
+        }
+}
+
+template <int NTILES>
+__device__ __forceinline__ void pg_bias_init(f32x4 (&acc)[2][NTILES], const float *__restrict__ bias, int N, int m0, int g)
+{
+#pragma unroll
+    for (int mt = 0; mt < NTILES; ++mt) {
+        f32x4 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = 16 * (m0 + mt) + 4 * g + r;
+            b[r] = (bias && ch < N) ? bias[ch] : 0.f;
+        }
+        acc[0][mt] = b; acc[1][mt] = b;
+    }
+}
+
+// relu + split of a layer's accumulators into the next layer's planes (k-tile j = C tiles 2j, 2j+1; a missing odd tile is zero)
+template <int NTILES, int KT>
+__device__ __forceinline__ void pg_to_planes(const f32x4 (&acc)[2][NTILES], bf16x8 (&pl)[2][KT][3])
+{
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            b3_split8(relu4(acc[nt][2 * j]), 2 * j + 1 < NTILES ? relu4(acc[nt][2 * j + 1]) : zero, pl[nt][j]);
+}
+
+template <int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP, bool GATHER>
+__global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__restrict__ bin, const int64_t *__restrict__ idx,
+                                                               long long rows_per_batch, long long n_src, int ldp, long long M,
+                                                               long long ntiles, int KT0,
+                                                               const float *__restrict__ wstream, const float *__restrict__ b0, int N0,
+                                                               const float *__restrict__ b1, int N1, const float *__restrict__ b2, int N2,
+                                                               const float *__restrict__ b3, int N3, int group, float *__restrict__ out,
+                                                               int ldo)
+{
+    static_assert(2 * KT1 <= 4 * MQ0 + 1 && 2 * KT2 <= 4 * MQ1 + 1 && 2 * KT3 <= 4 * MQ2 + 1, "a layer's K blocks come from the previous layer's tiles");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const long long blk = blockIdx.x;
+    const long long tile0 = blk * 8 + 2 * w;
+    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * PG_CHUNK * 64];
+    __shared__ float smax[4 * 128];
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int nch = MQ0 * KT0 + KT1 * MQ1 + KT2 * MQ2 + NP * KT3 * 2;
+    const WStreamT<PG_CHUNK, PG_NB> ws{wstream, swt, nch, lane, wu, false};
+    auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % PG_NB); };
+#pragma unroll
+    for (int c = 0; c < PG_NB - 1; ++c) dma(c);
+
+    const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
+    // ---- layer 0: as planes_gemm_kernel (HALVES = MQ0).  GATHER: the B operand is not read as planes but gathered here --
+    // bin = fp32 source rows (n_src per batch, ldp = 32 * KT0 floats each, zero padded), row r reads source row
+    // (r / rows_per_batch) * n_src + max(idx[r], 0) (pointnet_sa_module.py:27,73-83) -- and split in registers at use.
+    f32x4 acc0[2][4 * MQ0];
+    pg_bias_init<4 * MQ0>(acc0, b0, N0, 0, g);
+    {
+        constexpr int NBL = GATHER ? 4 : 6;                  // B loads per k-step
+        constexpr int NBV = GATHER ? 2 : 3;
+        uint4 bs[3][2][NBV];
+        const uint4 *gsrc[2] = {nullptr, nullptr};
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                long long r = (nt ? t1 : t0) * 16 + n;
+                if (r >= M) r = M - 1;
+                const long long j = idx[r];
+                gsrc[nt] = (const uint4 *)((const float *)bin + (size_t)((r / rows_per_batch) * n_src + (j < 0 ? 0 : j)) * ldp + 4 * g);
+            }
+        }
+        auto load_b = [&](uint4 (&dst)[2][NBV], int t) {
+            const int tc = t < KT0 ? t : KT0 - 1;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < NBV; ++pl)
+                    dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
+                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+        };
+        auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
+            bf16x8 bc[2][3];
+#pragma unroll
+            for (int half = 0; half < MQ0; ++half) {
+                const int c = MQ0 * t + half;
+                if (half == 0) {
+                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NBL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NBL) : "memory");
+                    __syncthreads();
+                    dma(c + PG_NB - 1);
+                    load_b(bload, t + 2);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if constexpr (GATHER)
+                            b3_split8(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), bc[nt]);
+                        else
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) bc[nt][pl] = __builtin_bit_cast(bf16x8, braw[nt][pl < NBV ? pl : 0]);
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NBL) : "memory");
+                    __syncthreads();
+                    dma(c + PG_NB - 1);
+                }
+                const f32x4 *buf = ws.chunk(c);
+                bf16x8 a[4][3];
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc0[nt][4 * half + mq] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], bc[nt][PB[q]], acc0[nt][4 * half + mq], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        load_b(bs[0], 0);
+        load_b(bs[1], 1);
+        kstep(0, bs[0], bs[2], true);
+        if (KT0 > 1) kstep(1, bs[1], bs[0], false);
+#pragma unroll 1
+        for (int t = 2; t < KT0; t += 3) {
+            kstep(t, bs[2], bs[1], false);
+            if (t + 1 < KT0) kstep(t + 1, bs[0], bs[2], false);
+            if (t + 2 < KT0) kstep(t + 2, bs[1], bs[0], false);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads land before their
+    }                                                                     // registers are reused; the ring's DMAs with them
+    int c = MQ0 * KT0;
+    // ---- layers 1, 2: registers to registers
+    bf16x8 i1[2][KT1][3];
+    pg_to_planes<4 * MQ0, KT1>(acc0, i1);
+    f32x4 acc1[2][4 * MQ1];
+    pg_bias_init<4 * MQ1>(acc1, b1, N1, 0, g);
+    pg_chain_layer<KT1, MQ1>(ws, c, nch, i1, acc1);
+    bf16x8 i2[2][KT2][3];
+    pg_to_planes<4 * MQ1, KT2>(acc1, i2);
+    f32x4 acc2[2][4 * MQ2];
+    pg_bias_init<4 * MQ2>(acc2, b2, N2, 0, g);
+    pg_chain_layer<KT2, MQ2>(ws, c, nch, i2, acc2);
+    bf16x8 i3[2][KT3][3];
+    pg_to_planes<4 * MQ2, KT3>(acc2, i3);
+    // ---- last layer in passes of 8 m-tiles, each reduced over the row groups
+    const int gpb = 128 / group, wpg = group / 32;
+    const long long G = M / group;
+#pragma unroll 1
+    for (int ps = 0; ps < NP; ++ps) {
+        f32x4 acc3[2][8];
+        pg_bias_init<8>(acc3, b3, N3, 8 * ps, g);
+        pg_chain_layer<KT3, 2>(ws, c, nch, i3, acc3);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(acc3[0][mt][r], acc3[1][mt][r]);
+                v = row16_max(v);
+                if (n == 0) smax[w * 128 + 16 * mt + 4 * g + r] = v;
+            }
+        __syncthreads();
+        for (int e = tid; e < gpb * 128; e += 256) {
+            const int gi = e >> 7, ch = e & 127;
+            float v = smax[(gi * wpg) * 128 + ch];
+            for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * 128 + ch]);
+            v = fmaxf(v, 0.f);                               // max(relu(x)) = relu(max(x))
+            const long long grp = blk * gpb + gi;
+            const int co = 128 * ps + ch;
+            if (grp < G && co < N3) out[(size_t)grp * ldo + co] = v;
+        }
+        // the next pass writes smax only after its first ring boundary (a barrier every thread reaches after these reads)
+    }
+    ws.drain();
+}
+
+// out (M / group, ldo) = max over each `group` consecutive rows of relu(L3(relu(L2(relu(L1(relu(L0(x)))))))).
+// wstream: the four layers' pccx_pack_planes_gemm streams back to back.  Supported stacks (PCCX_ERR_ARG otherwise; callers fall
+// back to pccx_planes_gemm layer by layer): widths (N0..N3) in the two shapes of PPPF_AE.py:29-34, (<=32, 33..64, 33..64, 65..128)
+// and (97..128 x3, 129..256), each layer's input being the previous layer's output.
+//   pccx_planes_chain4        : x given as planes (pccx_group_planes / a previous layer);
+//   pccx_planes_chain4_gather : x gathered in the kernel from fp32 rows src (n_src rows per batch of ldp = 32 * ceil(K0 / 32) floats,
+//                               the K0 channels zero padded) by idx (M entries, -1 -> row 0): the grouped tensor of
+//                               pointnet_sa_module.py:73-83 never exists in memory in any form.
+static int planes_chain4_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K0,
+                                const float *wstream, const float *b0, int N0, const float *b1, int N1, const float *b2, int N2,
+                                const float *b3, int N3, int group, float *out, int ldo, void *stream, const char *who)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
+    PCCX_CHECK_ARG(M > 0 && K0 >= 1 && N0 >= 1 && N1 >= 1 && N2 >= 1 && N3 >= 1 && ldo >= N3, "%s: bad shape", who);
+    PCCX_CHECK_ARG((group == 32 || group == 64 || group == 128) && M % group == 0, "%s: group in {32,64,128} dividing M (group=%d M=%lld)",
+                   who, group, (long long)M);
+    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
+    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "%s: M too large", who);
+    const int KT0 = pg_kt32(K0);
+    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1 && ldp == 32 * KT0 && (uintptr_t)x % 16 == 0),
+                   "%s: source rows must be 16-byte aligned with a stride of %d floats (got %d)", who, 32 * KT0, ldp);
+    hipStream_t st = (hipStream_t)stream;
+    auto kt = [](int N) { return pg_kt32(N); };
+#define PG_CHAIN(G_, MQ0, KT1, MQ1, KT2, MQ2, KT3, NP)                                                                           \
+    hipLaunchKernelGGL((planes_chain4_kernel<MQ0, KT1, MQ1, KT2, MQ2, KT3, NP, G_>), dim3((unsigned)nblk), dim3(256), 0, st,       \
+                       (const uint4 *)x, idx, (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT0, wstream, b0, \
+                       N0, b1, N1, b2, N2, b3, N3, group, out, ldo)
+    if (N0 <= 32 && N1 > 32 && N1 <= 64 && N2 > 32 && N2 <= 64 && N3 > 64 && N3 <= 128) {
+        // (3, 64, 64, 128): layer 1 reads one K block, layers 2 and 3 two
+        PCCX_CHECK_ARG(kt(N0) == 1 && kt(N1) == 2 && kt(N2) == 2, "%s: unsupported widths %d %d %d %d", who, N0, N1, N2, N3);
+        if (idx) PG_CHAIN(true, 1, 1, 1, 2, 1, 2, 1); else PG_CHAIN(false, 1, 1, 1, 2, 1, 2, 1);
+    } else if (N0 > 96 && N0 <= 128 && N1 > 96 && N1 <= 128 && N2 > 96 && N2 <= 128 && N3 > 128 && N3 <= 256) {
+        // (128, 128, 128, 256): four K blocks into every chained layer, two passes of the last
+        if (idx) PG_CHAIN(true, 2, 4, 2, 4, 2, 4, 2); else PG_CHAIN(false, 2, 4, 2, 4, 2, 4, 2);
+    } else {
+        pccx_set_error("%s: unsupported widths %d %d %d %d", who, N0, N1, N2, N3);
+        return PCCX_ERR_ARG;
+    }
+#undef PG_CHAIN
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
+                                  const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
+                                  int ldo, void *stream)
+{
+    return planes_chain4_launch(planes_in, nullptr, 1, 1, 0, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo, stream,
+                                "pccx_planes_chain4");
+}
+
+extern "C" int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                         int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
+                                         const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_chain4_gather: null indices");
+    return planes_chain4_launch(src, idx, rows_per_batch, n_src, ldp, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo,
+                                stream, "pccx_planes_chain4_gather");
+}
+
+// ---- three wide layers in one kernel -----------------------------------------------------------------------------
+// The first three layers of sa3 (PPPF_AE.py:32-34: 259 -> 256 -> 256 -> 512) are too wide for the two-tiles-per-wave chain above
+// (256 channels x 32 rows of accumulators and operand planes do not fit 256 registers), so they run as pn_forward_b3_kernel does:
+// ONE 16-row tile per wave, eight waves per workgroup sharing the weight stream of the three layers through a double-buffered
+// LDS-DMA ring (dense_b3_stream), every activation between the layers in registers; the last layer runs in two passes of 256
+// output channels whose epilogue writes the operand planes of the layer that follows (512 -> 1024 + max: planes_gemm_kernel).
+// The input rows are gathered in the kernel (fp32 source rows of 32 * KT0 floats, zero padded; idx -1 -> row 0).
+#define PW_CHUNK 24
+// a layer = one dense_b3_stream call per K block (the unroller gives up on a whole wide layer in one call)
+template <int KT, class WS>
+__device__ __forceinline__ void pw_layer(const WS &ws, int &f, const bf16x8 (&in)[1][KT][3], f32x4 (&acc)[1][16])
+{
+#pragma clang loop unroll(full)
+    for (int kt = 0; kt < KT; ++kt) {
+        bf16x8 pl[1][1][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pl[0][0][p] = in[0][kt][p];
+        dense_b3_stream<1, 16, 1>(ws, f, pl, acc);
+    }
+}
+template <int KT0>
+__global__ __launch_bounds__(512, 1) void planes_chain_wide_kernel(const uint4 *__restrict__ src, const int64_t *__restrict__ idx,
+                                                                   long long rows_per_batch, long long n_src, int ldp, long long M,
+                                                                   long long ntiles, const float *__restrict__ wstream,
+                                                                   const float *__restrict__ b0, const float *__restrict__ b1,
+                                                                   const float *__restrict__ b2, int N0, int N1, int N2,
+                                                                   uint4 *__restrict__ out)
+{
+    constexpr int FRAGS = (KT0 * 16 + 8 * 16 + 8 * 32) * 3;
+    constexpr int NCH = (FRAGS + PW_CHUNK - 1) / PW_CHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const long long tile = (long long)blockIdx.x * 8 + w;
+    const bool valid = tile < ntiles;                         // an idle wave recomputes the last tile and discards it (barriers inside)
+    const long long tc = valid ? tile : ntiles - 1;
+    __shared__ __attribute__((aligned(16))) f32x4 swt[2 * PW_CHUNK * 64];
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const WStreamT<PW_CHUNK, 2, 8> ws{wstream, swt, NCH, lane, wu, false};
+    ws.prologue();
+
+    bf16x8 in0[1][KT0][3];
+    {
+        long long r = tc * 16 + n;
+        if (r >= M) r = M - 1;
+        const long long j = idx ? idx[r] : r;
+        const long long s = idx ? (r / rows_per_batch) * n_src + (j < 0 ? 0 : j) : r;
+        const f32x4 *gp = (const f32x4 *)((const float *)src + (size_t)s * ldp + 4 * g);
+#pragma unroll
+        for (int t = 0; t < KT0; ++t) b3_split8(gp[8 * t], gp[8 * t + 4], in0[0][t]);
+    }
+    auto bias16 = [&](f32x4 (&acc)[1][16], const float *b, int N, int m0) {
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * (m0 + mt) + 4 * g + r;
+                acc[0][mt][r] = (b && ch < N) ? b[ch] : 0.f;
+            }
+    };
+    int f = 0;                                                // fragment cursor (constant-folds: the chain is fully unrolled)
+    f32x4 a0[1][16];
+    bias16(a0, b0, N0, 0);
+    pw_layer<KT0>(ws, f, in0, a0);
+    bf16x8 in1[1][8][3];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b3_split8(relu4(a0[0][2 * t]), relu4(a0[0][2 * t + 1]), in1[0][t]);
+    f32x4 a1[1][16];
+    bias16(a1, b1, N1, 0);
+    pw_layer<8>(ws, f, in1, a1);
+    bf16x8 in2[1][8][3];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b3_split8(relu4(a1[0][2 * t]), relu4(a1[0][2 * t + 1]), in2[0][t]);
+#pragma clang loop unroll(full)
+    for (int ps = 0; ps < 2; ++ps) {
+        f32x4 a2[1][16];
+        bias16(a2, b2, N2, 16 * ps);
+        pw_layer<8>(ws, f, in2, a2);
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                bf16x8 pl[3];
+                b3_split8(relu4(a2[0][2 * t]), relu4(a2[0][2 * t + 1]), pl);
+                uint4 *d = out + (((size_t)(8 * ps + t) * ntiles + tile) * 3) * 64 + lane;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+            }
+        }
+    }
+    ws.drain();
+}
+
+// The weight stream of pccx_planes_chain_wide: the three layers' pccx_pack_linear_b3 planes, the third reordered into its two
+// passes of 16 m-tiles, zero padded to whole ring chunks.
+extern "C" size_t pccx_planes_chain_wide_weight_floats(int K0)
+{
+    const size_t frags = (size_t)(pg_kt32(K0 > 0 ? K0 : 1) * 16 + 8 * 16 + 8 * 32) * 3;
+    return (frags + PW_CHUNK - 1) / PW_CHUNK * PW_CHUNK * 256;
+}
+
+extern "C" int pccx_pack_planes_chain_wide(const float *wp3_l0, const float *wp3_l1, const float *wp3_l2, int K0, int N0, int N1, int N2,
+                                           float *wstream_dev, void *stream)
+{
+    PCCX_CHECK_ARG(wp3_l0 && wp3_l1 && wp3_l2 && wstream_dev, "pccx_pack_planes_chain_wide: null pointer");
+    PCCX_CHECK_ARG(K0 >= 1 && N0 > 240 && N0 <= 256 && N1 > 240 && N1 <= 256 && N2 > 496 && N2 <= 512,
+                   "pccx_pack_planes_chain_wide: widths %d %d %d are not (241..256, 241..256, 497..512)", N0, N1, N2);
+    hipStream_t st = (hipStream_t)stream;
+    const int KT0 = pg_kt32(K0);
+    PCCX_CHECK_HIP(hipMemsetAsync(wstream_dev, 0, sizeof(float) * pccx_planes_chain_wide_weight_floats(K0), st));
+    const size_t n0 = (size_t)KT0 * 16 * 3 * 256, n1 = (size_t)8 * 16 * 3 * 256;
+    PCCX_CHECK_HIP(hipMemcpyAsync(wstream_dev, wp3_l0, sizeof(float) * n0, hipMemcpyDeviceToDevice, st));           // [t][16][3] as packed
+    PCCX_CHECK_HIP(hipMemcpyAsync(wstream_dev + n0, wp3_l1, sizeof(float) * n1, hipMemcpyDeviceToDevice, st));
+    const size_t total = (size_t)2 * 8 * 16 * 3 * 64;
+    hipLaunchKernelGGL(planes_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4 *)wp3_l2, 8, 32, 16, 2,
+                       (uint4 *)(wstream_dev + n0 + n1));                                                           // [pass][t][16][3]
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// relu(L2(relu(L1(relu(L0(x)))))) for widths (241..256, 241..256, 497..512) written as the operand planes of the next layer
+// (pccx_planes_floats(M, N2) floats).  x: fp32 source rows of ldp = 32 * ceil(K0 / 32) floats (zero padded, 16-byte aligned), row r
+// of the input = source row (r / rows_per_batch) * n_src + max(idx[r], 0), or row r itself when idx is NULL.  K0 <= 288 (nine K
+// blocks: sa3's 259 channels); other shapes return PCCX_ERR_ARG and the caller runs the layers one by one.
+extern "C" int pccx_planes_chain_wide(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                      int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1, const float *b2,
+                                      int N2, float *out_planes, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(src && wstream && out_planes && M > 0, "pccx_planes_chain_wide: null pointer");
+    const int KT0 = pg_kt32(K0);
+    PCCX_CHECK_ARG(N0 > 240 && N0 <= 256 && N1 > 240 && N1 <= 256 && N2 > 496 && N2 <= 512 && (KT0 == 8 || KT0 == 9),
+                   "pccx_planes_chain_wide: unsupported shape K0=%d widths %d %d %d", K0, N0, N1, N2);
+    PCCX_CHECK_ARG(ldp == 32 * KT0 && (uintptr_t)src % 16 == 0 && (!idx || (rows_per_batch >= 1 && n_src >= 1)),
+                   "pccx_planes_chain_wide: source rows must be 16-byte aligned with a stride of %d floats (got %d)", 32 * KT0, ldp);
+    const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
+    PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "pccx_planes_chain_wide: M too large");
+    hipStream_t st = (hipStream_t)stream;
+#define PW_LAUNCH(KT_)                                                                                                          \
+    hipLaunchKernelGGL((planes_chain_wide_kernel<KT_>), dim3((unsigned)nblk), dim3(512), 0, st, (const uint4 *)src, idx,           \
+                       (long long)(idx ? rows_per_batch : 1), (long long)(idx ? n_src : 1), ldp, (long long)M, ntiles, wstream, b0, b1, \
+                       b2, N0, N1, N2, (uint4 *)out_planes)
+    if (KT0 == 9) PW_LAUNCH(9); else PW_LAUNCH(8);
+#undef PW_LAUNCH
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
