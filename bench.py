@@ -179,13 +179,26 @@ class Ranks:
             self.local = self.local % max(torch.cuda.device_count(), 1)      # rehearsal: ranks may share a GPU
         self.gpu = args.workload != "launch-check"
         if self.gpu:
+            have = torch.cuda.device_count()
+            if self.local >= have:                                           # the launcher parent does not look at the GPUs: we do
+                raise SystemExit(f"bench.py rank {self.rank}: LOCAL_RANK {self.local} but only {have} GPU(s) visible "
+                                 f"(--gpus {self.world}; use --dist-backend gloo to rehearse the N>1 path on fewer GPUs)")
             torch.cuda.set_device(self.local)
             self.dev = torch.device("cuda", self.local)
         else:
             self.dev = torch.device("cpu")
         self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where the tiny collectives live
+        self.info = {"rccl_world": 1, "dist_backend": None, "rank_devices": [self.local if self.gpu else None]}
         if self.world > 1:
+            import torch.distributed as dist
             launch.init_process_group(self.backend, self.dev if self.backend == "nccl" else None)
+            # what the driver can check an N-rank run by: the size of the process group the collectives ran on and the device
+            # index every rank bound (one all_gather of an int, outside every timed region)
+            mine = torch.tensor([self.local if self.gpu else -1], dtype=torch.int64, device=self.cdev)
+            got = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(got, mine)
+            self.info = {"rccl_world": dist.get_world_size(), "dist_backend": "rccl (torch 'nccl')" if self.backend == "nccl" else "gloo",
+                         "rank_devices": [int(t[0]) if int(t[0]) >= 0 else None for t in got]}
 
     def barrier(self):
         if self.world > 1:
@@ -229,7 +242,7 @@ def bench_launch_check(args, rk):
     dt = timed(rk, lambda i: None, args.steps, lambda: None)
     s = rk.summaries(local)
     if rk.rank == 0:
-        print(json.dumps({"metric": "launch-check", "value": float(s["files"]), "unit": "files", "n_gpus": rk.world, "steps": args.steps,
+        print(json.dumps({"metric": "launch-check", "value": float(s["files"]), "unit": "files", "n_gpus": rk.world, **rk.info, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
                           "config": {"workload": "launch-check (no GPU work)", "dist_backend": rk.backend}, "summary": s}), flush=True)
@@ -382,7 +395,7 @@ def bench_ipdae(args, rk):
         res = {
             "metric": "points/sec compress+decompress (ModelNet40-shaped 8192 K=256)",
             "value": rk.world * pts / main["dt_host"], "unit": "points/s",
-            "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * main["dt_host"] / args.steps,
+            "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * main["dt_host"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "window": "host-to-host: cloud in HBM -> .s/.p/.c bytes on the host (compress.py:85-154) -> XYZ on the host "
                       "(decompress.py:77-118); kernels on one stream, copies overlapped on a copy stream",
@@ -451,7 +464,7 @@ def bench_s3dis(args, rk):
     if rk.rank == 0:
         print(json.dumps({
             "metric": "points/sec compress+decompress, room-scale clouds in 8192-pt Morton blocks", "value": n_pts * args.steps / dt,
-            "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split operands)", "data": "synthetic",
             "window": "resident; the block partition (Morton keys + torch.sort) and the inverse permutation are inside the step",
@@ -506,7 +519,7 @@ def bench_pppf(args, rk):
                            "their activation round trips through HBM rather than by the matrix pipe") + " (DESIGN.md section 7)"}
         print(json.dumps({
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
-            "unit": "points/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split operands)", "data": "synthetic",
             "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": args.matmul,
@@ -555,7 +568,7 @@ def bench_pppe_train(args, rk):
                   "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): small, launch-bound layers"}
         print(json.dumps({
             "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": rk.world * Bt * args.steps / dt,
-            "unit": "clouds/s", "points_per_s": rk.world * Bt * N_POINTS * args.steps / dt, "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "unit": "clouds/s", "points_per_s": rk.world * Bt * N_POINTS * args.steps / dt, "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
@@ -589,12 +602,15 @@ def main():
 
     from pccx import launch
     if args.gpus > 1 and not launch.launched_by_torchrun_or_us():
-        # start the N rank processes ourselves, BEFORE this process touches a GPU (device_count() does not initialise HIP)
-        if args.dist_backend == "nccl":
-            import torch
-            have = torch.cuda.device_count()
-            if have < args.gpus:
-                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (use --dist-backend gloo to rehearse the N>1 path)")
+        # Start the N rank processes ourselves.  The parent stays GPU-free: it imports neither torch nor anything that could
+        # initialise HIP (on this torch, torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi is not usable, and
+        # fork+exec from a GPU-initialised process is refused on this pool).  Whether N GPUs exist is each CHILD's check
+        # (Ranks.__init__): a rank whose LOCAL_RANK has no device exits non-zero and spawn_ranks reports that code.
+        if os.environ.get("PCCX_ASSERT_PARENT_GPU_FREE"):      # tests/test_sharding_gloo.py: prove the claim above
+            bad = [m for m in ("torch", "torch.cuda", "pccx._lib") if m in sys.modules]
+            if bad:
+                raise SystemExit("bench.py launcher parent imported " + ", ".join(bad))
+            print("[bench] launcher parent is GPU-free (no torch import)", file=sys.stderr, flush=True)
         sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     import pccx

@@ -104,6 +104,7 @@ def test_bench_self_launch_two_ranks_gloo():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["PCCX_ASSERT_PARENT_GPU_FREE"] = "1"                    # the parent exits non-zero if torch / the HIP library got imported
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload",
                         "launch-check", "--steps", "3"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -111,6 +112,8 @@ def test_bench_self_launch_two_ranks_gloo():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3
+    assert "launcher parent is GPU-free" in r.stderr           # the sentinel ran in the parent and found no torch import
+    assert j["rccl_world"] == 2 and j["dist_backend"] == "gloo" and j["rank_devices"] == [None, None]
     s = j["summary"]                                            # ranks contributed (1000, 8192, 30, 1e-4, 1, 0.5) * (r+1)-ish
     assert s["files"] == 3 and abs(s["bpp"] - 3000.0 / (3 * 8192)) < 1e-12
     assert abs(s["d1_psnr_db"] - (30.0 + 31.0) / 3) < 1e-12
@@ -126,3 +129,19 @@ def test_launcher_propagates_a_failing_rank(tmp_path):
     t0 = time.time()
     assert launch.spawn_ranks(str(script), [], 2) == 7          # rank 1 fails -> rank 0 is terminated, its code reported
     assert time.time() - t0 < 20
+
+
+def test_bench_rank_without_a_device_exits_nonzero():
+    """The launcher parent no longer counts GPUs: a rank whose LOCAL_RANK has no device must say so and exit non-zero
+    (here: no GPU at all, one rank, the rank environment set by hand as a launcher would)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() > 1:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--cpu-clouds", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
