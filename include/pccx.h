@@ -382,7 +382,13 @@ PCCX_API int pccx_sumsq_accumulate(const float *g, int64_t n, double *acc, void 
 PCCX_API int pccx_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                             const double *gnorm_sq, float max_norm, float lr, float beta1, float beta2,
                             float eps, int step, void *stream);
-/* pccx_adam_step with lr and the bias corrections read from device memory: hyper = {lr, 1 - beta1^t, 1 - beta2^t} (3 floats).
+/* Adam's per-step scalars kept on the device (torch.optim.Adam's `step` / bias_correction1/2, train_pppe_pcd_ae.py:216,220 via
+ * optimizer.step()): a 32-byte, 8-byte aligned state
+ *     float lr | float 1-beta1^t | float 1-beta2^t | int32 t | double beta1^t | double beta2^t
+ * pccx_adam_advance_dev does t += 1 and refreshes the two corrections (one thread, stream-ordered), so a captured training
+ * step carries its own step counter and a replay needs no host write. */
+PCCX_API int pccx_adam_advance_dev(float *hyper, double beta1, double beta2, void *stream);
+/* pccx_adam_step with lr and the bias corrections read from that device state (its first three floats).
  * No per-step launch argument, so the training step can be captured as a hipGraph (pccx.train.GraphedTrainStep). */
 PCCX_API int pccx_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                                 const double *gnorm_sq, float max_norm, const float *hyper, float beta1, float beta2,

@@ -57,6 +57,11 @@ def main():
             count = count.cpu().numpy()
             if (count < 0).any():
                 raise PccxError("corrupt .s.bin stream(s): " + ", ".join(n for n, k_ in zip(chunk, count) if k_ < 0))
+            if args.octree_mode == 'full' and (count == 0).any():
+                # an empty / truncated / root-bit-0 stream decodes to NO centres: there are no patches to decode the .p.bin against
+                # (S = 0 would mean zero-size launches and an empty .ply); more centres than the decoder holds come back as -1 above
+                bad = [n for n, k_ in zip(chunk, count) if k_ == 0]
+                raise PccxError("corrupt or empty .s.bin stream(s) (0 centres decoded; their .p.bin cannot be decoded): " + ", ".join(bad))
             S_of = np.full(len(chunk), 64) if args.octree_mode == 'reference' else (count if args.S is None else np.full(len(chunk), args.S))
             if args.octree_mode == 'full' and args.S is not None and (count != args.S).any():
                 raise PccxError(f"--S {args.S} given but the streams hold {sorted(set(count.tolist()))} centres")

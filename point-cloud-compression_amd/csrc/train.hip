@@ -510,6 +510,29 @@ __global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__
     }
 }
 
+// The step counter and the bias corrections live on the DEVICE: one thread advances t and recomputes 1 - beta^t.  The launch sits
+// inside the captured training step, so a replay needs no per-step host write at all (a pinned host buffer rewritten by a CPU that
+// runs several replays ahead would be read late by the queued copies).  Layout of the 32-byte state (pccx.h):
+//   float lr | float 1-b1^t | float 1-b2^t | int32 t | double b1^t | double b2^t
+__global__ void adam_advance_kernel(float *__restrict__ hyper, double b1, double b2)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int *t = (int *)(hyper + 3);
+    double *pw = (double *)(hyper + 4);
+    pw[0] *= b1; pw[1] *= b2;
+    *t += 1;
+    hyper[1] = (float)(1.0 - pw[0]);
+    hyper[2] = (float)(1.0 - pw[1]);
+}
+
+extern "C" int pccx_adam_advance_dev(float *hyper, double beta1, double beta2, void *stream)
+{
+    PCCX_CHECK_ARG(hyper && ((uintptr_t)hyper & 7) == 0, "pccx_adam_advance_dev: hyper must be an 8-byte aligned 32-byte state");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, beta1, beta2);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 extern "C" int pccx_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const double *gnorm_sq,
                                   float max_norm, const float *hyper, float beta1, float beta2, float eps, void *stream)
 {

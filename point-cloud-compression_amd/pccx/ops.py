@@ -147,17 +147,20 @@ def knn_points(p1, p2, K, return_nn=True, patch_scale=0.0):
     return KNN(dists, idx, nn)
 
 
-def ball_query(p1, p2, K, radius, method="auto"):
+def ball_query(p1, p2, K, radius, method="auto", extent=1.0):
     """pytorch3d.ops.ball_query (pointnet_sa_module.py:18): the first K candidates in index order with d2 < radius2, idx padded
     with -1.  method: "scan" = one wave per query walks the candidates in order and stops at the K-th hit; "grid" = uniform grid
     hash of the candidates (cells of side >= radius), 27-cell walk, index order restored by a bitmap; "auto" takes the grid for
-    N >= 4096 candidates (the scan's early exit wins on the few-hundred-point sets of PPPF_AE).  Same results either way."""
+    4096 <= N <= 32768 candidates when the clouds are at least four cells wide, extent / radius >= 4 (``extent`` = the callers'
+    bound on a cloud's longest side: 1.0 for this codec's normalised clouds; narrower boxes put most of the cloud in the 27-cell
+    walk and the ordered scan with its early exit at the K-th hit is faster -- as on the few-hundred-point sets of PPPF_AE).
+    Same results either way."""
     p1, p2 = _f32c(p1, "ball_query.p1"), _f32c(p2, "ball_query.p2")
     B, M, _ = p1.shape
     N = p2.shape[1]
     dists = torch.empty(B, M, K, device=p1.device, dtype=torch.float32)
     idx = torch.empty(B, M, K, device=p1.device, dtype=torch.int64)
-    if method == "grid" or (method == "auto" and 4096 <= N <= 32768):
+    if method == "grid" or (method == "auto" and 4096 <= N <= 32768 and float(extent) >= 4.0 * float(radius)):
         ws = torch.empty(_lib.load().pccx_ball_query_grid_workspace_ints(B, N), device=p1.device, dtype=torch.int32)
         _lib.call("pccx_ball_query_grid", p1.data_ptr(), B, M, p2.data_ptr(), N, int(K), float(radius), ws.data_ptr(),
                   dists.data_ptr(), idx.data_ptr(), _stream())

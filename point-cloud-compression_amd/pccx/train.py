@@ -292,23 +292,37 @@ class Adam:
         self.hyper = None           # device {lr, 1 - b1^t, 1 - b2^t}: set by make_capturable()
 
     def make_capturable(self, device):
-        """Read lr and the bias corrections from device memory (pccx_adam_step_dev) so that step() has no per-step launch
-        argument: advance() bumps t and refreshes them, step() can then sit inside a captured hipGraph."""
+        """Keep lr, the step counter and the bias corrections in DEVICE memory (pccx_adam_advance_dev / pccx_adam_step_dev), so
+        that step() has no per-step launch argument and no per-step host write: it can sit inside a captured hipGraph, and a CPU
+        that runs several replays ahead cannot race the values a queued replay reads.  The state starts from the current t."""
         if self.hyper is None:
-            self.hyper = torch.zeros(3, device=device, dtype=torch.float32)
-            self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+            import numpy as np
+            host = np.zeros(8, dtype=np.float32)                 # float lr | 1-b1^t | 1-b2^t | int32 t | double b1^t | double b2^t
+            host[0] = self.lr
+            host[1], host[2] = 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t
+            host.view(np.int32)[3] = self.t
+            host.view(np.float64)[2:4] = (self.betas[0] ** self.t, self.betas[1] ** self.t)
+            self.hyper = torch.from_numpy(host).to(device)       # one synchronous copy at set-up
         return self
 
+    def set_lr(self, lr):
+        """A new learning rate (the cosine schedule of train_pppe_pcd_ae.py:148): stream-ordered fill of the device word, the value
+        travels as a launch argument -- nothing on the host is read later."""
+        self.lr = float(lr)
+        if self.hyper is not None:
+            self.hyper[0:1].fill_(self.lr)
+
     def advance(self):
-        self.t += 1
-        self._hyper_host[0] = self.lr
-        self._hyper_host[1] = 1.0 - self.betas[0] ** self.t
-        self._hyper_host[2] = 1.0 - self.betas[1] ** self.t
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        """t += 1 on the device (and on the host mirror unless the launch is only being captured)."""
+        _lib.call("pccx_adam_advance_dev", self.hyper.data_ptr(), float(self.betas[0]), float(self.betas[1]), _stream())
+        if not torch.cuda.is_current_stream_capturing():
+            self.t += 1
 
     def step(self, max_norm=None):
         capturable = self.hyper is not None
-        if not capturable:
+        if capturable:
+            self.advance()              # eager or captured alike: the step advances its own device counter
+        else:
             self.t += 1
         live = [(p, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
         acc = None
@@ -373,7 +387,6 @@ class GraphedTrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    opt.advance()
                     self._body()
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -407,8 +420,8 @@ class GraphedTrainStep:
             self.starts[2].copy_(torch.as_tensor(starts[2]).to(self.x.device, torch.int32))
         if lam is not None:
             self.lam.fill_(float(lam))
-        self.opt.advance()
-        self.graph.replay()
+        self.graph.replay()             # carries pccx_adam_advance_dev: the device counter moves with the replay
+        self.opt.t += 1                 # host mirror
         return tuple(float(t) for t in self.out) if sync else self.out
 
 

@@ -134,6 +134,19 @@ def test_cli_compress_decompress_eval_end_to_end(tmp_path):
     for _, r in df.iterrows():
         bits = sum(os.stat(comp / (r.filename + e)).st_size * 8 for e in (".s.bin", ".p.bin", ".c.bin"))
         assert abs(r.bpp - bits / 8192) < 1e-12 and np.isfinite(r.p2pointPSNR) and r["uniformity coefficient"] > 0
+    # a truncated / empty .s.bin in --octree-mode full (S comes from the stream there): the CLI must name the file and fail,
+    # not decode S = 0 patches into an empty .ply
+    import shutil
+    bad = tmp_path / "comp_bad"
+    bad.mkdir()
+    for e in (".s.bin", ".p.bin", ".c.bin"):
+        shutil.copy(comp / (names[0] + e), bad / (names[0] + e))
+    for payload in (b"", b"\x00"):                                    # no bytes at all; a root bit of 0 (octree_np.py:16-17)
+        (bad / (names[0] + ".s.bin")).write_bytes(payload)
+        r = subprocess.run([sys.executable, os.path.join(cli, "decompress.py"), str(bad), str(tmp_path / "dec_bad"), str(mdl),
+                            "--octree-mode", "full"], capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "corrupt or empty .s.bin" in r.stderr and names[0] in r.stderr, r.stderr[-1500:]
+        assert not os.path.exists(tmp_path / "dec_bad" / names[0])
 
 
 @pytest.mark.gpu

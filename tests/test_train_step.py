@@ -319,3 +319,47 @@ def test_graphed_training_step_replays_the_eager_step():
     x2 = torch.from_numpy(synth.train_input(2, 2048)[:, ::-1].copy()).cuda()
     l3, _, _ = gs(batch_x=x2, lam=2e-3)
     assert np.isfinite(l3)
+
+
+@pytest.mark.gpu
+def test_unsynchronised_graph_replays_carry_their_own_adam_step_counter():
+    """N replays with sync=False (the CPU runs ahead of the GPU, as bench.py --workload pppe-train --graph does) against N
+    eager steps: Adam's step counter and bias corrections live on the device and advance INSIDE the captured step, so every
+    replay sees its own t (a pinned host buffer rewritten by the CPU would hand the last step's corrections to all queued
+    replays).  Also: an eager train_step on a capturable optimiser advances the same counter, and a graph captured with
+    warmup=0 starts from t = 0 without a 0/0 in lr / (1 - beta^t)."""
+    import copy
+    from pccx import families, train
+    o = _models(2048)
+    g1 = families.PointCloudAE(64, 16, 2048)
+    g1.load_state_dict(o.state_dict())
+    g1 = g1.cuda()
+    g2, g0 = copy.deepcopy(g1), copy.deepcopy(g1)
+    x = torch.from_numpy(synth.train_input(2, 2048)).cuda()
+    rng = np.random.default_rng(5)
+    starts = [[rng.integers(0, 2048, 2), rng.integers(0, 2048, 2)], rng.integers(0, 512, 2), rng.integers(0, 128, 2)]
+    opt1, opt2 = train.Adam(g1.parameters(), lr=1e-3), train.Adam(g2.parameters(), lr=1e-3)
+    gs = train.GraphedTrainStep(g2, opt2, x, starts, lam=1e-3, warmup=0)
+    n = 6
+    for _ in range(n):
+        out = gs(sync=False)                       # no host synchronisation between replays
+    torch.cuda.synchronize()
+    l2 = float(out[0])
+    for _ in range(n):
+        l1, _, _ = train.train_step(g1, opt1, x, starts, lam=1e-3)
+    st = opt2.hyper.cpu().numpy()
+    assert st.view(np.int32)[3] == n == opt2.t == opt1.t
+    assert abs(st[1] - (1 - 0.9 ** n)) < 1e-7 and abs(st[2] - (1 - 0.999 ** n)) < 1e-9 and st[0] == np.float32(1e-3)
+    assert np.isfinite(l2) and abs(l1 - l2) <= 5e-2 * abs(l1), (l1, l2)
+    # with the last step's corrections applied to every replay the first updates would be 1/(1-0.9^6) / (1/(1-0.9)) = 0.21 of
+    # Adam's; compare the parameter movement of the two runs instead of the (chaotic) values
+    mv1 = torch.cat([(p - q).flatten() for p, q in zip(g1.parameters(), g0.parameters())]).abs().mean()
+    mv2 = torch.cat([(p - q).flatten() for p, q in zip(g2.parameters(), g0.parameters())]).abs().mean()
+    assert 0.8 < float(mv2 / mv1) < 1.25, (float(mv1), float(mv2))
+    # eager steps on the capturable optimiser advance the device counter too
+    l3, _, _ = train.train_step(g2, opt2, x, starts, lam=1e-3)
+    assert np.isfinite(l3) and opt2.t == n + 1 and opt2.hyper.cpu().numpy().view(np.int32)[3] == n + 1
+    opt2.set_lr(5e-4)
+    gs(sync=False)
+    torch.cuda.synchronize()
+    assert opt2.hyper.cpu().numpy()[0] == np.float32(5e-4) and all(bool(torch.isfinite(p).all()) for p in g2.parameters())
