@@ -226,6 +226,21 @@ PCCX_API int pccx_ae_encode_b3_fused_ok(int K);
 PCCX_API int pccx_ae_encode_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
                                const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
                                float *latent_q, void *stream);
+/* The in-patch neighbour selection SetAbstraction starts with (pn_kit.py:186-190: knn_points(xyz, xyz, K=16) on each
+ * (K,3) patch) as a kernel of its own: pure vector-ALU work that runs at 8 waves per SIMD here instead of the encoder's 2.
+ * Table layout nbr[P][K][16], pccx_patch_knn16_index_bytes(K) bytes per index (1 while K <= 256, else 2), 16-byte aligned,
+ * pccx_patch_knn16_bytes(P, K) bytes in all.  Rows hold the SET of the 16 nearest points under the oracle's (distance, index)
+ * order (orc_knn); the order inside a row is unspecified (a max-pool follows, pn_kit.py:211). */
+PCCX_API int pccx_patch_knn16_index_bytes(int K);
+PCCX_API size_t pccx_patch_knn16_bytes(int P, int K);
+PCCX_API int pccx_patch_knn16(const float *patches, int P, int K, void *nbr, void *stream);
+/* pccx_ae_encode_b3 with the neighbour selection taken out into pccx_patch_knn16 (both launched from this call): the form
+ * the host layer uses.  workspace: pccx_ae_encode_b3_workspace_bytes(P, K) bytes on the device, 16-byte aligned.  Results are
+ * bit-identical to pccx_ae_encode_b3. */
+PCCX_API size_t pccx_ae_encode_b3_workspace_bytes(int P, int K);
+PCCX_API int pccx_ae_encode_b3_ws(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
+                                  const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
+                                  float *latent_q, void *workspace, void *stream);
 PCCX_API size_t pccx_dec_b3_blob_floats(int k);
 PCCX_API int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream);
 PCCX_API size_t pccx_ae_decode_b3_workspace_floats(int P);

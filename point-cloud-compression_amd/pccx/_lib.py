@@ -51,6 +51,11 @@ _SIGNATURES = {
     "pccx_pn_forward_b3": [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P],
     "pccx_ae_encode_b3_fused_ok": [C.c_int],
     "pccx_ae_encode_b3": [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P],
+    "pccx_patch_knn16_index_bytes": [C.c_int],
+    "pccx_patch_knn16_bytes": [C.c_int, C.c_int],
+    "pccx_patch_knn16": [_P, C.c_int, C.c_int, _P, _P],
+    "pccx_ae_encode_b3_workspace_bytes": [C.c_int, C.c_int],
+    "pccx_ae_encode_b3_ws": [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_dec_b3_blob_floats": [C.c_int],
     "pccx_pack_ae_decoder_b3": [_P, C.c_int, _P, _P],
     "pccx_ae_decode_b3_workspace_floats": [C.c_int],
@@ -101,7 +106,7 @@ _SIGNATURES = {
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
-_RESTYPES = {"pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
+_RESTYPES = {"pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
              "pccx_packed_linear_floats": C.c_size_t, "pccx_ball_query_grid_workspace_ints": C.c_size_t, "pccx_packed_linear_b3_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t, "pccx_pn_b3_blob_floats": C.c_size_t,
              "pccx_ae_decode_b3_workspace_floats": C.c_size_t, "pccx_planes_floats": C.c_size_t,

@@ -311,11 +311,15 @@ class AE(nn.Module):
         sa_matmul, pn_matmul = sa_matmul or _pccx_default_matmul(), pn_matmul or _pccx_default_matmul()
         if fused and sa_matmul == pn_matmul == "bf16x3" and _lib.load().pccx_ae_encode_b3_fused_ok(K):
             # one kernel, the (P,128,K) feature map never leaves the CU (csrc/encoder_fused.hip)
+            # (csrc/encoder_fused.hip); the in-patch 16-NN tables come from a kernel of their own (csrc/patch_knn.hip) through
+            # a persistent workspace: 4 KB per 256-point patch
             enc, _ = self._blobs(x.device)
+            nbytes = _lib.load().pccx_ae_encode_b3_workspace_bytes(P, K)
+            ws = workspace("patch_knn16", (nbytes + 3) // 4, x.device)
             with stage("sa_pn_forward"):
-                _lib.call("pccx_ae_encode_b3", x.data_ptr(), P, K, enc.data_ptr(), self._sa_b3_blob(x.device).data_ptr(),
+                _lib.call("pccx_ae_encode_b3_ws", x.data_ptr(), P, K, enc.data_ptr(), self._sa_b3_blob(x.device).data_ptr(),
                           self._pn_b3_blob(x.device).data_ptr(), self.d, self.L, outs[0].data_ptr(), outs[1].data_ptr(),
-                          outs[2].data_ptr(), _stream())
+                          outs[2].data_ptr(), ws.data_ptr(), _stream())
             return tuple(outs)
         ws = workspace("sa_feat", P * K * 128, x.device)
         with stage("sa_forward"):

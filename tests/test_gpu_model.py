@@ -394,3 +394,48 @@ def test_fused_encoder_kernel_equals_the_two_kernel_path_bit_for_bit(Kx, P):
         a = ae.encode(xb, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=True)
         b = ae.encode(xb, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=False)
         assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+@pytest.mark.parametrize("Kx", [256, 64, 16, 48, 512, 1024])
+def test_patch_knn16_table_equals_the_oracle_sets_and_feeds_the_fused_encoder(Kx):
+    """pccx_patch_knn16 (csrc/patch_knn.hip: the in-patch 16-NN of pn_kit.py:186-190 as its own kernel) against orc_knn on
+    patches that hit both sides of its boundary test -- a lattice (exact ties), a jittered shell (near-ties in the dropped
+    distance bits), duplicated points, random -- compared as SETS per point (a max-pool follows; the row order is unspecified);
+    and pccx_ae_encode_b3_ws (table from that kernel) against pccx_ae_encode_b3 (selection inside the encoder): bit-identical."""
+    from oracle import cport
+    from pccx import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(Kx)
+    n = Kx
+    side = int(np.ceil(n ** (1 / 3)))
+    lattice = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)
+    lattice = ((lattice[rng.permutation(len(lattice))[:n]] - side / 2) * 0.05).astype(np.float32)
+    dirs = rng.normal(size=(n - 1, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    shell = np.concatenate([np.zeros((1, 3)), dirs * (0.3 * (1.0 + rng.integers(-40, 41, size=(n - 1, 1)) * 2.0 ** -24))]).astype(np.float32)
+    dup = rng.uniform(-0.4, 0.4, size=(n // 2, 3)).astype(np.float32)
+    dup = np.concatenate([dup, dup])[rng.permutation(n)]
+    rand = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    patches = np.stack([lattice, shell, dup, rand])
+    x = torch.from_numpy(patches).cuda()
+    P = x.shape[0]
+    ib = lib.pccx_patch_knn16_index_bytes(Kx)
+    assert ib == (1 if Kx <= 256 else 2) and lib.pccx_patch_knn16_bytes(P, Kx) == P * Kx * 16 * ib
+    tab = torch.zeros(P * Kx * 16, dtype=torch.uint8 if ib == 1 else torch.int16, device="cuda")
+    _lib.call("pccx_patch_knn16", x.data_ptr(), P, Kx, tab.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = tab.cpu().numpy().astype(np.int64).reshape(P, Kx, 16)
+    for p_ in range(P):
+        _, want = cport.knn(patches[p_], patches[p_], 16)
+        assert np.array_equal(np.sort(got[p_], axis=1), np.sort(want, axis=1)), f"patch {p_}: neighbour sets differ from orc_knn"
+    if lib.pccx_ae_encode_b3_fused_ok(Kx):
+        ae = models.AE(Kx, Kx // 2, d, L)
+        ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+        ae.pack("cuda")
+        enc, _ = ae._blobs(x.device)
+        st = torch.cuda.current_stream().cuda_stream
+        a = [torch.zeros(P, d, device="cuda") for _ in range(3)]
+        b = [torch.zeros(P, d, device="cuda") for _ in range(3)]
+        _lib.call("pccx_ae_encode_b3", x.data_ptr(), P, Kx, enc.data_ptr(), ae._sa_b3_blob(x.device).data_ptr(), ae._pn_b3_blob(x.device).data_ptr(),
+                  d, L, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), st)
+        _lib.call("pccx_ae_encode_b3_ws", x.data_ptr(), P, Kx, enc.data_ptr(), ae._sa_b3_blob(x.device).data_ptr(), ae._pn_b3_blob(x.device).data_ptr(),
+                  d, L, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), tab.data_ptr(), st)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))

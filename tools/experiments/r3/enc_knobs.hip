@@ -20,7 +20,7 @@
 
 #include "blobs.h"
 #include "common.h"
-#include "mfma_chain.h"
+#include "mfma_chain_knobs.h"
 
 #define FU_STAGE_STRIDE 132                               // floats per staged point: 128 channels + 4 (bank rotation)
 #define FU_STAGE_WAVE (16 * FU_STAGE_STRIDE)              // floats per wave
@@ -45,15 +45,10 @@ __host__ __device__ inline size_t fu_lds_bytes(int K)
     return (size_t)(FU_W1_FRAGS + FU_W2_FRAGS) * 1024 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32 + fu_region_bytes() + 8 * 16 * 4 + 32;
 }
 
-// EXT_NBR: the neighbour table of every patch comes from patch_knn.hip (pccx_patch_knn16, one or two bytes per index) instead of
-// being selected here at two waves per SIMD -- the default since round 3; the in-kernel selection stays for the workspace-free
-// entry point pccx_ae_encode_b3.
-template <bool EXT_NBR>
 __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *__restrict__ x, int npatches, int K, const float *__restrict__ blob,
                                                                   const float *__restrict__ sa3, const float *__restrict__ pn3, int d,
                                                                   float spread, float half_spread, float *__restrict__ latent_raw,
-                                                                  float *__restrict__ latent, float *__restrict__ latent_q,
-                                                                  const unsigned char *__restrict__ nbr_tab)
+                                                                  float *__restrict__ latent, float *__restrict__ latent_q)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4 *sw1 = (f32x4 *)smem;
@@ -83,26 +78,6 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
     const float *xp = x + P * (size_t)K * 3;
     for (int i = tid; i < 3 * K; i += 512) sx[i] = xp[i];
     if (tid < 8) sa_next[tid] = 0;
-    if (EXT_NBR) {                                         // the patch's neighbour table, widened to the u16 rows the units read
-        if (K <= 256) {
-            const uint4 *tab = (const uint4 *)nbr_tab + P * (size_t)K;
-            for (int i = tid; i < K; i += 512) {
-                const uint4 v = tab[i];
-                const unsigned b[4] = {v.x, v.y, v.z, v.w};
-                unsigned w[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w[2 * q] = (b[q] & 0xFFu) | ((b[q] & 0xFF00u) << 8);
-                    w[2 * q + 1] = ((b[q] >> 16) & 0xFFu) | ((b[q] >> 8) & 0xFF0000u);
-                }
-                ((uint4 *)nbr16)[2 * i] = make_uint4(w[0], w[1], w[2], w[3]);
-                ((uint4 *)nbr16)[2 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-            }
-        } else {
-            const uint4 *tab = (const uint4 *)nbr_tab + P * (size_t)K * 2;
-            for (int i = tid; i < 2 * K; i += 512) ((uint4 *)nbr16)[i] = tab[i];
-        }
-    }
     __syncthreads();
 
     // ---- kNN-16 inside the patch (pn_kit.py:190), the selection of sa_forward_kernel with TWO threads per point: thread t and
@@ -115,7 +90,12 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
     while ((int)jmask < K - 1) jmask = 2u * jmask + 1u;
     unsigned *kmerge = (unsigned *)region;                 // [256][17]
     const int khalf = tid >> 8, kslot = tid & 255;
-    for (int ib = 0; ib < (EXT_NBR ? 0 : K); ib += 256) {
+#ifdef K_NO_KNN
+    for (int i = tid; i < K * 16; i += 512) nbr16[i] = (unsigned short)(((i >> 4) + (i & 15) * 7) % K);
+    __syncthreads();
+#endif
+#ifndef K_NO_KNN
+    for (int ib = 0; ib < K; ib += 256) {
         const int i = ib + kslot;
         const bool act = i < K;
         unsigned tk[17];
@@ -183,6 +163,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         }
         __syncthreads();
     }
+#endif
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (lane < 16) smax[wu][lane] = -INFINITY;            // running channel maximum of this wave, kept in LDS between passes
@@ -209,6 +190,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         // the tile the points belong to, so the hand-over reads the same layout as before -- after a barrier now.
         const int pass_base = it * 128;
         const int units = ((K - pass_base < 128 ? K - pass_base : 128) + 1) >> 1;
+#ifndef K_NO_SA
         for (;;) {
             int unit = 0;
             if (lane0 == 0) unit = atomicAdd(&sa_next[it & 7], 1);
@@ -254,6 +236,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
             }
         }
 
+#endif
         __syncthreads();                                  // every row of the pass is staged
         // ---- hand-over: the rows of this wave's tile, read back as PointNet's B operand and split into planes
         lane = lane0;
@@ -276,6 +259,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         }
         __syncthreads();                                  // every wave has its tile in registers: the region becomes the weight ring
 
+#ifndef K_NO_PN
         // ---- PointNet pass (pn_forward_b3_kernel's), ring started cold
         lane = lane0;
         asm volatile("" : "+v"(lane));
@@ -318,6 +302,9 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
             }
         }
         ws.drain();
+#else
+        f32x4 a3[1][1]; a3[0][0] = i0p[0][0][0][0] == (__bf16)1.0f ? zero4 : *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
+#endif
         if (valid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -349,56 +336,22 @@ extern "C" int pccx_ae_encode_b3_fused_ok(int K)
     return (K >= 16 && K <= 1024 && K % 16 == 0 && fu_lds_bytes(K) <= (size_t)160 * 1024) ? 1 : 0;
 }
 
-static int fu_launch(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob, const float *pn_b3_blob, int d,
-                     int L, float *latent_raw, float *latent, float *latent_q, const unsigned char *nbr_tab, hipStream_t stream)
-{
-    const float spread = (float)((double)L - 0.2);
-    const float half = (float)(((double)L - 0.2) / 2);
-    // one workgroup per CU at a time (LDS): a grid of 8 workgroups per CU, each walking P / grid patches, keeps the SetAbstraction
-    // weights staged and still balances the tail
-    const int grid = P < 2048 ? P : 2048;
-    if (nbr_tab) {
-        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_pn_forward_b3_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(sa_pn_forward_b3_kernel<true>, dim3(grid), dim3(512), fu_lds_bytes(K), stream, patches, P, K, enc_blob, sa_b3_blob,
-                           pn_b3_blob, d, spread, half, latent_raw, latent, latent_q, nbr_tab);
-    } else {
-        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_pn_forward_b3_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(sa_pn_forward_b3_kernel<false>, dim3(grid), dim3(512), fu_lds_bytes(K), stream, patches, P, K, enc_blob, sa_b3_blob,
-                           pn_b3_blob, d, spread, half, latent_raw, latent, latent_q, (const unsigned char *)nullptr);
-    }
-    PCCX_CHECK_LAUNCH();
-    return PCCX_OK;
-}
-
-#define FU_CHECK(fn)                                                                                                                   \
-    PCCX_CHECK_ARG(patches && enc_blob && sa_b3_blob && pn_b3_blob && latent_raw && latent && latent_q, fn ": null pointer");             \
-    PCCX_CHECK_ARG(P >= 0 && pccx_ae_encode_b3_fused_ok(K), fn ": K=%d does not fit the fused kernel (pccx_ae_encode_b3_fused_ok)", K); \
-    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, fn ": unsupported d=%d L=%d", d, L)
-
-// workspace-free form: the in-patch neighbour selection runs inside the kernel (round 2's shape)
 extern "C" int pccx_ae_encode_b3(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
                                  const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent, float *latent_q, void *stream)
 {
     if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    FU_CHECK("pccx_ae_encode_b3");
-    return fu_launch(patches, P, K, enc_blob, sa_b3_blob, pn_b3_blob, d, L, latent_raw, latent, latent_q, nullptr, (hipStream_t)stream);
-}
-
-// the default form: pccx_patch_knn16 (own kernel, 8 waves per SIMD) fills the neighbour table in `workspace`
-// (pccx_ae_encode_b3_workspace_bytes(P, K) bytes, 16-byte aligned), then the fused kernel reads it.  Same results, bit for bit.
-extern "C" size_t pccx_ae_encode_b3_workspace_bytes(int P, int K) { return pccx_patch_knn16_bytes(P, K); }
-
-extern "C" int pccx_ae_encode_b3_ws(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
-                                    const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent, float *latent_q,
-                                    void *workspace, void *stream)
-{
-    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    FU_CHECK("pccx_ae_encode_b3_ws");
-    PCCX_CHECK_ARG(workspace, "pccx_ae_encode_b3_ws: null workspace");
-    const int rc = pccx_patch_knn16(patches, P, K, workspace, stream);
-    if (rc != PCCX_OK) return rc;
-    return fu_launch(patches, P, K, enc_blob, sa_b3_blob, pn_b3_blob, d, L, latent_raw, latent, latent_q, (const unsigned char *)workspace,
-                     (hipStream_t)stream);
+    PCCX_CHECK_ARG(patches && enc_blob && sa_b3_blob && pn_b3_blob && latent_raw && latent && latent_q, "pccx_ae_encode_b3: null pointer");
+    PCCX_CHECK_ARG(P >= 0 && pccx_ae_encode_b3_fused_ok(K), "pccx_ae_encode_b3: K=%d does not fit the fused kernel (pccx_ae_encode_b3_fused_ok)", K);
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode_b3: unsupported d=%d L=%d", d, L);
+    const float spread = (float)((double)L - 0.2);
+    const float half = (float)(((double)L - 0.2) / 2);
+    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_pn_forward_b3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+    // one workgroup per CU at a time (LDS): a grid of 8 workgroups per CU, each walking P / grid patches, keeps the SetAbstraction
+    // weights staged and still balances the tail
+    const int grid = P < 2048 ? P : 2048;
+    hipLaunchKernelGGL(sa_pn_forward_b3_kernel, dim3(grid), dim3(512), fu_lds_bytes(K), (hipStream_t)stream, patches, P, K, enc_blob,
+                       sa_b3_blob, pn_b3_blob, d, spread, half, latent_raw, latent, latent_q);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
 }

@@ -1,0 +1,375 @@
+// mfma_chain.h -- fp32 MFMA building blocks for the per-point MLP stacks (gfx950).
+//
+// The reference's 1x1 Conv / Linear stacks (pn_kit.py:98-144,146-211,263-305; AE.py:19-27,96-105)
+// are evaluated TRANSPOSED: activations are the B operand (k = channel, n = point), weights the A
+// operand (m = output channel).  With v_mfma_f32_16x16x4_f32 the C/D tile then has
+//     lane (g = lane>>4, n = lane&15), register r  <->  output channel 16*mt + 4*g + r of point n
+// which is exactly the B-operand lane map of the NEXT layer's k-tile kt = mt, step r
+// (B[k = lane>>4][n = lane&15], with the k order inside a 16-channel tile permuted to 4*g + r on
+// both operands).  A whole Conv-ReLU-Conv-... chain therefore runs out of registers: no LDS round
+// trip and no lane shuffles between layers; bias is the accumulator's initial value and ReLU is
+// one v_max per register.  f32-in MFMA is bit-for-bit a k-ordered fmaf chain, so the arithmetic
+// is plain fp32 (no TF32/bf16 anywhere on the path to the quantiser).
+//
+// Weight fragment layout ("packed", built once at model load by pccx/weights.py):
+//     Wp[kt][mt][lane][r] = W[16*mt + (lane&15)][16*kt + 4*(lane>>4) + r]      (zero padded)
+// so one 16-byte load per lane feeds 4 MFMAs and a wave's load is 1 KiB contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v)
+{
+    f32x4 o;
+    o[0] = fmaxf(v[0], 0.f); o[1] = fmaxf(v[1], 0.f); o[2] = fmaxf(v[2], 0.f); o[3] = fmaxf(v[3], 0.f);
+    return o;
+}
+
+// acc[nt][mt] += W[kt0..kt0+KT)[mt0..mt0+MT) * in[nt][kt]   for NT point tiles sharing the A fragments.
+// `w` (wave-uniform, so loads use the scalar-base + lane-offset form) points at fragment (kt=0, mt=0); WMT = number of m-tiles in the
+// packed layer (row stride of the fragment table).
+template <int KT, int MT, int NT, int WMT, bool SWAP = false>
+__device__ __forceinline__ void dense_acc(const f32x4 *__restrict__ w, int lane, const f32x4 (&in)[NT][KT],
+                                          f32x4 (&acc)[NT][MT], int kt0 = 0, int mt0 = 0)
+{
+    // Fragments are consumed in groups of MG m-tiles of one k-tile: consecutive MFMAs then hit
+    // different accumulators (dependent-accumulator latency of 16x16x4_f32 is 40 cycles against a
+    // 32-cycle issue).  The loads of group i+1 are issued ahead of group i's MFMAs and pinned there
+    // with sched_barrier: left alone, hipcc hoists every fragment load of the unrolled chain to the
+    // top and spills thousands of registers.
+    //
+    // SWAP exchanges the MFMA operands (the A and B lane maps of 16x16x4 are mirror images, so the
+    // same registers serve either way): the tile comes out transposed, D[point][channel], i.e.
+    // lane (g, j) register r holds channel 16*mt + j of point 4*g + r.  Used for a chain's LAST layer
+    // when a max over the 16 points follows: it becomes an in-lane max over 4 registers plus two
+    // cross-row steps instead of a 16-lane reduction per register.
+    constexpr int MG = MT >= 4 ? 4 : MT;
+    static_assert(MT % MG == 0, "MT must be a multiple of the m-group");
+    constexpr int GPK = MT / MG;          // groups per k-tile
+    constexpr int NG = KT * GPK;
+    const char *wb = (const char *)w;     // wave-uniform base: loads take the scalar-base + lane-offset form
+    const unsigned voff = (unsigned)lane * 16u;
+    f32x4 cur[MG], nxt[MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) cur[m] = *(const f32x4 *)(wb + (size_t)(kt0 * WMT + mt0 + m) * 1024 + voff);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / GPK, m0 = (gi % GPK) * MG;
+        if (gi + 1 < NG) {
+            const int kt_n = (gi + 1) / GPK, m0_n = ((gi + 1) % GPK) * MG;
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+                nxt[m] = *(const f32x4 *)(wb + (size_t)((kt0 + kt_n) * WMT + mt0 + m0_n + m) * 1024 + voff);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? mfma16(in[nt][kt][r], cur[m][r], acc[nt][m0 + m])
+                                           : mfma16(cur[m][r], in[nt][kt][r], acc[nt][m0 + m]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m) cur[m] = nxt[m];
+    }
+}
+
+// Max over the 16 points of EIGHT transposed tiles (dense_acc<..., SWAP=true> outputs, lane (g, j)
+// register r = channel 16*t + j of point 4*g + r), as a transpose-reduce: in-lane max over the 4
+// registers, then v_permlane32_swap / v_permlane16_swap pair the lane groups so that each swap+max
+// finishes two tiles at once.  Result: out[s] (s = 0,1) in lane (row, j) is the max of channel
+// 16*(2*row + s) + j.  ~30 VALU instead of ~400 for the 16-lane DPP reduction per register.
+__device__ __forceinline__ void max16_of_8_transposed_tiles(const f32x4 (&t)[8], float (&out)[2])
+{
+    float p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = fmaxf(fmaxf(t[i][0], t[i][1]), fmaxf(t[i][2], t[i][3]));
+    float u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // lanes 0-31 finish tile i over rows {0,2},{1,3}; lanes 32-63 tile i+4
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[i]), __float_as_uint(p[i + 4]), false, false);
+        u[i] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {       // row0: tile s, row1: tile s+2, row2: tile s+4, row3: tile s+6
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[s]), __float_as_uint(u[s + 2]), false, false);
+        out[s] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16x3 operands: fp32 products formed on the bf16 matrix cores from three bf16
+// pieces per operand (x = hi + mid + lo exactly), the six products of weight i + j <= 4 accumulated in fp32.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// In-register split of two fp32 C tiles (8 values per lane = one K=32 B operand) into the three bf16 planes:
+// v_cvt_pk_bf16_f32 (round to nearest even), widen back, exact residual, twice.
+__device__ __forceinline__ void b3_split8(const f32x4 &v0, const f32x4 &v1, bf16x8 (&pl)[3])
+{
+#ifdef K_NOSPLIT
+    pl[0] = __builtin_bit_cast(bf16x8, v0); pl[1] = __builtin_bit_cast(bf16x8, v1); pl[2] = __builtin_bit_cast(bf16x8, v0);
+    return;
+#endif
+    unsigned w[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2v x = q < 2 ? f32x2v{v0[2 * q], v0[2 * q + 1]} : f32x2v{v1[2 * q - 4], v1[2 * q - 3]};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const bf16x2 h = __builtin_convertvector(x, bf16x2);
+            w[p][q] = __builtin_bit_cast(unsigned, h);
+            if (p < 2) x = x - __builtin_convertvector(h, f32x2v);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pl[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+}
+
+// dense layer on bf16x3 operands with the weight blocks RESIDENT in LDS as [kt][mt][plane] fragments (K = 32 per kt).
+// SWAP exchanges the MFMA operands (the lane maps of 16x16x32 mirror each other like those of 16x16x4): the tile comes out
+// transposed, D[point][channel].
+template <int KT, int MT, int NT, bool SWAP = false>
+__device__ __forceinline__ void dense_b3(const f32x4 *w, int lane, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    bf16x8 cur[MG][3], nxt[MG][3];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[m][p] = __builtin_bit_cast(bf16x8, w[(size_t)(m * 3 + p) * 64 + lane]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+#ifdef K_SA_NOLDSW
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = cur[m][p];
+#else
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = __builtin_bit_cast(bf16x8, w[(size_t)(((gi + 1) * MG + m) * 3 + p) * 64 + lane]);
+        }
+#endif
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(in[nt][kt][PB[q]], cur[m][PA[q]], acc[nt][m0 + m], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight stream through LDS.  When every wave of a workgroup consumes the SAME fragment sequence
+// (PointNet: each wave runs the whole layer stack on its own 16 points), the sequence is packed on
+// the host in consumption order and streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4, one
+// 1 KiB fragment per wave-instruction, no VGPRs), one CH-fragment chunk ahead of the MFMAs (CH = 8 measured
+// best on MI355X: 16 costs 1 %, 32 costs 3 %, 4 equals 8):
+//   * L2 -> CU traffic drops by the number of waves sharing the stream,
+//   * MFMAs read fragments with short, uniform LDS latency instead of exposed L2 latency.
+// Protocol per chunk c (all waves in lock step, ONE barrier per chunk):
+//   s_waitcnt vmcnt(0)   own DMA of chunk c has landed
+//   __syncthreads()      everyone's has, and everyone finished reading chunk c-1's buffer
+//   issue DMA of chunk c+1 into that buffer; run the MFMAs of chunk c.
+// The fragment counter is a plain int that constant-folds after full unrolling, so the chunk hook
+// costs nothing between boundaries.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+
+// NB buffers of CH fragments: the DMA of chunk c + NB - 1 is issued at the boundary of chunk c into the buffer chunk c - 1
+// has just vacated (NB = 2: one chunk ahead).
+template <int CH, int NB = 2, int NW = 4>
+struct WStreamT {
+    const float *g;                       // global stream, NCH * CH fragments, wave-uniform
+    f32x4 *lds;                           // [NB][CH][64]
+    int nch;                              // chunks per pass (a multiple of NB when wrap)
+    int lane, wave;
+    bool wrap;                            // several passes over the same stream
+
+    __device__ __forceinline__ void issue(int c, int buf) const
+    {
+        // NW waves x CH/NW fragments: wave w moves fragments (CH/NW)w .. of the chunk.  Source address =
+        // wave-uniform fragment base (scalar registers) + lane*16 (one VGPR shared by every DMA).
+        static_assert(CH % NW == 0, "chunk must divide over the waves");
+        const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int q = 0; q < CH / NW; ++q) {
+            const int fr = wave * (CH / NW) + q;               // wave is scalar (readfirstlane)
+            const char *src = (const char *)g + ((size_t)c * CH + fr) * 1024;
+            f32x4 *dst = lds + (buf * CH + fr) * 64;          // wave-uniform; hardware adds lane*16
+#ifndef K_NODMA
+            __builtin_amdgcn_global_load_lds((const void *)(src + voff), (lds_u32 *)(uintptr_t)dst, 16, 0, 0);
+#endif
+        }
+    }
+    __device__ __forceinline__ void prologue() const
+    {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) issue(i, i);
+    }
+    __device__ __forceinline__ void issue_ahead(int c) const
+    {
+        const int n = c + NB - 1;
+        if (n < nch) issue(n, n % NB);
+        else if (wrap) issue(n - nch, n % NB);      // next pass starts over
+    }
+    __device__ __forceinline__ void boundary(int c) const     // before the first read of chunk c
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef K_NOBAR
+        __syncthreads();
+#endif
+        issue_ahead(c);
+    }
+    // boundary that may leave the wave's N most recent VMEM loads in flight: the caller guarantees that the DMA of
+    // chunk c was issued before them (in-order completion)
+    template <int N>
+    __device__ __forceinline__ void boundary_keep(int c) const
+    {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        __syncthreads();
+        issue_ahead(c);
+    }
+    __device__ __forceinline__ const f32x4 *chunk(int c) const { return lds + (c % NB) * CH * 64 + lane; }
+    __device__ __forceinline__ f32x4 get(int f) const         // fragment f of the current pass
+    {
+        if ((f % CH) == 0) boundary(f / CH);
+        return lds[(((f / CH) % NB) * CH + (f % CH)) * 64 + lane];
+    }
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// dense_acc fed from a WStream: fragments are taken in stream order (kt-major, m inner), `f` is the
+// running fragment index of the pass.
+template <int KT, int MT, int NT, bool SWAP = false, class WS>
+__device__ __forceinline__ void dense_acc_stream(const WS &ws, int &f, const f32x4 (&in)[NT][KT], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 4 ? 4 : MT;
+    static_assert(MT % MG == 0, "MT must be a multiple of the m-group");
+    constexpr int GPK = MT / MG;
+    constexpr int NG = KT * GPK;
+    f32x4 cur[MG], nxt[MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) cur[m] = ws.get(f + m);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / GPK, m0 = (gi % GPK) * MG;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) nxt[m] = ws.get(f + (gi + 1) * MG + m);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? mfma16(in[nt][kt][r], cur[m][r], acc[nt][m0 + m])
+                                           : mfma16(cur[m][r], in[nt][kt][r], acc[nt][m0 + m]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m) cur[m] = nxt[m];
+    }
+    f += NG * MG;
+}
+
+// Launders a wave-uniform pointer through an empty asm so loads through it are not treated as
+// loop-invariant: weights do not depend on the point-tile loop, and without this hipcc's LICM hoists
+// every fragment load of the chain out of that loop and parks the lot in scratch.
+template <class T>
+__device__ __forceinline__ const T *opaque_uniform(const T *p)
+{
+    unsigned zero = 0;                      // an offset the optimiser cannot see through keeps the
+    asm volatile("" : "+s"(zero));          // pointer's global address space (no flat loads)
+    return p + zero;
+}
+
+// max over the 16 lanes of a DPP row (the n index of a C/D tile); every lane ends with the max.
+__device__ __forceinline__ float row16_max(float v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true);   // row_mirror
+    v = fmaxf(v, __int_as_float(t));
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v = fmaxf(v, __int_as_float(t));
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x1B, 0xf, 0xf, true);    // quad_perm [3,2,1,0]
+    v = fmaxf(v, __int_as_float(t));
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(t));
+    return v;
+}
+
+// dense layer of the chain on bf16x3 operands: in[nt][kt][plane] are K=32 B operands, the weight blocks ([kt][mt][plane],
+// three 1 KiB A fragments each) come from the LDS ring in stream order; six products per block, two blocks in flight.
+template <int KT, int MT, int NT, class WS>
+__device__ __forceinline__ void dense_b3_stream(const WS &ws, int &f, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
+{
+    constexpr int CHK = 24;
+    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    bf16x8 cur[MG][3], nxt[MG][3];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * m + p));
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+#ifdef K_PN_NOLDSW
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { if (((f + 3 * ((gi + 1) * MG + m) + p) % CHK) == 0 && gi + 1 < NG) ws.boundary((f + 3 * ((gi + 1) * MG + m) + p) / CHK); nxt[m][p] = cur[m][p]; }
+#else
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = __builtin_bit_cast(bf16x8, ws.get(f + 3 * ((gi + 1) * MG + m) + p));
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
+    }
+    f += 3 * KT * MT;
+}
+
