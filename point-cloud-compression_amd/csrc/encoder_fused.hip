@@ -22,6 +22,12 @@
 #include "common.h"
 #include "mfma_chain.h"
 
+#ifndef FU_CHUNK
+#define FU_CHUNK PN_B3_CHUNK                             // fragments per ring chunk of the PointNet weight stream
+#endif
+#ifndef FU_NB
+#define FU_NB 2                                          // ring buffers (chunks in flight + the one being read)
+#endif
 #define FU_STAGE_STRIDE 132                               // floats per staged point: 128 channels + 4 (bank rotation)
 #define FU_STAGE_WAVE (16 * FU_STAGE_STRIDE)              // floats per wave
 #define FU_W1_FRAGS (1 * 4 * 3)
@@ -37,7 +43,7 @@ __device__ __forceinline__ unsigned fu_umed3(unsigned a, unsigned b, unsigned c)
 // LDS map (bytes): [sw1 12 KiB][sw2 48 KiB][sb1 256][sb2 512][sx 12K][nbr 32K][region: max(ring 48 KiB, 8 staging blocks)]
 __host__ __device__ inline size_t fu_region_bytes()
 {
-    const size_t ring = (size_t)2 * PN_B3_CHUNK * 1024, stage = (size_t)8 * FU_STAGE_WAVE * 4;
+    const size_t ring = (size_t)FU_NB * FU_CHUNK * 1024, stage = (size_t)8 * FU_STAGE_WAVE * 4;
     return ring > stage ? ring : stage;
 }
 __host__ __device__ inline size_t fu_lds_bytes(int K)
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         asm volatile("" : "+v"(lane));
         g = lane >> 4; n = lane & 15;
         blob = opaque_uniform(blob);
-        WStreamT<PN_B3_CHUNK, 2, 8> ws{opaque_uniform(pn3), swt, (PN_B3_STREAM_FRAGS + PN_B3_CHUNK - 1) / PN_B3_CHUNK, lane, wu, false};   // data chunks only
+        WStreamT<FU_CHUNK, FU_NB, 8> ws{opaque_uniform(pn3), swt, (PN_B3_STREAM_FRAGS + FU_CHUNK - 1) / FU_CHUNK, lane, wu, false};   // data chunks only
         ws.prologue();
         int f = 0;                                        // fragment cursor of this pass (constant-folds)
         f32x4 a0[1][8];

@@ -140,10 +140,12 @@ def test_reference_loop_bodies_call_for_call_through_compat(nets, matmul_mode):
     bad = q != o["latent_q"]
     assert (np.abs(o["latent"][bad] - np.floor(o["latent"][bad]) - 0.5) < 1e-4).all()
     assert isinstance(p_stream, bytes) and len(p_stream) > 0
-    if not bad.any():
-        ci = ref_model.cdf_float_to_int(cdf).reshape(-1, L + 1)
-        if np.array_equal(ci, o["cdf_int"]):
-            assert p_stream == o["p"]                                          # .p.bin byte-identical with the oracle coder
+    # .p.bin byte-identical with the oracle coder, unconditionally: the oracle's range encoder on the integer CDF torchac's
+    # conversion gives for THIS float CDF and on THESE symbols (with the oracle's CDF and symbols that is o["p"] itself)
+    ci = ref_model.cdf_float_to_int(cdf).reshape(-1, L + 1)
+    assert p_stream == cport.range_encode(ci, n_latent_quantized.numpy().reshape(-1))
+    if not bad.any() and np.array_equal(ci, o["cdf_int"]):
+        assert p_stream == o["p"]
 
     # ---------------- decompress.py:77-116
     with torch.no_grad():
@@ -177,7 +179,10 @@ def test_reference_loop_bodies_call_for_call_through_compat(nets, matmul_mode):
     comp = codec.Codec(ae, prob, K=K).compress(torch.from_numpy(pc_np)[None].cuda(), [start], keep_extras=True)
     s2, p2, c2 = comp.files(0)
     assert s2 == bytes(s_stream) and c2 == c_stream
-    if np.array_equal(comp.extras["latent_q"].cpu().numpy(), q):
+    q2 = comp.extras["latent_q"].cpu().numpy()
+    ci2 = comp.extras["cdf_int"][0].cpu().numpy().reshape(-1, L + 1)
+    assert p2 == cport.range_encode(ci2, (q2.reshape(-1) + L // 2).astype(np.int16))          # unconditional: coder byte-identity
+    if np.array_equal(q2, q) and np.array_equal(ci2, ci):
         assert p2 == p_stream
 
 

@@ -77,8 +77,12 @@ def test_decoder_matches_golden(nets):
     out = ae.decode(lq)
     np.testing.assert_allclose(out.cpu().numpy(), md["dec_out"], rtol=1e-4, atol=2e-5)
     rec, latent, q = ae(torch.from_numpy(synth.patch_batch(K)).cuda())
-    if np.array_equal(q.cpu().numpy(), md["ae_latent_q"]):
-        np.testing.assert_allclose(rec.cpu().numpy(), md["ae_recon"], rtol=1e-4, atol=2e-5)
+    same = (q.cpu().numpy() == md["ae_latent_q"]).all(axis=1)                  # patches whose 16 symbols all equal the reference's
+    assert same.mean() >= 0.9, "too few patches reproduce the reference's symbols for the reconstruction fixture to apply"
+    np.testing.assert_allclose(rec.cpu().numpy()[same], md["ae_recon"][same], rtol=1e-4, atol=2e-5)
+    with torch.no_grad():                                                       # every patch, against the oracle fed the GPU's symbols
+        want = nets[2].decode(q.cpu())
+    np.testing.assert_allclose(rec.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
 
 
 def test_prob_model_matches_golden(nets):

@@ -51,8 +51,15 @@ def build(tags):
         if p.returncode != 0:
             print(err[-3000:])
             raise SystemExit(f"variant {t} failed to build")
-        keep = [l.split("remark:")[-1].strip() for l in err.splitlines() if "sa_pn_forward" in l or "VGPRs:" in l or "Spill" in l or "ScratchSize" in l or "Occupancy" in l or "LDS Size" in l]
-        print(t, "|", "; ".join(keep[:8]))
+        cur, rows = None, {}
+        for l in err.splitlines():
+            m = l.split("remark:")[-1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+            if m.startswith("Function Name:"):
+                cur = m.split(":")[1].strip()
+                rows[cur] = []
+            elif cur and any(k in m for k in ("VGPRs:", "VGPRs Spill", "ScratchSize")):
+                rows[cur].append(m.replace(" [bytes/lane]", ""))
+        print(t, "|", " || ".join(f"{k[-28:]}: " + ", ".join(v) for k, v in rows.items() if "sa_pn" in k or "variant" in k))
 
 
 def run(clouds, tags):

@@ -157,7 +157,7 @@ __device__ __forceinline__ void dense_b3(const f32x4 *w, int lane, const bf16x8 
 #pragma unroll
             for (int m = 0; m < MG; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) nxt[m][p] = cur[m][p];
+                for (int p = 0; p < 3; ++p) { nxt[m][p] = cur[m][p]; asm volatile("" : "+v"(nxt[m][p])); }
 #else
         if (gi + 1 < NG) {
 #pragma unroll
@@ -347,7 +347,7 @@ __device__ __forceinline__ void dense_b3_stream(const WS &ws, int &f, const bf16
 #pragma unroll
             for (int m = 0; m < MG; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { if (((f + 3 * ((gi + 1) * MG + m) + p) % CHK) == 0 && gi + 1 < NG) ws.boundary((f + 3 * ((gi + 1) * MG + m) + p) / CHK); nxt[m][p] = cur[m][p]; }
+                for (int p = 0; p < 3; ++p) { if (((f + 3 * ((gi + 1) * MG + m) + p) % CHK) == 0 && gi + 1 < NG) ws.boundary((f + 3 * ((gi + 1) * MG + m) + p) / CHK); nxt[m][p] = cur[m][p]; asm volatile("" : "+v"(nxt[m][p])); }
 #else
         if (gi + 1 < NG) {
 #pragma unroll
