@@ -68,61 +68,27 @@ __global__ __launch_bounds__(256, B3 ? 2 : 3) void sa_forward_kernel(const float
     }
     __syncthreads();
 
-    // ---- phase 1: kNN-16 inside the patch (pn_kit.py:190, K=16).  Only the SET matters (max-pool).
-    // Fast path, one pass: the candidate index rides in the low bits of the distance (key = distance bits with
-    // the low log2(K) bits replaced by j; distances are >= 0 so their bit patterns order like the floats), and 17
-    // sorted keys are kept with one v_med3_u32 per slot per candidate.  Truncation is monotone, so whenever the
-    // 16th and 17th keys differ in their distance part every selected candidate is strictly nearer than every
-    // other one and the 16 indices are exactly the oracle's set.  Otherwise (a tie or near-tie at the boundary)
-    // the lane takes the exact two-pass selection: 16 smallest distances by v_med3_f32, then the indices below
-    // the 16th distance plus ties at it in index order -- the oracle's (distance, index) sort.
-    unsigned jmask = 15u;
-    while ((int)jmask < K - 1) jmask = 2u * jmask + 1u;
-    for (int i = tid; i < K; i += 256) {
-        const float px = sx[3 * i], py = sx[3 * i + 1], pz = sx[3 * i + 2];
-        unsigned tk[17];
+    // ---- phase 1: the 16 nearest points of every point inside the patch (pn_kit.py:190, K=16; only the SET matters, a max-pool
+    // follows).  Selected by patch_knn.hip (its own kernel at 8 waves per SIMD; round 2 selected here, at this kernel's 2-3 waves
+    // per SIMD, where the vector-ALU-only phase cost 4 ms per 1024 clouds).  launch_sa parks the table of patch P at the head of
+    // patch P's OWN slice of `feat` (K x 16 or 32 bytes of its K x 512): read it into LDS before the first feature row is written.
+    {
+        const unsigned char *tab = (const unsigned char *)(feat + P * (size_t)K * 128);
+        if (K <= 256) {
+            for (int i = tid; i < K; i += 256) {
+                const uint4 v = ((const uint4 *)tab)[i];
+                const unsigned b[4] = {v.x, v.y, v.z, v.w};
+                unsigned wd[8];
 #pragma unroll
-        for (int s = 0; s < 17; ++s) tk[s] = 0xFFFFFFFFu;
-        for (int j0 = 0; j0 < K; j0 += 4) {              // K % 16 == 0; four broadcast reads in flight
-            float d[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                d[u] = pccx_sqdist(px, py, pz, sx[3 * (j0 + u)], sx[3 * (j0 + u) + 1], sx[3 * (j0 + u) + 2]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned key = (__float_as_uint(d[u]) & ~jmask) | (unsigned)(j0 + u);
-#pragma unroll
-                for (int s = 16; s >= 1; --s) tk[s] = umed3(tk[s - 1], key, tk[s]);
-                tk[0] = min(tk[0], key);
+                for (int q = 0; q < 4; ++q) {
+                    wd[2 * q] = (b[q] & 0xFFu) | ((b[q] & 0xFF00u) << 8);
+                    wd[2 * q + 1] = ((b[q] >> 16) & 0xFFu) | ((b[q] >> 8) & 0xFF0000u);
+                }
+                ((uint4 *)nbr16)[2 * i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                ((uint4 *)nbr16)[2 * i + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
             }
-        }
-        if (((tk[15] ^ tk[16]) & ~jmask) != 0u) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) nbr16[i * 16 + s] = (unsigned short)(tk[s] & jmask);
-            continue;
-        }
-        float td[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) td[s] = INFINITY;
-        for (int j = 0; j < K; ++j) {
-            const float d = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
-#pragma unroll
-            for (int s = 15; s >= 1; --s) td[s] = __builtin_amdgcn_fmed3f(td[s - 1], d, td[s]);
-            td[0] = fminf(td[0], d);
-        }
-        const float T = td[15];
-        int need = 16;                                   // ties at T to take = 16 - #(d < T)
-#pragma unroll
-        for (int s = 0; s < 16; ++s) need -= td[s] < T ? 1 : 0;
-        int c = 0, ties = 0;
-        for (int j = 0; j < K; ++j) {
-            const float d = pccx_sqdist(px, py, pz, sx[3 * j], sx[3 * j + 1], sx[3 * j + 2]);
-            const bool tie = d == T;
-            if (d < T || (tie && ties < need)) {
-                if (c < 16) nbr16[i * 16 + c] = (unsigned short)j;
-                ++c;
-            }
-            ties += tie ? 1 : 0;
+        } else {
+            for (int i = tid; i < 2 * K; i += 256) ((uint4 *)nbr16)[i] = ((const uint4 *)tab)[i];
         }
     }
     __syncthreads();
@@ -408,9 +374,14 @@ __global__ __launch_bounds__(512, 1) void pn_forward_b3_kernel(const float *__re
     }
 }
 
+int pccx_patch_knn16_strided(const float *patches, int P, int K, void *nbr, size_t patch_stride, hipStream_t stream);   // patch_knn.hip
+
 static int launch_sa(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob, float *feat, hipStream_t st)
 {
     const bool b3 = sa_b3_blob != nullptr;
+    // the neighbour tables, one per patch, at the head of each patch's slice of the feature map (see the kernel's phase 1)
+    const int rc = pccx_patch_knn16_strided(patches, P, K, feat, (size_t)K * 128 * sizeof(float), st);
+    if (rc != PCCX_OK) return rc;
     const size_t sa_lds = (size_t)(SA_W1_FRAGS(b3) + SA_W2_FRAGS(b3)) * 64 * 16 + (64 + 128) * 4 + (size_t)K * 12 + (size_t)K * 32;
     if (b3) {
         PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_forward_kernel<true>),

@@ -23,7 +23,8 @@ __device__ __forceinline__ unsigned pk_umed3(unsigned a, unsigned b, unsigned c)
 }
 
 template <typename IDX>
-__global__ __launch_bounds__(256) void patch_knn16_kernel(const float *__restrict__ x, int npatches, int K, IDX *__restrict__ nbr)
+__global__ __launch_bounds__(256) void patch_knn16_kernel(const float *__restrict__ x, int npatches, int K, unsigned char *__restrict__ nbr_bytes,
+                                                          size_t patch_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float sx[];      // [3K]
     const int tid = threadIdx.x;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void patch_knn16_kernel(const float *__restric
                 }
             }
             // 16 (or 32) contiguous bytes per point: one (two) 16-byte store(s)
-            uint4 *dst = (uint4 *)(nbr + (P * (size_t)K + i) * 16);
+            uint4 *dst = (uint4 *)(nbr_bytes + P * patch_stride + (size_t)i * 16 * sizeof(IDX));
             if (sizeof(IDX) == 1) {
                 unsigned w[4];
 #pragma unroll
@@ -112,19 +113,27 @@ extern "C" size_t pccx_patch_knn16_bytes(int P, int K)
     return (size_t)(P > 0 ? P : 0) * (size_t)(K > 0 ? K : 0) * 16 * (size_t)pccx_patch_knn16_index_bytes(K);
 }
 
+// patch_stride: bytes between the tables of consecutive patches (>= K * 16 * index bytes, a multiple of 16).  The unfused
+// SetAbstraction kernels park each patch's table at the head of that patch's own slice of the feature map, which they overwrite
+// only after reading it (encoder.hip).
+int pccx_patch_knn16_strided(const float *patches, int P, int K, void *nbr, size_t patch_stride, hipStream_t stream)
+{
+    // 8 workgroups of 4 waves per CU fill the 32 wave slots; no state is kept between patches, so the grid is one workgroup per
+    // patch up to 64 per CU
+    const int grid = P < 256 * 64 ? P : 256 * 64;
+    if (K <= 256)
+        hipLaunchKernelGGL(patch_knn16_kernel<uint8_t>, dim3(grid), dim3(256), (size_t)K * 12, stream, patches, P, K, (unsigned char *)nbr, patch_stride);
+    else
+        hipLaunchKernelGGL(patch_knn16_kernel<uint16_t>, dim3(grid), dim3(256), (size_t)K * 12, stream, patches, P, K, (unsigned char *)nbr, patch_stride);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 extern "C" int pccx_patch_knn16(const float *patches, int P, int K, void *nbr, void *stream)
 {
     if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(patches && nbr, "pccx_patch_knn16: null pointer");
     PCCX_CHECK_ARG(P >= 0 && K >= 16 && K <= 1024 && K % 16 == 0, "pccx_patch_knn16: need K %% 16 == 0, 16 <= K <= 1024 (K=%d)", K);
     PCCX_CHECK_ARG(((uintptr_t)nbr & 15) == 0, "pccx_patch_knn16: the table must be 16-byte aligned");
-    // 8 workgroups of 4 waves per CU fill the 32 wave slots; a few patches per workgroup amortise nothing (no state is kept
-    // between patches), so the grid is simply one workgroup per patch up to 16 per CU resident-and-queued
-    const int grid = P < 256 * 64 ? P : 256 * 64;
-    if (K <= 256)
-        hipLaunchKernelGGL(patch_knn16_kernel<uint8_t>, dim3(grid), dim3(256), (size_t)K * 12, (hipStream_t)stream, patches, P, K, (uint8_t *)nbr);
-    else
-        hipLaunchKernelGGL(patch_knn16_kernel<uint16_t>, dim3(grid), dim3(256), (size_t)K * 12, (hipStream_t)stream, patches, P, K, (uint16_t *)nbr);
-    PCCX_CHECK_LAUNCH();
-    return PCCX_OK;
+    return pccx_patch_knn16_strided(patches, P, K, nbr, (size_t)K * 16 * (size_t)pccx_patch_knn16_index_bytes(K), (hipStream_t)stream);
 }
