@@ -166,6 +166,80 @@ def cpu_baseline(max_clouds, budget_s):
             "one_thread": {"value": n1 * N_POINTS / tot1, "unit": "points/s", "cores": 1, "sample": f"{n1} clouds", "ms_per_cloud": 1e3 * tot1 / n1}}
 
 
+def cpu_baseline_blocks(blocks, starts, budget_s):
+    """configs[3] beside the GPU number: the CPU restatement of the reference loop (oracle/ref_pipeline.py) on a bounded sample of the
+    SAME 8192-point Morton blocks the GPU leg compresses (handed over from the device: the partition itself, one sort per room, is not
+    re-done on the CPU), compress + decompress windows as in cpu_baseline()."""
+    import torch
+    from oracle import ref_model, ref_pipeline
+    ae = ref_model.AE(K_PATCH, K_SMALL, D_LAT, L_LEV).eval()
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, AE_SEED, last_gain=AE_LAST_GAIN))
+    prob = ref_model.ConditionalProbabilityModel(L_LEV, D_LAT).eval()
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, PROB_SEED, gain=PROB_GAIN))
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ref_pipeline.compress_one(blocks[0], ae, prob, int(starts[0]))                    # warm-up, discarded
+    tot, n, bits, psnr, t0 = 0.0, 0, 0, 0.0, time.time()
+    while n < len(blocks) and (n < 2 or time.time() - t0 < budget_s):
+        o, tc = ref_pipeline.compress_one(blocks[n], ae, prob, int(starts[n]))
+        rec, td = ref_pipeline.decompress_one(o["s"], o["p"], o["c"], ae, prob)
+        tot += tc + td
+        bits += 8 * (len(o["s"]) + len(o["p"]) + len(o["c"]))
+        psnr += ref_pipeline.d1_psnr(blocks[n], rec)
+        n += 1
+    return {"value": n * N_POINTS / tot, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"the first {n} of the GPU leg's 8192-point Morton blocks (room 0), compress+decompress windows of compress.py:85-154 / "
+                      f"decompress.py:77-118 per block, CPU restatement of the reference loop (torch CPU fp32 + C oracle); partition not re-done",
+            "ms_per_block": 1e3 * tot / n, "bpp": bits / (n * N_POINTS), "d1_psnr_db": psnr / n}
+
+
+def cpu_baseline_pppf(state_dict, patches, Kp, budget_s):
+    """configs[2] beside the GPU number: the oracle's PPPF_AE forward (oracle/ref_families.py, torch CPU fp32, eval mode) on a bounded
+    sample of the same patches, 8 patches (one cloud) per call as the reference's patch loop feeds the model."""
+    import torch
+    from oracle import ref_families
+    m = ref_families.PPPF_AE(K=Kp, k=Kp // ALPHA, d=16, L=7).eval()
+    m.load_state_dict(state_dict)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    x = patches.cpu()
+    with torch.no_grad():
+        m(x[:8])                                                                     # warm-up, discarded
+        tot, n, t0 = 0.0, 0, time.time()
+        while n + 8 <= x.shape[0] and (n < 16 or time.time() - t0 < budget_s):
+            t1 = time.time()
+            m(x[n:n + 8])
+            tot += time.time() - t1
+            n += 8
+    return {"value": n * Kp / tot, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"the first {n} of the GPU leg's {Kp}-point patches, PPPF_AE forward (encode + decode) 8 patches per call, CPU restatement of "
+                      f"PPPF_AE.py:114-150 (torch CPU fp32)", "ms_per_patch": 1e3 * tot / n}
+
+
+def cpu_baseline_pppe_train(state_dict, x, starts, budget_s):
+    """configs[4] beside the GPU number: the oracle's training iteration (oracle/ref_train.py: torch autograd + torch.optim.Adam on the
+    restated PointCloudAE) on the same batch; the brute-force Chamfer of an 8192-point cloud makes one step seconds long, so the sample
+    is a few steps (at least one after the warm-up)."""
+    import torch
+    from oracle import ref_families, ref_train
+    m = ref_families.PointCloudAE(64, 16, N_POINTS)
+    m.load_state_dict(state_dict)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    xb = x.cpu()
+    ref_train.train_step(m, opt, xb, starts, lam=1e-3)                               # warm-up, discarded
+    tot, n, t0 = 0.0, 0, time.time()
+    while n < 1 or time.time() - t0 < budget_s:
+        t1 = time.time()
+        loss, _, _ = ref_train.train_step(m, opt, xb, starts, lam=1e-3)
+        tot += time.time() - t1
+        n += 1
+    return {"value": n * xb.shape[0] / tot, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": f"{n} optimisation step(s) on the GPU leg's batch of {xb.shape[0]} x {N_POINTS} points, CPU restatement of "
+                      f"train_pppe_pcd_ae.py:184-226 without autocast (torch autograd + torch.optim.Adam)", "ms_per_step": 1e3 * tot / n, "loss": loss}
+
+
 # =====================================================================================================================
 # distributed plumbing
 # =====================================================================================================================
@@ -450,7 +524,12 @@ def bench_s3dis(args, rk):
         keep["out"] = large.decompress_large_many(cd, parts, metas)
     for _ in range(args.warmup):
         step(0)
+    from pccx import ops
+    timer = ops.StageTimer()
+    ops.set_timer(timer)
     dt = timed(rk, step, args.steps, torch.cuda.synchronize)
+    ops.set_timer(None)
+    stages = {k_: (ms / n_, n_) for k_, (ms, n_) in timer.totals_ms().items()}
     # quality, outside the timed region: bits of this rank's blocks and their block-level D1 (a block's decoded rows are a set;
     # with world > 1 a rank holds only its own blocks' rows, so the per-room D1 is replaced by the mean over blocks)
     bits = psnr_sum = blocks = pts = 0.0
@@ -462,6 +541,19 @@ def bench_s3dis(args, rk):
         pts += len(ids) * flat.shape[1]
     summ = rk.summaries([bits, pts, psnr_sum, 0.0, blocks, dt])
     if rk.rank == 0:
+        # the dominant kernel is the fused encoder, as in the headline workload: its launches here cover `blocks_per_launch` blocks
+        # (the last one of a step fewer), so the FLOPs of a launch are taken from the mean number of patches per launch
+        n_launch = max(stages[max((k_ for k_ in STAGE_FLOP if k_ in stages), key=lambda k_: stages[k_][0] * stages[k_][1])][1] // args.steps, 1)
+        rf, per_step_ms, _ = roofline_of(stages, args.steps, int(blocks) * S_PATCH / n_launch, args.matmul, int(blocks) / n_launch)
+        rf["note"] += f"; mean over {n_launch} launches per step of <= {args.batch} blocks x {S_PATCH} patches"
+        cpu = None
+        if rk.world == 1 and args.cpu_clouds > 0:
+            try:
+                from pccx import dist as pdist
+                nb0 = min(int(keep["metas"][0][1]), 64)
+                cpu = cpu_baseline_blocks(flat[:nb0].cpu().numpy(), [pdist.fps_start_index(11, j, N_POINTS) for j in range(nb0)], args.cpu_budget / 2)
+            except Exception as e:
+                cpu = {"error": repr(e)}
         print(json.dumps({
             "metric": "points/sec compress+decompress, room-scale clouds in 8192-pt Morton blocks", "value": n_pts * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -470,7 +562,9 @@ def bench_s3dis(args, rk):
             "window": "resident; the block partition (Morton keys + torch.sort) and the inverse permutation are inside the step",
             "config": {"workload": f"S3DIS-like rooms (configs[3]): {args.rooms} rooms, {n_pts} points, IPDAE K=256 per 8192-pt block",
                        "sharding": f"block-sharded x{rk.world}", "matmul": args.matmul, "blocks_per_launch": args.batch},
-            "roofline": None, "cpu_baseline": None, "bpp_padded_blocks": summ["bpp"], "d1_psnr_db_blockwise": summ["d1_psnr_db"],
+            "roofline": rf, "stage_ms_per_step": {k_: round(v, 4) for k_, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
+            "cpu_baseline": cpu, "gpu_over_cpu": (n_pts * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None,
+            "bpp_padded_blocks": summ["bpp"], "d1_psnr_db_blockwise": summ["d1_psnr_db"],
             "blocks": int(summ["files"])}), flush=True)
 
 
@@ -506,6 +600,12 @@ def bench_pppf(args, rk):
     dt = timed(rk, lambda i: keep.__setitem__("o", model(patches)), args.steps, torch.cuda.synchronize)
     flop = families.pppf_flops_per_patch(model) if hasattr(families, "pppf_flops_per_patch") else None
     if rk.rank == 0:
+        cpu = None
+        if rk.world == 1 and args.cpu_clouds > 0:
+            try:
+                cpu = cpu_baseline_pppf(model.state_dict(), patches[:min(patches.shape[0], 256)], Kp, args.cpu_budget / 2)
+            except Exception as e:
+                cpu = {"error": repr(e)}
         rf = None
         if flop:
             ach = flop * B * S * args.steps / dt / 1e12
@@ -524,7 +624,8 @@ def bench_pppf(args, rk):
             "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split operands)", "data": "synthetic",
             "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": args.matmul,
                        "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
-            "roofline": rf, "cpu_baseline": None}), flush=True)
+            "roofline": rf, "cpu_baseline": cpu,
+            "gpu_over_cpu": (rk.world * B * S * Kp * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None}), flush=True)
 
 
 def bench_pppe_train(args, rk):
@@ -539,6 +640,7 @@ def bench_pppe_train(args, rk):
     for k, v in model.state_dict().items():                  # sane BatchNorm statistics
         if k.endswith("running_var"):
             v.fill_(1.0)
+    sd0 = {k_: v.detach().clone() for k_, v in model.state_dict().items()}          # the CPU leg starts from the same weights
     model = model.to(rk.dev)
     opt = train.Adam(model.parameters(), lr=1e-3)
     x = torch.from_numpy(np.stack([synth.cad_cloud(900 + rk.rank * Bt + i, N_POINTS) for i in range(Bt)])).to(rk.dev)
@@ -559,6 +661,12 @@ def bench_pppe_train(args, rk):
             train.train_step(model, opt, x, starts, **kw)
         dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), args.steps, torch.cuda.synchronize)
     if rk.rank == 0:
+        cpu = None
+        if rk.world == 1 and args.cpu_clouds > 0:
+            try:
+                cpu = cpu_baseline_pppe_train(sd0, x, starts, args.cpu_budget / 2)
+            except Exception as e:
+                cpu = {"error": repr(e)}
         flop = train.step_flops(model, Bt) if hasattr(train, "step_flops") else None
         rf = None
         if flop:
@@ -573,7 +681,8 @@ def bench_pppe_train(args, rk):
             "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
                        "launch": "one hipGraph replay per step" if args.graph else "eager (about 600 launches per step)"},
-            "roofline": rf, "cpu_baseline": None, "loss": keep["o"][0]}), flush=True)
+            "roofline": rf, "cpu_baseline": cpu,
+            "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": keep["o"][0]}), flush=True)
 
 
 def main():
