@@ -344,6 +344,15 @@ PCCX_API int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t 
                                        int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
                                        const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream);
 
+/* out[r][c] = act(base[r / div][c] + sum_{k<Ks} x[(mod ? r % mod : r)][k] * w[c][k]), Ks <= 4, C % 4 == 0: the per-point part of a
+ * layer whose input rows are [small per-point part | long per-patch part] (FoldingNet's [grid | latent] and [coarse | latent],
+ * PPPF_AE.py:99-107); base = the per-patch part's Linear (bias included), one row per patch.  w is (C, Ks) row-major. */
+PCCX_API int pccx_rows_affine_small(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod,
+                                    const float *w, int relu, int64_t M, float *out, void *stream);
+/* torch.max(knn_gather(y, idx.clamp(min=0)), nsample_dim)[0] without the gathered tensor (pointnet_sa_module.py:27-28,91):
+ * y (B,N,C) fp32 rows, idx (B,M,ns) int64 with -1 padding -> out (B,M,C).  C % 4 == 0.  With it PointnetSAModule (which gathers
+ * un-centred rows, :73-85) runs its Conv-BN-ReLU stack on the N source rows once instead of on M*ns copies of them. */
+PCCX_API int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream);
 /* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
  * x (G,Kn,C) -> out (G,C). */
 PCCX_API int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream);

@@ -323,6 +323,131 @@ __global__ void group_max_kernel(const float *__restrict__ x, long long G, int K
     }
 }
 
+// out[b][g][c] = max_s y[b][max(idx[b][g][s], 0)][c]: torch.max over nsample of knn_gather(features, idx.clamp(min=0))
+// (pointnet_sa_module.py:27-28,91) WITHOUT the (B, M, nsample, C) tensor.  It is what makes the de-duplicated PointnetSAModule
+// possible (families.PointnetSAModule.run): that module gathers features and xyz un-centred, so every grouped row is a copy of a
+// source row and the Conv-BN(eval)-ReLU stack needs to run on the N source rows only; the groups then take their maxima from the
+// (B, N, C) result.  Workgroup = (cloud b, chunk of channels): the chunk of all N rows sits in LDS (<= 64 KB), a thread owns four
+// channels of one group and walks the group's nsample indices (16-byte LDS reads, rows contiguous: conflict-free within a group).
+// LDS-bound by design: 4 B read per (group, sample, channel); N too large for LDS reads through L2 instead.
+// out[r][c] = act(base[r / div][c] + sum_{k < Ks} x[(mod ? r % mod : r)][k] * w[c][k]),  Ks <= 4.
+// The first layer of FoldingNet's two MLPs (PPPF_AE.py:99-107) acts on [grid | latent] and [coarse | latent] rows whose 1024-wide
+// latent part is the SAME for the 256 points of a patch: W [a ; latent] = W_a a + (W_lat latent + bias), so the latent part is one
+// row per patch (a Linear on B rows, `base`) and what is left per point is this 2- or 3-term update -- instead of a K = 1026 / 1027
+// product on every one of the B x 256 rows (0.8 of the decoder's matrix work) and the planes of their concatenation (3 GB per 2048
+// patches).  fp32 fmaf chain on top of base; not bit-identical to the single long dot product (summation order), well inside the
+// 1e-5 parity bar of the family tests.
+__global__ __launch_bounds__(256) void rows_affine_small_kernel(const float *__restrict__ base, int C, long long div, const float *__restrict__ x,
+                                                               int ldx, int Ks, long long mod, const float *__restrict__ w, int relu,
+                                                               long long M, float *__restrict__ out)
+{
+    const int c4n = C >> 2;
+    const long long total = M * c4n;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+        const long long r = it / c4n;
+        const int c = (int)(it - r * c4n) * 4;
+        const float *xr = x + (mod ? r % mod : r) * ldx;
+        float4 v = *(const float4 *)(base + (r / div) * C + c);
+        float a[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < Ks; ++k) {
+            const float xk = xr[k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fmaf(xk, w[(size_t)(c + u) * Ks + k], a[u]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fmaxf(a[u], 0.f);
+        }
+        *(float4 *)(out + r * C + c) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+extern "C" int pccx_rows_affine_small(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                      int relu, int64_t M, float *out, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(base && x && w && out, "pccx_rows_affine_small: null pointer");
+    PCCX_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0 && Ks >= 1 && Ks <= 4 && ldx >= Ks && div >= 1 && mod >= 0,
+                   "pccx_rows_affine_small: bad arguments (C=%d Ks=%d)", C, Ks);
+    long long blocks = (M * (C >> 2) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(rows_affine_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, base, C, (long long)div, x, ldx, Ks,
+                       (long long)mod, w, relu, (long long)M, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+#define GM_THREADS 1024                    // 2 workgroups of 64 KB per CU = all 32 wave slots: the walk is a chain of dependent reads
+template <bool LDS_TILE>
+__global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__restrict__ y, int N, int C, const int64_t *__restrict__ idx, int M,
+                                                                int ns, int chunk, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float gm_tile[];
+    const int b = blockIdx.y, c0 = blockIdx.x * chunk, tid = threadIdx.x;
+    const int cw = min(chunk, C - c0), q4 = chunk >> 2;                      // chunk % 4 == 0, C % 4 == 0
+    const float4 *y4 = (const float4 *)(y + (size_t)b * N * C + c0);
+    const int ldy4 = C >> 2;
+    if (LDS_TILE) {
+        float4 *t4 = (float4 *)gm_tile;
+        for (int i = tid; i < N * q4; i += GM_THREADS) {
+            const int row = i / q4, q = i - row * q4;
+            if (4 * q < cw) t4[i] = y4[(size_t)row * ldy4 + q];
+        }
+        __syncthreads();
+    }
+    const float4 *t4 = (const float4 *)gm_tile;
+    for (int it = tid; it < M * q4; it += GM_THREADS) {
+        const int g = it / q4, q = it - g * q4;
+        if (4 * q >= cw) continue;
+        const int64_t *ig = idx + ((size_t)b * M + g) * ns;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int s_ = 0;
+        for (; s_ + 8 <= ns; s_ += 8) {                                       // eight index loads in flight, then eight row reads
+            long long j[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) j[u] = ig[s_ + u];
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long jj = j[u] < 0 ? 0 : j[u];                     // idx.clamp(min=0), pointnet_sa_module.py:27
+                v[u] = LDS_TILE ? t4[(int)jj * q4 + q] : y4[(size_t)jj * ldy4 + q];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w); }
+        }
+        for (; s_ < ns; ++s_) {
+            long long jj = ig[s_];
+            jj = jj < 0 ? 0 : jj;
+            const float4 v = LDS_TILE ? t4[(int)jj * q4 + q] : y4[(size_t)jj * ldy4 + q];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+        ((float4 *)(out + ((size_t)b * M + g) * C + c0))[q] = m;
+    }
+}
+
+extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream)
+{
+    if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(y && idx && out, "pccx_gather_max: null pointer");
+    PCCX_CHECK_ARG(B > 0 && N >= 1 && M >= 1 && ns >= 1 && C >= 4 && C % 4 == 0, "pccx_gather_max: bad shape B=%d N=%d C=%d M=%d ns=%d (C %% 4 == 0)",
+                   B, N, C, M, ns);
+    PCCX_CHECK_ARG(B <= 65535, "pccx_gather_max: B=%d exceeds the grid's y dimension", B);
+    int chunk = (int)((size_t)65536 / ((size_t)N * 4)) & ~3;                  // channels of all N rows in 64 KB
+    if (chunk > C) chunk = C;
+    if (chunk >= 16) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_max_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           64 * 1024));
+        hipLaunchKernelGGL(gather_max_kernel<true>, dim3((C + chunk - 1) / chunk, B), dim3(GM_THREADS), (size_t)N * chunk * 4, (hipStream_t)stream, y,
+                           N, C, idx, M, ns, chunk, out);
+    } else {
+        chunk = C < 256 ? C : 256;                                            // rows through L2: a workgroup per 256 channels
+        hipLaunchKernelGGL(gather_max_kernel<false>, dim3((C + chunk - 1) / chunk, B), dim3(GM_THREADS), 0, (hipStream_t)stream, y, N, C, idx, M,
+                           ns, chunk, out);
+    }
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 extern "C" int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream)
 {
     if (G == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null

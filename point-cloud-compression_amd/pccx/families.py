@@ -261,6 +261,25 @@ def run_stack(stack, x):
     return x
 
 
+def rows_affine_small(base, div, x, mod, w_small, relu, M):
+    """act(base[r // div] + x[r % mod if mod else r] @ w_small.T) for r < M (pccx_rows_affine_small): base (B, C), x (.., Ks <= 4)."""
+    x = x.contiguous()
+    Cc, Ks = int(base.shape[-1]), int(w_small.shape[1])
+    out = torch.empty(M, Cc, device=base.device, dtype=torch.float32)
+    _lib.call("pccx_rows_affine_small", base.contiguous().data_ptr(), Cc, int(div), x.data_ptr(), int(x.shape[-1]), Ks, int(mod),
+              w_small.data_ptr(), int(bool(relu)), int(M), out.data_ptr(), _stream())
+    return out
+
+
+def gather_max(y, idx):
+    """max over nsample of y[b, idx.clamp(min=0)] (pointnet_sa_module.py:27-28,91): y (B,N,C) rows, idx (B,M,ns) int64 -> (B,M,C)."""
+    B, N, Cc = y.shape
+    _, M, ns = idx.shape
+    out = torch.empty(B, M, Cc, device=y.device, dtype=torch.float32)
+    _lib.call("pccx_gather_max", y.contiguous().data_ptr(), B, N, Cc, idx.contiguous().data_ptr(), M, ns, out.data_ptr(), _stream())
+    return out
+
+
 def group_max(x):
     """(G,Kn,C) -> (G,C)."""
     G, Kn, Cc = x.shape
@@ -320,11 +339,22 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
             last = out
         self.mlp = nn.Sequential(*layers)
 
+    # The module gathers features and xyz UN-CENTRED (:73-85) and its Conv-BN(eval)-ReLU stack acts on each (group, sample) row by
+    # itself, so every one of the npoint * nsample grouped rows is a copy of one of the N source rows: the stack is evaluated on
+    # the N rows once and each group takes the maximum over its members from that result (pccx_gather_max) -- the same fp32 chain
+    # per row, hence bit-identical outputs, for 1 / (npoint * nsample / N) of the matrix work (PPPF_AE: 16384 -> 512, 8192 -> 512,
+    # 4096 -> 128 rows per patch).  dedup=False keeps the literal grouped evaluation (tests compare the two bit for bit).
+    dedup = True
+
     def run(self, stack, xyz, feats):
         """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C'))."""
         B = xyz.shape[0]
         new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)                   # :66-68 (start index 0)
         idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
+        if self.dedup and B > 0 and stack[-1].N % 4 == 0:
+            rows = cat_rows([feats, xyz] if feats is not None else [xyz])           # :83 features first, xyz last, one row per SOURCE point
+            y = run_stack(stack, rows)                                              # :90 Conv-BN-ReLU, (B * N, C) rows
+            return new_xyz, gather_max(y.view(B, xyz.shape[1], -1), idx)            # :91 max over the group's members
         if stack[0].mode() == "bf16x3" and self.nsample in (32, 64, 128) and B > 0:
             # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue
             if getattr(self, "_chain_of", None) is not stack:                       # new pack -> new stream
@@ -360,6 +390,8 @@ class FoldingNet(nn.Module):                            # PPPF_AE.py:50-80
 class PPPF_AE(_Packable):
     """PPPF_AE.PPPF_AE (PPPF_AE.py:114-150)."""
 
+    split_fold = True       # FoldingNet's first layers evaluated as per-patch + per-point parts (forward()); False = the literal rows
+
     def __init__(self, K=512, k=0, d=16, L=7, dim=1024):
         super().__init__()
         self.L, self.d, self.dim = L, d, dim
@@ -375,6 +407,11 @@ class PPPF_AE(_Packable):
                             enc=FoldedLinear(self.enc_proj.weight, self.enc_proj.bias, False, None, device),
                             dec=FoldedLinear(self.dec_proj.weight, self.dec_proj.bias, False, None, device),
                             mlp1=_fold_stack(dcd.mlp1, device), mlp2=_fold_stack(dcd.mlp2, device))
+        # first layers of the two folding MLPs split into their per-patch (latent) and per-point (grid / coarse) parts, see forward()
+        for name, seq, ks in (("mlp1", dcd.mlp1, 2), ("mlp2", dcd.mlp2, 3)):
+            w = seq[0].weight.detach().to("cpu", torch.float32).reshape(seq[0].weight.shape[0], -1)
+            self._packed[name + "_lat"] = FoldedLinear(w[:, ks:], seq[0].bias, False, None, device)
+            self._packed[name + "_small"] = w[:, :ks].contiguous().to(device)
         x = torch.linspace(-1, 1, dcd.grid_size)
         gx, gy = torch.meshgrid(x, x, indexing="ij")
         self._packed["grid"] = torch.stack([gx, gy], dim=-1).reshape(-1, 2).to(device)            # :82-88
@@ -394,9 +431,17 @@ class PPPF_AE(_Packable):
         q = round_(pk["enc"](latent))                                               # :139-142
         lat_dec = pk["dec"](q)                                                      # :145
         P = self.decoder.num_points
+        if self.split_fold and B > 0 and pk["mlp1"][0].N % 4 == 0 and pk["mlp2"][0].N % 4 == 0:
+            # The folding inputs [grid | latent] and [coarse | latent] (:99-106) are never built: their 1024-wide latent part is the
+            # same for the P points of a patch, so the first layer of each MLP is W_lat latent + bias once per PATCH (a Linear on B
+            # rows) plus a 2- / 3-term per-point update with ReLU (pccx_rows_affine_small); the remaining layers run on the P rows.
+            h = rows_affine_small(pk["mlp1_lat"](lat_dec), P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P)
+            x = run_stack(pk["mlp1"][1:], h)                                                                 # :104 coarse
+            h = rows_affine_small(pk["mlp2_lat"](lat_dec), P, x, 0, pk["mlp2_small"], pk["mlp2"][0].relu, B * P)
+            x = run_stack(pk["mlp2"][1:], h)                                                                 # :107 fine
+            return x.view(B, P, 3), latent, q
         if pk["mlp1"][0].mode() == "bf16x3" and B > 0:
-            # the folding inputs [grid | latent] and [coarse | latent] (:99-106) go straight to operand planes: nothing is
-            # concatenated or repeated in memory
+            # the literal form on operand planes: nothing is concatenated or repeated in memory either
             x = run_stack_planes(pk["mlp1"], fold_planes(pk["grid"], P, lat_dec, P, B * P), B * P)          # :104 coarse
             x = run_stack_planes(pk["mlp2"], fold_planes(x, 0, lat_dec, P, B * P), B * P)                   # :107 fine
             return x.view(B, P, 3), latent, q
@@ -408,17 +453,27 @@ class PPPF_AE(_Packable):
         return x.view(B, P, 3), latent, q
 
 
-def pppf_flops_per_patch(model):
-    """Algorithmic FLOPs (2 * MACs of every Conv / Linear, rows x in x out) of one PPPF_AE forward on one patch."""
+def pppf_flops_per_patch(model, executed=False, n_points=512):
+    """FLOPs (2 * MACs of every Conv / Linear, rows x in x out) of one PPPF_AE forward on one patch of n_points points.
+    executed=False: as the reference evaluates it, every set-abstraction stack on its npoint x nsample grouped rows
+    (pointnet_sa_module.py:86-90).  executed=True: what this implementation runs -- the stacks on the source rows only
+    (PointnetSAModule.dedup), everything else unchanged."""
     if model._packed is None:
         raise _lib.PccxError("pppf_flops_per_patch: pack() the model first")
     pk, e = model._packed, model.encoder
-    macs = 0
+    macs, n_src = 0, n_points
     for mod, stack in zip((e.sa1, e.sa2, e.sa3), pk["sa"]):
-        macs += sum(mod.npoint * mod.nsample * l.N * l.K for l in stack)
+        rows = n_src if (executed and mod.dedup) else mod.npoint * mod.nsample
+        macs += sum(rows * l.N * l.K for l in stack)
+        n_src = mod.npoint
     macs += pk["enc"].N * pk["enc"].K + pk["dec"].N * pk["dec"].K
     P = model.decoder.num_points
-    macs += sum(P * l.N * l.K for l in pk["mlp1"]) + sum(P * l.N * l.K for l in pk["mlp2"])
+    for name, ks in (("mlp1", 2), ("mlp2", 3)):
+        st = pk[name]
+        if executed and model.split_fold:
+            macs += st[0].N * (st[0].K - ks) + P * st[0].N * ks + sum(P * l.N * l.K for l in st[1:])
+        else:
+            macs += sum(P * l.N * l.K for l in st)
     return 2 * macs
 
 

@@ -100,6 +100,46 @@ def test_pppf_ae_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets, matm
 
 
 @pytest.mark.gpu
+def test_pointnet_sa_module_on_source_rows_equals_the_grouped_evaluation_bit_for_bit(oracle_nets, matmul_mode):
+    """PointnetSAModule gathers features and xyz un-centred (pointnet_sa_module.py:73-85), so each grouped row is a copy of a source
+    row: families.PointnetSAModule evaluates its Conv-BN-ReLU stack on the N source rows and takes every group's maximum from that
+    (pccx_gather_max).  Against the literal evaluation on all npoint x nsample gathered rows (dedup=False): IDENTICAL latents,
+    symbols and reconstructions, on the fixture input and on a sparse batch whose balls are padded with -1 (-> row 0, :27)."""
+    from pccx import families
+    m, _ = oracle_nets
+    g = families.PPPF_AE(512, 0, 16, 7)
+    g.load_state_dict(m.state_dict())
+    rng = np.random.default_rng(7)
+    for x in (synth.pppf_input(), (rng.random((5, 512, 3)) * 1.6).astype(np.float32)):
+        xc = torch.from_numpy(x).cuda()
+        a = g(xc)
+        try:
+            families.PointnetSAModule.dedup = False
+            b = g(xc)
+        finally:
+            families.PointnetSAModule.dedup = True
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    # FoldingNet's first layers as per-patch + per-point parts (PPPF_AE.split_fold) against the literal 1026- / 1027-wide rows:
+    # the same numbers up to the summation order of one long dot product
+    xc = torch.from_numpy(synth.pppf_input()).cuda()
+    a = g(xc)
+    try:
+        families.PPPF_AE.split_fold = False
+        b = g(xc)
+    finally:
+        families.PPPF_AE.split_fold = True
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=2e-6, rtol=1e-5)
+    # the gather-max kernel alone against torch, LDS-tiled and through-L2 forms, -1 padding, ragged channel chunks
+    for (B, N, Cc, M, ns) in ((3, 128, 1024, 32, 128), (2, 512, 128, 512, 32), (2, 20000, 8, 7, 5), (1, 512, 260, 9, 64)):
+        y = torch.from_numpy(rng.normal(size=(B, N, Cc)).astype(np.float32)).cuda()
+        idx = torch.from_numpy(rng.integers(-1, N, size=(B, M, ns))).cuda()
+        want = torch.gather(y[:, None].expand(B, M, N, Cc), 2, idx.clamp(min=0)[..., None].expand(B, M, ns, Cc)).amax(dim=2)
+        assert torch.equal(families.gather_max(y, idx), want)
+
+
+@pytest.mark.gpu
 def test_pppe_forward_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets, matmul_mode):
     from pccx import families
     _, p = oracle_nets
