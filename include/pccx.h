@@ -384,6 +384,14 @@ PCCX_API int pccx_bn_relu_forward(const float *Z, int64_t M, int C, const float 
 PCCX_API int pccx_bn_relu_backward(const float *dY, const float *Y, const float *Z, int64_t M, int C,
                                    const float *mean, const float *rstd, const float *gamma, double *sums,
                                    float *dZ, float *g_gamma, float *g_beta, void *stream);
+/* nn.Linear on 1..8 rows (the pppe model's global, decoder and probability Linears at batch 4, pppe_pcd_ae.py:655-714, :739-802):
+ * out (M, N) = act(x (M, K) . W^T + b) and dX (M, K) += dZ (M, N) . W straight from the row-major W (N, K), each W row read once
+ * (a weight stream, not matrix work; no packed copy).  flags as pccx_linear (bit 0 ReLU, bit 1 autocast rounding).  K % 4 == 0;
+ * dX is zeroed by the caller. */
+PCCX_API int pccx_linear_skinny(const float *x, int M, int K, int ldx, const float *W, const float *bias, int N, int flags,
+                                float *out, int ldo, void *stream);
+PCCX_API int pccx_linear_skinny_dx(const float *dZ, int M, int N, int ldz, const float *W, int K, int flags, float *dX, int ldd,
+                                   void *stream);
 PCCX_API int pccx_col_sum(const float *dY, int64_t M, int C, double *sums, float *g_bias, void *stream);
 PCCX_API int pccx_relu_backward(const float *dY, const float *Y, int64_t n, float *dZ, void *stream);
 PCCX_API int pccx_group_max_arg(const float *x, int64_t G, int Kn, int C, float *out, int32_t *arg,

@@ -139,6 +139,121 @@ extern "C" int pccx_linear_dw(const float *dZ, const float *X, int64_t M, int N,
     return launch_dw<1, 1>(dZ, X, M, N, K, ldz, ldx, dW, flags, (hipStream_t)stream);
 }
 
+// ---- layers with a handful of rows (the pppe model's global / decoder / probability Linears: M = batch = 4) ---------------------
+// out[m][n] = act(sum_k x[m][k] W[n][k] + b[n]) and dX[m][k] = sum_n dZ[m][n] W[n][k] for M <= 8 rows straight from the UNPACKED
+// row-major W (N, K): these products are weight streams (the 24576 x 1024 expansion layer is 100 MB), not matrix work.  The generic
+// MFMA layer walks K serially per workgroup (one exposed L2 / HBM latency per k-tile: 2.2 ms for that layer's dX at 256
+// workgroups); here every W row is read once, coalesced, by a wave (forward) or by n-chunks of a split-K grid (dX, fp32 atomics
+// into a zeroed dX like the other gradient kernels), and no packed copy of W is made.  bf16 = the autocast rounding of linear_kernel.
+__device__ __forceinline__ float sk_bf16(float v) { return (float)(__bf16)v; }
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float *__restrict__ x, int M, int K, int ldx, const float *__restrict__ W,
+                                                        const float *__restrict__ bias, int N, int relu, float *__restrict__ out, int ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;                                                // whole wave
+    const float4 *w4 = (const float4 *)(W + (size_t)n * K);
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    for (int k4 = lane; k4 < (K >> 2); k4 += 64) {
+        float4 wv = w4[k4];
+        if (BF16) { wv.x = sk_bf16(wv.x); wv.y = sk_bf16(wv.y); wv.z = sk_bf16(wv.z); wv.w = sk_bf16(wv.w); }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m < M) {
+                float4 xv = *(const float4 *)(x + (size_t)m * ldx + 4 * k4);
+                if (BF16) { xv.x = sk_bf16(xv.x); xv.y = sk_bf16(xv.y); xv.z = sk_bf16(xv.z); xv.w = sk_bf16(xv.w); }
+                acc[m] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (m < M) {
+            float v = acc[m];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) {
+                v += bias ? bias[n] : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                out[(size_t)m * ldo + n] = BF16 ? sk_bf16(v) : v;
+            }
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void skinny_dx_kernel(const float *__restrict__ dz, int M, int N, int ldz, const float *__restrict__ W, int K,
+                                                       int rows_per_chunk, float *__restrict__ dx, int ldd)
+{
+    const int k4 = blockIdx.x * 256 + threadIdx.x;
+    if (4 * k4 >= K) return;
+    const int n0 = blockIdx.y * rows_per_chunk, n1 = min(n0 + rows_per_chunk, N);
+    float4 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = n0; n < n1; ++n) {
+        float4 wv = *(const float4 *)(W + (size_t)n * K + 4 * k4);
+        if (BF16) { wv.x = sk_bf16(wv.x); wv.y = sk_bf16(wv.y); wv.z = sk_bf16(wv.z); wv.w = sk_bf16(wv.w); }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m < M) {
+                float d = dz[(size_t)m * ldz + n];                     // wave-uniform
+                if (BF16) d = sk_bf16(d);
+                acc[m].x = fmaf(d, wv.x, acc[m].x); acc[m].y = fmaf(d, wv.y, acc[m].y);
+                acc[m].z = fmaf(d, wv.z, acc[m].z); acc[m].w = fmaf(d, wv.w, acc[m].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (m < M) {
+            float *o = dx + (size_t)m * ldd + 4 * k4;
+            atomicAdd(o, acc[m].x); atomicAdd(o + 1, acc[m].y); atomicAdd(o + 2, acc[m].z); atomicAdd(o + 3, acc[m].w);
+        }
+    }
+}
+
+extern "C" int pccx_linear_skinny(const float *x, int M, int K, int ldx, const float *W, const float *bias, int N, int flags, float *out,
+                                  int ldo, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(x && W && out, "pccx_linear_skinny: null pointer");
+    PCCX_CHECK_ARG(M >= 1 && M <= 8 && K >= 4 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && N >= 1 && ldo >= N && ((uintptr_t)x & 15) == 0 &&
+                       ((uintptr_t)W & 15) == 0,
+                   "pccx_linear_skinny: needs 1 <= M <= 8 rows, K %% 4 == 0 and 16-byte aligned rows (M=%d K=%d ldx=%d)", M, K, ldx);
+    if (flags & 2)
+        hipLaunchKernelGGL(skinny_fwd_kernel<true>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, W, bias, N, flags & 1, out, ldo);
+    else
+        hipLaunchKernelGGL(skinny_fwd_kernel<false>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, M, K, ldx, W, bias, N, flags & 1, out, ldo);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// dX (M, K) += dZ (M, N) . W (N, K); dX must be zeroed by the caller (partial sums of the n-chunks are added atomically).
+extern "C" int pccx_linear_skinny_dx(const float *dZ, int M, int N, int ldz, const float *W, int K, int flags, float *dX, int ldd, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dZ && W && dX, "pccx_linear_skinny_dx: null pointer");
+    PCCX_CHECK_ARG(M >= 1 && M <= 8 && K >= 4 && K % 4 == 0 && N >= 1 && ldz >= N && ldd >= K && ((uintptr_t)W & 15) == 0,
+                   "pccx_linear_skinny_dx: needs 1 <= M <= 8 rows and K %% 4 == 0 (M=%d K=%d)", M, K);
+    const int kblocks = (K / 4 + 255) / 256;
+    int chunks = 1024 / kblocks;                                       // about four workgroups per CU in all
+    if (chunks < 1) chunks = 1;
+    int rpc = (N + chunks - 1) / chunks;
+    if (rpc < 16) rpc = 16;
+    chunks = (N + rpc - 1) / rpc;
+    if (flags & 2)
+        hipLaunchKernelGGL(skinny_dx_kernel<true>, dim3(kblocks, chunks), dim3(256), 0, (hipStream_t)stream, dZ, M, N, ldz, W, K, rpc, dX, ldd);
+    else
+        hipLaunchKernelGGL(skinny_dx_kernel<false>, dim3(kblocks, chunks), dim3(256), 0, (hipStream_t)stream, dZ, M, N, ldz, W, K, rpc, dX, ldd);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // ---- column reductions -----------------------------------------------------------------------------
 // mode 0: out0[c] += sum z, out1[c] += sum z^2                       (BatchNorm moments)
 // mode 1: out0[c] += sum dy*(y>0)*xhat, out1[c] += sum dy*(y>0)      (BatchNorm-ReLU backward: dgamma, dbeta)

@@ -90,6 +90,8 @@ _SIGNATURES = {
     "pccx_sigmoid_spread": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_round": [_P, C.c_int64, _P, _P],
     "pccx_pack_linear_device": [_P, C.c_int, C.c_int, C.c_int, _P, _P],
+    "pccx_linear_skinny": [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
+    "pccx_linear_skinny_dx": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_linear_dw": [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_bn_train_stats": [_P, C.c_int64, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P],
     "pccx_bn_relu_forward": [_P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P],

@@ -57,7 +57,14 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, W2)
         ctx.has_bias, ctx.wshape = b is not None, W.shape
         ctx.flags = 2 if _AUTOCAST else 0
-        return _linear_raw(x, _packed(W2, False), b, W2.shape[0], W2.shape[1], ctx.flags)
+        N, K = W2.shape
+        ctx.skinny = x.shape[0] <= 8 and K % 4 == 0          # a few rows: a weight stream, not matrix work (csrc/train.hip)
+        if ctx.skinny:
+            out = torch.empty(x.shape[0], N, device=x.device, dtype=torch.float32)
+            _lib.call("pccx_linear_skinny", x.data_ptr(), x.shape[0], K, x.stride(0), W2.data_ptr(), b.data_ptr() if b is not None else None,
+                      N, ctx.flags, out.data_ptr(), N, _stream())
+            return out
+        return _linear_raw(x, _packed(W2, False), b, N, K, ctx.flags)
 
     @staticmethod
     def backward(ctx, dz):
@@ -65,7 +72,12 @@ class LinearFn(torch.autograd.Function):
         dz = dz.contiguous()
         N, K = W2.shape
         M = x.shape[0]
-        dx = _linear_raw(dz, _packed(W2, True), None, K, N, ctx.flags) if ctx.needs_input_grad[0] else None      # dX = dZ . W
+        dx = None
+        if ctx.needs_input_grad[0] and ctx.skinny:
+            dx = torch.zeros(M, K, device=dz.device, dtype=torch.float32)
+            _lib.call("pccx_linear_skinny_dx", dz.data_ptr(), M, N, dz.stride(0), W2.data_ptr(), K, ctx.flags, dx.data_ptr(), K, _stream())
+        elif ctx.needs_input_grad[0]:
+            dx = _linear_raw(dz, _packed(W2, True), None, K, N, ctx.flags)                                       # dX = dZ . W
         dW = torch.zeros_like(W2)
         _lib.call("pccx_linear_dw", dz.data_ptr(), x.data_ptr(), M, N, K, N, x.stride(0), dW.data_ptr(), ctx.flags, _stream())
         db = None
@@ -210,11 +222,14 @@ class SmoothL1Fn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
-def _sa_train(mod, xyz, feats, start):
-    """PointNetSetAbstraction.forward (pppe_pcd_ae.py:586-611) in train mode, channels-last."""
+def _sa_train(mod, xyz, feats, start, fps_idx=None):
+    """PointNetSetAbstraction.forward (pppe_pcd_ae.py:586-611) in train mode, channels-last.  fps_idx: the module's FPS indices
+    when the caller has drawn them already (the MSG branches' draws share one launch, forward_train)."""
     B, N, _ = xyz.shape
     S = mod.npoint
-    new_xyz = xyz if S == N else ops.index_points(xyz, ops.farthest_point_sample_batch(xyz, S, start))
+    if fps_idx is None and S != N:
+        fps_idx = ops.farthest_point_sample_batch(xyz, S, start)
+    new_xyz = xyz if S == N else ops.index_points(xyz, fps_idx)
     nn_ = ops.knn_points(new_xyz, xyz, mod.K, patch_scale=1.0)
     grouped = nn_.knn                                                       # no gradient: xyz is data
     if feats is not None:
@@ -232,8 +247,16 @@ def forward_train(model, x, starts):
     B = x.shape[0]
     sa = enc.sa_modules
     outs, new_xyz = [], None
-    for br, st in zip(sa[0].branches, starts[0]):
-        new_xyz, f = _sa_train(br, x, None, st)
+    brs = list(sa[0].branches)
+    fps_of = [None] * len(brs)
+    if len(brs) > 1 and all(b_.npoint == brs[0].npoint != x.shape[1] for b_ in brs):
+        # the branches draw independent FPS samples of the SAME cloud from their own start indices (pppe_pcd_ae.py:624-632): FPS is a
+        # chain of npoint dependent rounds on one CU per cloud, so the draws of all branches go into ONE launch (B x branches clouds)
+        st_all = torch.cat([torch.as_tensor(s_).to(device=x.device, dtype=torch.int32).reshape(-1) for s_ in starts[0]])
+        idx_all = ops.farthest_point_sample_batch(x.repeat(len(brs), 1, 1), brs[0].npoint, st_all)
+        fps_of = list(idx_all.view(len(brs), B, -1))
+    for br, st, fi in zip(brs, starts[0], fps_of):
+        new_xyz, f = _sa_train(br, x, None, st, fi)
         outs.append(f)
     feats = torch.cat(outs, dim=-1)
     xyz, feats = _sa_train(sa[1], new_xyz, feats, starts[1])
