@@ -44,6 +44,25 @@ __device__ __forceinline__ float pccx_sqdist(float ax, float ay, float az, float
 
 __device__ __forceinline__ int pccx_lane() { return threadIdx.x & 63; }
 
+// Zero `bytes` (a multiple of 4, 4-byte aligned) on the stream with a KERNEL rather than hipMemsetAsync.  The buffers cleared this way
+// are accumulated into by the very next kernel (column sums, scatter-adds, Chamfer gradients), and the training step is replayed as
+// a hipGraph: with memset NODES between the kernel nodes a replay issued after a short idle gap left non-finite gradients about
+// every other time, and never with kernels serialised (AMD_SERIALIZE_KERNEL=3; tools/experiments/r3/dbg_train4.py).  As a kernel
+// node the clear is ordered like every other kernel of the captured stream.
+static __global__ void pccx_zero_kernel(unsigned *__restrict__ p, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t pccx_zero_async(void *p, size_t bytes, hipStream_t st)
+{
+    const size_t n4 = bytes / 4;
+    if (n4 == 0) return hipSuccess;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pccx_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned *)p, n4);
+    return hipGetLastError();
+}
+
 // Inclusive-of-lower-lanes population count of a wave ballot.
 __device__ __forceinline__ int pccx_ballot_rank(unsigned long long mask)
 {

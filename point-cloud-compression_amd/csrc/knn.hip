@@ -848,8 +848,8 @@ static int chamfer_grad_launch(const float *X, int B, int P, const float *Y, int
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(X && Y && nn_xy && nn_yx && gX && gY, "pccx_chamfer_grad: null pointer");
     PCCX_CHECK_ARG(P >= 1 && Q >= 1 && B <= 65535, "pccx_chamfer_grad: bad shape");
-    PCCX_CHECK_HIP(hipMemsetAsync(gX, 0, sizeof(float) * (size_t)B * P * 3, (hipStream_t)stream));
-    PCCX_CHECK_HIP(hipMemsetAsync(gY, 0, sizeof(float) * (size_t)B * Q * 3, (hipStream_t)stream));
+    PCCX_CHECK_HIP(pccx_zero_async(gX, sizeof(float) * (size_t)B * P * 3, (hipStream_t)stream));
+    PCCX_CHECK_HIP(pccx_zero_async(gY, sizeof(float) * (size_t)B * Q * 3, (hipStream_t)stream));
     const int n = P > Q ? P : Q;
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, nn_xy, nn_yx,
                        grad_out / ((float)B * P), grad_out / ((float)B * Q), g_dev, gX, gY);

@@ -14,6 +14,7 @@ clipping and Adam stay fp32 on fp32 master weights, as under autocast; the backw
 way.  bf16 has fp32's exponent range, so no GradScaler is needed (the reference's scaler guards fp16).  Correctness-first.
 """
 import math
+import os
 
 import torch
 
@@ -312,7 +313,7 @@ class Adam:
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
-        self.hyper = None           # device {lr, 1 - b1^t, 1 - b2^t}: set by make_capturable()
+        self.hyper = None           # device {lr, 1 - b1^t, 1 - b2^t, t, b1^t, b2^t}: set by make_capturable()
 
     def make_capturable(self, device):
         """Keep lr, the step counter and the bias corrections in DEVICE memory (pccx_adam_advance_dev / pccx_adam_step_dev), so
@@ -416,6 +417,11 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._body()
+        # Leave no python handle on the captured iteration: the parameters' .grad are graph-pool tensors the replays own.  Eager
+        # iterations on the same model / optimiser may alternate with replays (the optimiser's step counter lives on the device
+        # and both advance it).
+        for p in opt.params:
+            p.grad = None
 
     def _body(self):
         global _AUTOCAST
