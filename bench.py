@@ -456,6 +456,38 @@ def bench_ipdae(args, rk):
             r["host_bytes_equal_resident"] = bool(torch.equal(hc.s_nbytes, comp.s_nbytes.cpu()) and torch.equal(hc.p_nbytes, comp.p_nbytes.cpu()))
             r["d2h_bytes_per_step"] = row * B + B * N_POINTS * 12
             del copy_stream, pin_comp, pin_out
+            if args.with_files:
+                # ---- the window WITH the file system in it (compress.py:139-152 writes the three files inside its timer,
+                # decompress.py:80-91 reads them back inside its own): files on tmpfs, plain Python I/O as the reference does,
+                # synchronous (a secondary figure: 3 x B small files per step are the host's work, not the GPU's)
+                import shutil
+                import tempfile
+                tmp = tempfile.mkdtemp(prefix="pccx_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                try:
+                    def step_files(i):
+                        c = cd.compress(clouds, starts)
+                        for b_ in range(B):
+                            for ext, blob in zip((".s.bin", ".p.bin", ".c.bin"), c.files(b_)):
+                                with open(os.path.join(tmp, f"{b_:05d}{ext}"), "wb") as f:
+                                    f.write(blob)
+                        rd = lambda b_, ext: open(os.path.join(tmp, f"{b_:05d}{ext}"), "rb").read()
+                        sb = np.zeros((B, s_stride), dtype=np.uint8)
+                        pb = np.zeros((B, p_cap), dtype=np.uint8)
+                        sn, pn, cc = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4), np.float32)
+                        for b_ in range(B):
+                            s_, p_, c_ = rd(b_, ".s.bin"), rd(b_, ".p.bin"), rd(b_, ".c.bin")
+                            sb[b_, :len(s_)] = np.frombuffer(s_, np.uint8); sn[b_] = len(s_)
+                            pb[b_, :len(p_)] = np.frombuffer(p_, np.uint8); pn[b_] = len(p_)
+                            cc[b_] = np.frombuffer(c_, np.float32)
+                        up = codec.Compressed(torch.from_numpy(sb).to(dev), torch.from_numpy(sn).to(dev), torch.from_numpy(pb).to(dev),
+                                              torch.from_numpy(pn).to(dev), torch.from_numpy(cc).to(dev), N_POINTS)
+                        keep["files_out"] = cd.decompress(up, S=S).cpu()
+                    step_files(0)
+                    nf = max(2, min(args.steps, 3))
+                    r["dt_files"], r["files_steps"] = timed(rk, step_files, nf, sync), nf
+                    r["files_equal_resident"] = bool(torch.equal(keep["files_out"], out.cpu()))
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
         res_by_mode[mode] = r
         del cd
         torch.cuda.empty_cache()
@@ -493,6 +525,12 @@ def bench_ipdae(args, rk):
                 "value_resident": rk.world * pts / r["dt_res"], "ms_per_step_resident": 1e3 * r["dt_res"] / args.steps,
                 "dtype": mode, "roofline": rf2, "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(ps2.items(), key=lambda kv: -kv[1])},
                 "bpp": r["bits"] / (B * N_POINTS), "d1_psnr_db": r["psnr_sum"] / B}
+        if "dt_files" in main:
+            res["with_files"] = {"value": rk.world * B * N_POINTS * main["files_steps"] / main["dt_files"], "unit": "points/s",
+                                 "ms_per_step": 1e3 * main["dt_files"] / main["files_steps"], "steps": main["files_steps"],
+                                 "decoded_equals_resident": main["files_equal_resident"],
+                                 "note": "secondary figure: the three .bin files of every cloud written to and read back from tmpfs INSIDE the "
+                                         "timed window (compress.py:139-152, decompress.py:80-91), plain synchronous Python file I/O"}
         res["cpu_baseline"] = None
         print("[bench] gpu legs done: %.3e points/s host-to-host (%.2f ms/step), %.3e resident; dominant %s %.1f TFLOP/s (%.2f of %s peak)" %
               (res["value"], res["ms_per_step"], res["value_resident"], rf["kernel"], rf["achieved"], rf["frac"], args.matmul),
@@ -707,6 +745,8 @@ def main():
     ap.add_argument("--rooms", type=int, default=8, help="s3dis: number of rooms")
     ap.add_argument("--autocast", action="store_true", help="pppe-train: the bf16 autocast branch of train_pppe_pcd_ae.py:193-217")
     ap.add_argument("--graph", action="store_true", help="pppe-train: capture the step once as a hipGraph and replay it (single GPU)")
+    ap.add_argument("--with-files", action="store_true",
+                    help="ipdae: also time a leg with the three .bin files of every cloud written to / read from tmpfs inside the window")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU / on CPU")
     args = ap.parse_args()

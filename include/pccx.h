@@ -414,6 +414,14 @@ PCCX_API int pccx_sumsq_accumulate(const float *g, int64_t n, double *acc, void 
 PCCX_API int pccx_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                             const double *gnorm_sq, float max_norm, float lr, float beta1, float beta2,
                             float eps, int step, void *stream);
+/* The same two steps over ALL parameter tensors in one launch each.  table_dev: ntensors rows of six int64 in device memory,
+ * {param, grad, exp_avg, exp_avg_sq (device pointers), n (elements), first_block}; a workgroup handles 1024 consecutive elements
+ * of one tensor, first_block = sum over the earlier rows of ceil(n / 1024), total_blocks = that sum over all rows.  hyper_dev
+ * (the device state below) replaces lr / step when not NULL.  Element for element the arithmetic of pccx_adam_step. */
+PCCX_API int pccx_sumsq_multi(const int64_t *table_dev, int ntensors, int64_t total_blocks, double *acc, void *stream);
+PCCX_API int pccx_adam_multi(const int64_t *table_dev, int ntensors, int64_t total_blocks, const double *gnorm_sq,
+                             float max_norm, const float *hyper_dev, float lr, int step, float beta1, float beta2,
+                             float eps, void *stream);
 /* Adam's per-step scalars kept on the device (torch.optim.Adam's `step` / bias_correction1/2, train_pppe_pcd_ae.py:216,220 via
  * optimizer.step()): a 32-byte, 8-byte aligned state
  *     float lr | float 1-beta1^t | float 1-beta2^t | int32 t | double beta1^t | double beta2^t

@@ -695,6 +695,88 @@ __global__ void adam_dev_kernel(float *__restrict__ p, const float *__restrict__
     }
 }
 
+// ---- clip_grad_norm_ + Adam over ALL parameter tensors in two launches ------------------------------------------------------------
+// The pppe model has 49 parameter tensors; one sum-of-squares and one update launch per tensor were 98 of the step's 494 launches
+// (0.75 ms of its 6.6 ms of kernel time, most tensors a few hundred bytes).  The tensors are described by a table in device memory,
+// one row of six int64 per tensor: {param, grad, exp_avg, exp_avg_sq (pointers), n (elements), first block}; a workgroup of 256
+// threads owns 1024 consecutive elements of one tensor and finds its row by a scan of the first-block column (T <= 1024 rows).
+#define MT_ELEMS 1024
+struct MtRow { float *p; const float *g; float *m; float *v; long n; long first; };
+
+__device__ __forceinline__ int mt_find_row(const MtRow *__restrict__ tab, int T, long blk)
+{
+    int lo = 0, hi = T - 1;                                            // last row with first <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const MtRow *__restrict__ tab, int T, double *__restrict__ acc)
+{
+    const int r = mt_find_row(tab, T, blockIdx.x);
+    const MtRow row = tab[r];
+    const long base = ((long)blockIdx.x - row.first) * MT_ELEMS;
+    double s = 0;
+    for (int u = 0; u < MT_ELEMS / 256; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i < row.n) { const double gi = row.g[i]; s += gi * gi; }
+    }
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const MtRow *__restrict__ tab, int T, const double *__restrict__ gnorm_sq, float max_norm,
+                                                        const float *__restrict__ hyper, float lr, float bc1, float bc2, float b1, float b2,
+                                                        float eps)
+{
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }
+    float clip = 1.f;
+    if (gnorm_sq) {
+        const float norm = (float)sqrt(*gnorm_sq);
+        clip = fminf(1.f, max_norm / (norm + 1e-6f));
+    }
+    const int r = mt_find_row(tab, T, blockIdx.x);
+    const MtRow row = tab[r];
+    const long base = ((long)blockIdx.x - row.first) * MT_ELEMS;
+    for (int u = 0; u < MT_ELEMS / 256; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i >= row.n) break;
+        const float gi = row.g[i] * clip;                              // the arithmetic of adam_kernel, element for element
+        const float mi = b1 * row.m[i] + (1.f - b1) * gi;
+        const float vi = b2 * row.v[i] + (1.f - b2) * gi * gi;
+        row.m[i] = mi; row.v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        row.p[i] = row.p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+extern "C" int pccx_sumsq_multi(const int64_t *table_dev, int ntensors, int64_t total_blocks, double *acc, void *stream)
+{
+    if (ntensors == 0 || total_blocks == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(table_dev && acc && ntensors >= 1 && total_blocks >= 1 && total_blocks <= 0x7fffffffLL, "pccx_sumsq_multi: bad arguments");
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const MtRow *)table_dev, ntensors, acc);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+extern "C" int pccx_adam_multi(const int64_t *table_dev, int ntensors, int64_t total_blocks, const double *gnorm_sq, float max_norm,
+                               const float *hyper_dev, float lr, int step, float beta1, float beta2, float eps, void *stream)
+{
+    if (ntensors == 0 || total_blocks == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(table_dev && ntensors >= 1 && total_blocks >= 1 && total_blocks <= 0x7fffffffLL && (hyper_dev || step >= 1),
+                   "pccx_adam_multi: bad arguments");
+    const float bc1 = hyper_dev ? 1.f : 1.f - powf(beta1, (float)step), bc2 = hyper_dev ? 1.f : 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const MtRow *)table_dev, ntensors,
+                       gnorm_sq, max_norm, hyper_dev, lr, bc1, bc2, beta1, beta2, eps);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // The step counter and the bias corrections live on the DEVICE: one thread advances t and recomputes 1 - beta^t.  The launch sits
 // inside the captured training step, so a replay needs no per-step host write at all (a pinned host buffer rewritten by a CPU that
 // runs several replays ahead would be read late by the queued copies).  Layout of the 32-byte state (pccx.h):

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "pccx_rate_from_logits": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "pccx_sumsq_accumulate": [_P, C.c_int64, _P, _P],
     "pccx_adam_step": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P],
+    "pccx_sumsq_multi": [_P, C.c_int, C.c_int64, _P, _P],
+    "pccx_adam_multi": [_P, C.c_int, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, _P],
     "pccx_adam_advance_dev": [_P, C.c_double, C.c_double, _P],
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],

@@ -314,6 +314,7 @@ class Adam:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
         self.hyper = None           # device {lr, 1 - b1^t, 1 - b2^t, t, b1^t, b2^t}: set by make_capturable()
+        self._table = self._graph_table = self._pending = self._keep = None   # step(): device tables of tensor addresses
 
     def make_capturable(self, device):
         """Keep lr, the step counter and the bias corrections in DEVICE memory (pccx_adam_advance_dev / pccx_adam_step_dev), so
@@ -327,6 +328,7 @@ class Adam:
             host.view(np.int32)[3] = self.t
             host.view(np.float64)[2:4] = (self.betas[0] ** self.t, self.betas[1] ** self.t)
             self.hyper = torch.from_numpy(host).to(device)       # one synchronous copy at set-up
+            self._graph_table = torch.zeros(len(self.params), 6, device=device, dtype=torch.int64)
         return self
 
     def set_lr(self, lr):
@@ -343,28 +345,51 @@ class Adam:
             self.t += 1
 
     def step(self, max_norm=None):
+        """clip_grad_norm_(max_norm) + Adam over every parameter that has a gradient: two launches in all (pccx_sumsq_multi,
+        pccx_adam_multi) driven by a table of the tensors' addresses in device memory."""
+        import numpy as np
         capturable = self.hyper is not None
+        capturing = torch.cuda.is_current_stream_capturing()
         if capturable:
             self.advance()              # eager or captured alike: the step advances its own device counter
         else:
             self.t += 1
-        live = [(p, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        live = [(p, p.grad.contiguous(), m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        if not live:
+            return None
+        dev = live[0][0].device
+        rows, first = np.zeros((len(live), 6), dtype=np.int64), 0
+        for r, (p, g, m, v) in enumerate(live):
+            rows[r] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), first)
+            first += (p.numel() + 1023) // 1024
+        self._keep = [g for _, g, _, _ in live]                      # the addresses in the table stay valid until the next step
+        if capturing:
+            # nothing may be copied from the host inside a capture: the kernels are recorded with the ADDRESS of a table of their own
+            # (eager steps on this optimiser keep theirs), its content is uploaded right after the capture (flush_table, called by
+            # GraphedTrainStep) -- the captured gradients live at fixed addresses in the graph's pool
+            if self._graph_table is None:
+                raise _lib.PccxError("Adam.step inside a capture needs make_capturable() first (it allocates the captured step's table)")
+            table = self._graph_table                                # allocated (zeroed: n = 0 rows touch nothing) OUTSIDE the capture
+            self._pending = rows
+        else:
+            if self._table is None:
+                self._table = torch.zeros(len(self.params), 6, device=dev, dtype=torch.int64)
+            table = self._table
+            table[:len(live)].copy_(torch.from_numpy(rows))          # pageable source: the copy has completed when this returns
         acc = None
-        if max_norm is not None and live:
-            acc = torch.zeros(1, device=live[0][0].device, dtype=torch.float64)
-            for p, _, _ in live:
-                _lib.call("pccx_sumsq_accumulate", p.grad.contiguous().data_ptr(), p.numel(), acc.data_ptr(), _stream())
-        if capturable:
-            for p, m, v in live:
-                _lib.call("pccx_adam_step_dev", p.data_ptr(), p.grad.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
-                          acc.data_ptr() if acc is not None else None, float(max_norm or 0.0), self.hyper.data_ptr(),
-                          float(self.betas[0]), float(self.betas[1]), float(self.eps), _stream())
-            return acc
-        for p, m, v in live:
-            _lib.call("pccx_adam_step", p.data_ptr(), p.grad.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
-                      acc.data_ptr() if acc is not None else None, float(max_norm or 0.0), float(self.lr), float(self.betas[0]),
-                      float(self.betas[1]), float(self.eps), self.t, _stream())
+        if max_norm is not None:
+            acc = torch.zeros(1, device=dev, dtype=torch.float64)
+            _lib.call("pccx_sumsq_multi", table.data_ptr(), len(live), first, acc.data_ptr(), _stream())
+        _lib.call("pccx_adam_multi", table.data_ptr(), len(live), first, acc.data_ptr() if acc is not None else None,
+                  float(max_norm or 0.0), self.hyper.data_ptr() if capturable else None, float(self.lr), int(max(self.t, 1)),
+                  float(self.betas[0]), float(self.betas[1]), float(self.eps), _stream())
         return acc
+
+    def flush_table(self):
+        """Upload the tensor table recorded during a capture (step() could not copy from the host there)."""
+        if self._pending is not None:
+            self._graph_table[:self._pending.shape[0]].copy_(torch.from_numpy(self._pending))
+            self._pending = None
 
 
 def step_flops(model, batch):
@@ -417,6 +442,8 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._body()
+        self._grads = opt._keep            # the captured gradients: graph-pool tensors at the addresses the table holds
+        opt.flush_table()
         # Leave no python handle on the captured iteration: the parameters' .grad are graph-pool tensors the replays own.  Eager
         # iterations on the same model / optimiser may alternate with replays (the optimiser's step counter lives on the device
         # and both advance it).
