@@ -691,9 +691,8 @@ def bench_pppe_train(args, rk):
     if args.autocast:
         kw["autocast"] = True
     if args.graph:
-        if rk.world > 1:
-            raise SystemExit("--graph: the captured step is single-GPU (the gradient all-reduce is not captured)")
-        gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=args.autocast, warmup=max(args.warmup, 1))
+        gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=args.autocast, warmup=max(args.warmup, 1),
+                                       data_parallel=rk.world > 1)     # N > 1: two graphs cut at the gradient all-reduce
         dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), args.steps, torch.cuda.synchronize)
         keep["o"] = tuple(float(t) for t in keep["o"])
     else:
@@ -720,7 +719,8 @@ def bench_pppe_train(args, rk):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
-                       "launch": "one hipGraph replay per step" if args.graph else "eager (about 600 launches per step)"},
+                       "launch": ("one hipGraph replay per step" if rk.world == 1 else "two hipGraph replays per step around the RCCL gradient all-reduce")
+                                 if args.graph else "eager (about 400 launches per step" + (", gradient all-reduce overlapped with backward)" if rk.world > 1 else ")")},
             "roofline": rf, "cpu_baseline": cpu,
             "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": keep["o"][0]}), flush=True)
 
@@ -743,8 +743,11 @@ def main():
                          "blocks; pppf = configs[2] PPPF_AE forward; pppe-train = the training step of configs[4]; "
                          "launch-check = no GPU work, exercises the N-rank launch and the summary all-gather")
     ap.add_argument("--rooms", type=int, default=8, help="s3dis: number of rooms")
-    ap.add_argument("--autocast", action="store_true", help="pppe-train: the bf16 autocast branch of train_pppe_pcd_ae.py:193-217")
-    ap.add_argument("--graph", action="store_true", help="pppe-train: capture the step once as a hipGraph and replay it (single GPU)")
+    ap.add_argument("--autocast", action="store_true", default=None,
+                    help="pppe-train: the bf16 autocast branch of train_pppe_pcd_ae.py:193-217 (the default for this workload: BASELINE "
+                         "configs[4] names bf16)")
+    ap.add_argument("--fp32", action="store_true", help="pppe-train: the fp32 step instead of the bf16 autocast one")
+    ap.add_argument("--graph", action="store_true", help="pppe-train: capture the step once as a hipGraph and replay it (N > 1: two graphs around the gradient all-reduce)")
     ap.add_argument("--with-files", action="store_true",
                     help="ipdae: also time a leg with the three .bin files of every cloud written to / read from tmpfs inside the window")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -764,6 +767,7 @@ def main():
             print("[bench] launcher parent is GPU-free (no torch import)", file=sys.stderr, flush=True)
         sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    args.autocast = not args.fp32 if args.autocast is None else bool(args.autocast)
     import pccx
     if args.matmul is None:
         args.matmul = pccx.DEFAULT_MATMUL

@@ -418,14 +418,18 @@ class GraphedTrainStep:
     compiler).  Everything that changes from step to step lives in device memory the graph reads: the batch, the FPS start indices,
     lambda, and Adam's lr / bias corrections (Adam.make_capturable).  Shapes are fixed at construction.  The ``warmup`` eager
     iterations run before the capture are REAL optimisation steps on the construction batch (they also size the scratch buffers).
-    Single-GPU: the data-parallel gradient all-reduce is not captured."""
+    data_parallel=True (one replica per GPU under torch.distributed): the iteration is captured as TWO graphs cut at the only
+    exchange of the step -- forward + backward, then clip + Adam -- and the bucketed gradient all-reduce over RCCL
+    (dist.allreduce_mean_, on the gradients' fixed graph-pool addresses) runs between the two replays on the same stream."""
 
-    def __init__(self, model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, loss_type="chamfer", autocast=False, warmup=2):
+    def __init__(self, model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, loss_type="chamfer", autocast=False, warmup=2,
+                 data_parallel=False):
         if loss_type != "chamfer":
             raise _lib.PccxError("GraphedTrainStep: loss_type='chamfer' (what train_pppe_pcd_ae.py:48 builds) is the captured loss; "
                                  "the smooth-L1 backward still reads its upstream gradient on the host")
         dev = batch_x.device
         self.model, self.opt, self.grad_clip, self.loss_type, self.autocast = model, opt, grad_clip, loss_type, autocast
+        self.data_parallel, self.graph_opt = bool(data_parallel), None
         opt.make_capturable(dev)
         as_dev = lambda s_: torch.as_tensor(s_).to(device=dev, dtype=torch.int32).contiguous().clone()
         self.x = batch_x.detach().clone().contiguous()
@@ -440,8 +444,16 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._body()
+        if self.data_parallel:
+            with torch.cuda.graph(self.graph):
+                self.out = self._fwd_bwd()
+            self._dp_grads = [p.grad for p in opt.params if p.grad is not None]      # fixed addresses: what the all-reduce averages
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self.opt.step(max_norm=self.grad_clip)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
         self._grads = opt._keep            # the captured gradients: graph-pool tensors at the addresses the table holds
         opt.flush_table()
         # Leave no python handle on the captured iteration: the parameters' .grad are graph-pool tensors the replays own.  Eager
@@ -450,7 +462,7 @@ class GraphedTrainStep:
         for p in opt.params:
             p.grad = None
 
-    def _body(self):
+    def _fwd_bwd(self):
         global _AUTOCAST
         for p in self.opt.params:
             p.grad = None
@@ -462,8 +474,15 @@ class GraphedTrainStep:
         finally:
             _AUTOCAST = False
         loss.backward()
-        self.opt.step(max_norm=self.grad_clip)
         return loss.detach(), dist, rate
+
+    def _body(self):
+        out = self._fwd_bwd()
+        if self.data_parallel:                                       # warm-up iterations of a replica: average, then step
+            from . import dist as pdist
+            pdist.allreduce_mean_([p.grad for p in self.opt.params])
+        self.opt.step(max_norm=self.grad_clip)
+        return out
 
     def __call__(self, batch_x=None, starts=None, lam=None, sync=True):
         """One iteration.  Returns (loss, dist, rate) as floats (sync=True) or the device scalars of the graph (sync=False)."""
@@ -477,6 +496,10 @@ class GraphedTrainStep:
         if lam is not None:
             self.lam.fill_(float(lam))
         self.graph.replay()             # carries pccx_adam_advance_dev: the device counter moves with the replay
+        if self.graph_opt is not None:
+            from . import dist as pdist
+            pdist.allreduce_mean_(self._dp_grads)                    # RCCL, same stream, between the two graphs
+            self.graph_opt.replay()
         self.opt.t += 1                 # host mirror
         return tuple(float(t) for t in self.out) if sync else self.out
 
@@ -496,9 +519,16 @@ def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_paralle
         loss, dist, rate = rd_loss(fine.float(), batch_x.float(), fbpp, lam, loss_type)      # :205 casts back to fp32 for the loss
     finally:
         _AUTOCAST = False
-    loss.backward()
     if data_parallel:
+        # gradient averaging overlapped with backward: each bucket is all-reduced on a side stream as soon as its last gradient is
+        # written (dist.GradBuckets); the clipped Adam step waits for the last bucket
         from . import dist as pdist
-        pdist.allreduce_mean_([p.grad for p in opt.params])
+        if getattr(opt, "_dp", None) is None:
+            opt._dp = pdist.GradBuckets(opt.params)
+        opt._dp.begin()
+        loss.backward()
+        opt._dp.finish()
+    else:
+        loss.backward()
     opt.step(max_norm=grad_clip)
     return float(loss.detach()), float(dist), float(rate)

@@ -145,3 +145,56 @@ def test_bench_rank_without_a_device_exits_nonzero():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--cpu-clouds", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+def _gb_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 300), torch.nn.ReLU(), torch.nn.Linear(300, 200), torch.nn.ReLU(), torch.nn.Linear(200, 4))
+    unused = torch.nn.Parameter(torch.zeros(5))                    # a parameter that never receives a gradient
+    params = list(net.parameters()) + [unused]
+    gb = pdist.GradBuckets(params, bucket_bytes=2048, big_bytes=100_000)      # the 300x200 weight travels alone, the rest in flat buckets
+    x = torch.randn(16, 8, generator=torch.Generator().manual_seed(100 + rank))
+    res = []
+    for it in range(2):                                            # hooks must re-arm
+        for p in params:
+            p.grad = None
+        gb.begin()
+        (net(x) ** 2).mean().backward()
+        launched = gb.finish()
+        res.append((launched, [None if p.grad is None else p.grad.numpy().copy() for p in params]))
+    local = []
+    for p in params:
+        p.grad = None
+    (net(x) ** 2).mean().backward()
+    local = [None if p.grad is None else p.grad.numpy().copy() for p in params]
+    q.put((rank, len(gb.buckets), res, local))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_buckets_two_ranks():
+    """dist.GradBuckets (the all-reduce of the data-parallel training step, launched bucket by bucket from post-accumulate hooks
+    while backward is still running): after finish() every gradient is the mean over ranks of the local gradients, a large tensor
+    travels alone, parameters without a gradient are skipped consistently, and the hooks re-arm for the next step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, nb0, r0, l0), (_, nb1, r1, l1) = res
+    assert nb0 == nb1 >= 3
+    for it in range(2):
+        assert r0[it][0] == r1[it][0] == nb0                        # every bucket issued exactly once per step
+        for a, b, la, lb in zip(r0[it][1], r1[it][1], l0, l1):
+            if la is None:
+                assert a is None and b is None
+                continue
+            want = (la + lb) / 2
+            np.testing.assert_allclose(a, want, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(b, want, rtol=1e-6, atol=1e-7)
