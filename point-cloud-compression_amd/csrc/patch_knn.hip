@@ -39,13 +39,21 @@ __global__ __launch_bounds__(256) void patch_knn16_kernel(const float *__restric
             unsigned tk[17];
 #pragma unroll
             for (int s = 0; s < 17; ++s) tk[s] = 0xFFFFFFFFu;
-            for (int j0 = 0; j0 < K; j0 += 4) {          // K % 16 == 0; broadcast reads, four candidates in flight
-                float d[4];
+#ifndef PK_UNROLL
+#define PK_UNROLL 4
+#endif
+#ifdef PK_SGPR
+            const float *__restrict__ cand = xp;         // wave-uniform address: scalar loads, candidates arrive in SGPRs
+#else
+            const float *cand = sx;                      // LDS broadcast reads
+#endif
+            for (int j0 = 0; j0 < K; j0 += PK_UNROLL) {  // K % 16 == 0; PK_UNROLL candidates in flight
+                float d[PK_UNROLL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    d[u] = pccx_sqdist(px, py, pz, sx[3 * (j0 + u)], sx[3 * (j0 + u) + 1], sx[3 * (j0 + u) + 2]);
+                for (int u = 0; u < PK_UNROLL; ++u)
+                    d[u] = pccx_sqdist(px, py, pz, cand[3 * (j0 + u)], cand[3 * (j0 + u) + 1], cand[3 * (j0 + u) + 2]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < PK_UNROLL; ++u) {
                     const unsigned key = (__float_as_uint(d[u]) & ~jmask) | (unsigned)(j0 + u);
 #pragma unroll
                     for (int s = 16; s >= 1; --s) tk[s] = pk_umed3(tk[s - 1], key, tk[s]);

@@ -46,3 +46,14 @@ def test_version_and_error_string():
     # argument validation happens on the host, before any HIP call
     rc = lib.pccx_octree_encode(None, 1, 64, 8192, 0.25, None, None, None, None, None, None)
     assert rc == -1 and b"null pointer" in lib.pccx_last_error()
+
+
+def test_model_limits_name_the_reference_flags():
+    """compress.py:30-34 accepts any --K / --d / --L; the fused kernels cover --d <= 16, --d * --L <= 128 and --K % 16 == 0 in
+    16..1024 (known limits).  Outside that range the constructor refuses loudly and names the flags, before any GPU work."""
+    import pytest as _pt
+    from pccx import models
+    for K, k, d, L, word in ((256, 128, 32, 7, "--d"), (256, 128, 16, 9, "--L"), (250, 125, 16, 7, "--K"), (2048, 1024, 16, 7, "--K")):
+        with _pt.raises(_lib.PccxError, match=word):
+            models.AE(K, k, d, L)
+    models.AE(512, 256, 8, 16)          # d * L = 128: the edge is inside
