@@ -12,6 +12,7 @@
 // MFMA-bound; weights (64 MiB) and activations stream from L2 / Infinity Cache as 1 KiB fragments.
 // dec_main_kernel<true> is the bf16x3 variant (the host layer's default mode); <false> is the exact-fp32 product.
 #include <math.h>
+#include <stdlib.h>
 
 #include "blobs.h"
 #include "common.h"
@@ -102,8 +103,11 @@ __device__ __forceinline__ uint4 b3_load_async(const uint4 *p)    // placed exac
 // grid: x = patch block (8 n-tiles = 128 patches), y = point p.  4 waves, wave w owns n-tiles 2w, 2w+1.
 // B3 = false: exact fp32 MFMA GEMM (the product path).  B3 = true (the bf16x3 mode): the K = 1024 GEMM runs as six
 // v_mfma_f32_16x16x32_bf16 passes over pre-split operands (blob3 / h2p hold bf16 planes) and inv_mlp as a bf16x3 chain on registers.
-template <bool B3>
-__global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restrict__ h2p, const float *__restrict__ latent_q,
+// NT = patch tiles per wave.  2 (the default): two workgroups of four waves per CU, two waves per SIMD.  4 (bf16x3 only): ONE wave per
+// SIMD on the 512-register budget, a workgroup covers 256 patches -- point p's weight stream enters LDS and is read from it half as
+// often per MFMA (the untried lever of round 2's review; selected with PCCX_DEC_NT=4, measured in DESIGN.md section 4).
+template <bool B3, int NT = 2>
+__global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void dec_main_kernel(const f32x4 *__restrict__ h2p, const float *__restrict__ latent_q,
                                                           int P, int d, int k, int ntiles, const float *__restrict__ blob,
                                                           const float *__restrict__ blob3,
                                                           float *__restrict__ patches_out, float inv_scale_div,
@@ -117,11 +121,12 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     // the group.  Consecutive workgroups share point p's weight stream (L2), and a group's activation fragments
     // (DEC_GROUP x 8 tiles, 32-48 MB) stay in the Infinity Cache while all k points sweep over them, instead of the whole
     // activation array being re-streamed from HBM once per point.
-    const int nblk = (ntiles + 7) / 8;
-    const int grp = blockIdx.x / (DEC_GROUP * k), rem = blockIdx.x % (DEC_GROUP * k);
-    const int p = rem / DEC_GROUP, blk = grp * DEC_GROUP + rem % DEC_GROUP;
+    constexpr int GRP = DEC_GROUP * 2 / NT;                   // patch blocks per group: the same number of PATCHES per group for any NT
+    const int nblk = (ntiles + 4 * NT - 1) / (4 * NT);
+    const int grp = blockIdx.x / (GRP * k), rem = blockIdx.x % (GRP * k);
+    const int p = rem / GRP, blk = grp * GRP + rem % GRP;
     if (blk >= nblk) return;                                  // whole workgroup (before any barrier)
-    const int tile0 = blk * 8 + 2 * w;
+    const int tile0 = blk * 4 * NT + NT * w;
     constexpr int CH = B3 ? DEC_B3_CHUNK : DEC_WS_CHUNK;
     constexpr int NB = B3 ? 4 : 2;                                        // ring depth: B3 chunks are short, their DMA needs 3 chunks of lead
     __shared__ __attribute__((aligned(16))) f32x4 swt[NB * CH * 64];     // ring: one k-tile (8 m-tiles) per chunk; B3: 4 m-tiles x 3 planes
@@ -131,13 +136,17 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
                           swt, B3 ? DEC_B3_STREAM_CHUNKS : DEC_STREAM_CHUNKS, lane, wu, false};
     ws.prologue();
 
-    f32x4 acc[2][8];
+    f32x4 acc[NT][8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const f32x4 b = *(const f32x4 *)(blob + DEC_G_B + p * 128 + 16 * mt + 4 * g);
-        acc[0][mt] = b; acc[1][mt] = b;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = b;
     }
-    const int t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
+    int tq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) tq[nt] = tile0 + nt < ntiles ? tile0 + nt : ntiles - 1;
+    const int t0 = tq[0], t1 = tq[NT > 1 ? 1 : 0];
     if constexpr (!B3) {
         // ---- GEMM over K = 1024 (64 k-tiles).  A (weights of point p, shared by the 4 waves) comes through
         // the LDS ring one chunk (2 k-tiles) ahead; B (this wave's 2 patch tiles) is prefetched one k-tile
@@ -178,23 +187,23 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
         // so boundary(2t) needs all but its 12 youngest loads (DMA(2t) was issued at boundary(2t-3), B(t) at 2t-4) and
         // boundary(2t+1) all but its 18 youngest; loads complete in order.
         const uint4 *h3 = (const uint4 *)h2p;
-        uint4 bs[3][2][3];
-        auto load_b = [&](uint4 (&dst)[2][3], int t) {
+        uint4 bs[3][NT][3];
+        auto load_b = [&](uint4 (&dst)[NT][3], int t) {
             const int tc = t < 32 ? t : 31;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) dst[nt][pl] = b3_load_async(h3 + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+                for (int pl = 0; pl < 3; ++pl) dst[nt][pl] = b3_load_async(h3 + (((size_t)tc * ntiles + tq[nt]) * 3 + pl) * 64 + lane);
         };
-        auto kstep = [&](int t, const uint4 (&bc)[2][3], uint4 (&bload)[2][3], bool first) {
+        auto kstep = [&](int t, const uint4 (&bc)[NT][3], uint4 (&bload)[NT][3], bool first) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int c = 2 * t + half;
                 if (half == 0) {
-                    if (first) ws.boundary(c); else ws.template boundary_keep<12>(c);
+                    if (first) ws.boundary(c); else ws.template boundary_keep<6 + 3 * NT>(c);      // NT = 2: 12 youngest may fly
                     load_b(bload, t + 2);
                 } else
-                    ws.template boundary_keep<18>(c);
+                    ws.template boundary_keep<6 + 6 * NT>(c);                                       // NT = 2: 18
                 const f32x4 *buf = ws.chunk(c);
                 bf16x8 a[4][3];
 #pragma unroll
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
 #pragma unroll
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < NT; ++nt)
                             acc[nt][4 * half + mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 a[mq][PA[q]], __builtin_bit_cast(bf16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads
     }
-    f32x4 m3[2][1];
+    f32x4 m3[NT][1];
     if constexpr (!B3) {
         // ---- inv_mlp on registers: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent
         f32x4 in[2][9];
@@ -278,10 +287,10 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
         // ---- inv_mlp as a bf16x3 chain: every layer's input is split in registers (relu, then three bf16 planes per pair
         // of 16-channel tiles); the ninth input tile (the latent) pairs with zeros.
         int f = DEC_B3_GEMM_FRAGS;
-        bf16x8 i0[2][5][3];
+        bf16x8 i0[NT][5][3];
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) b3_split8(relu4(acc[nt][2 * t]), relu4(acc[nt][2 * t + 1]), i0[nt][t]);
             const int patch = (tile0 + nt) * 16 + n;
@@ -290,47 +299,47 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
             for (int r = 0; r < 4; ++r) lat[r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
             b3_split8(lat, zero, i0[nt][4]);
         }
-        f32x4 m0[2][8];
+        f32x4 m0[NT][8];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(blob + DEC_M_B0 + 16 * mt + 4 * g);
-        dense_b3_stream<5, 8, 2>(ws, f, i0, m0);
-        bf16x8 i1[2][4][3];
+        dense_b3_stream<5, 8, NT>(ws, f, i0, m0);
+        bf16x8 i1[NT][4][3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int t = 0; t < 4; ++t) b3_split8(relu4(m0[nt][2 * t]), relu4(m0[nt][2 * t + 1]), i1[nt][t]);
-        f32x4 m1[2][4];
+        f32x4 m1[NT][4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(blob + DEC_M_B1 + 16 * mt + 4 * g);
-        dense_b3_stream<4, 4, 2>(ws, f, i1, m1);
-        bf16x8 i2[2][2][3];
+        dense_b3_stream<4, 4, NT>(ws, f, i1, m1);
+        bf16x8 i2[NT][2][3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int t = 0; t < 2; ++t) b3_split8(relu4(m1[nt][2 * t]), relu4(m1[nt][2 * t + 1]), i2[nt][t]);
-        f32x4 m2[2][2];
+        f32x4 m2[NT][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(blob + DEC_M_B2 + 16 * mt + 4 * g);
-        dense_b3_stream<2, 2, 2>(ws, f, i2, m2);
-        bf16x8 i3[2][1][3];
+        dense_b3_stream<2, 2, NT>(ws, f, i2, m2);
+        bf16x8 i3[NT][1][3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b3_split8(relu4(m2[nt][0]), relu4(m2[nt][1]), i3[nt][0]);
+        for (int nt = 0; nt < NT; ++nt) b3_split8(relu4(m2[nt][0]), relu4(m2[nt][1]), i3[nt][0]);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(blob + DEC_M_B3 + 4 * g);
-        dense_b3_stream<1, 1, 2>(ws, f, i3, m3);          // last layer: no ReLU (AE.py:27)
+        for (int nt = 0; nt < NT; ++nt) m3[nt][0] = *(const f32x4 *)(blob + DEC_M_B3 + 4 * g);
+        dense_b3_stream<1, 1, NT>(ws, f, i3, m3);          // last layer: no ReLU (AE.py:27)
     }
     ws.drain();
 
     // ---- epilogue: rows 0..2 of the last tile (g == 0, r = 0..2) are x,y,z of (patch, point p)
     if (g == 0) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const int patch = (tile0 + nt) * 16 + n;
             if (tile0 + nt < ntiles && patch < P) {
                 float v[3] = {m3[nt][0][0], m3[nt][0][1], m3[nt][0][2]};
@@ -356,10 +365,11 @@ __global__ __launch_bounds__(256, 2) void dec_main_kernel(const f32x4 *__restric
     }
 }
 
-static unsigned dec_grid(int ntiles, int k)
+static unsigned dec_grid(int ntiles, int k, int NT = 2)
 {
-    const int nblk = (ntiles + 7) / 8, groups = (nblk + DEC_GROUP - 1) / DEC_GROUP;
-    return (unsigned)groups * DEC_GROUP * (unsigned)k;
+    const int grp = DEC_GROUP * 2 / NT;
+    const int nblk = (ntiles + 4 * NT - 1) / (4 * NT), groups = (nblk + grp - 1) / grp;
+    return (unsigned)groups * grp * (unsigned)k;
 }
 
 extern "C" size_t pccx_ae_decode_workspace_floats(int P)
@@ -487,9 +497,15 @@ extern "C" int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, con
     hipLaunchKernelGGL(b3_split_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const f32x4 *)h2p, h3, 1, 64, ntiles,
                        (size_t)0, (size_t)0, ntiles);
     PCCX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_main_kernel<true>, dim3(dec_grid(ntiles, k)), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
-                       ntiles, dec_blob, b3_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,
-                       (float)(1.0 - margin), pc_out);
+    static const int dec_nt = []() { const char *e = getenv("PCCX_DEC_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
+    if (dec_nt == 4)
+        hipLaunchKernelGGL((dec_main_kernel<true, 4>), dim3(dec_grid(ntiles, k, 4)), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
+                           ntiles, dec_blob, b3_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,
+                           (float)(1.0 - margin), pc_out);
+    else
+        hipLaunchKernelGGL((dec_main_kernel<true, 2>), dim3(dec_grid(ntiles, k)), dim3(256), 0, st, (const f32x4 *)h3, latent_q, P, d, k,
+                           ntiles, dec_blob, b3_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1,
+                           (float)(1.0 - margin), pc_out);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
