@@ -344,6 +344,14 @@ PCCX_API int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t 
                                        int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
                                        const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream);
 
+/* The epilogue of pccx_prob_forward as an op of its own, for the generic (any --d / --L, compress.py:30-34) path: softmax over
+ * the L levels of each row of logits (rows, L), pmf_to_cdf (pn_kit.py:452-461: cumsum, leading 0, clamp <= 1) and torchac 0.9.3's
+ * integer CDF.  Any of pmf (rows, L), cdf (rows, L+1), cdf_int (rows, L+1) may be NULL. */
+PCCX_API int pccx_softmax_cdf(const float *logits, int64_t rows, int L, float *pmf, float *cdf, int32_t *cdf_int, void *stream);
+/* The reassembly epilogue of pccx_ae_decode as an op of its own (decompress.py:104-116): patches (P, k, 3) raw decoder output ->
+ * out (P*k, 3) = ((patch / scale) + centres[patch] - 0.5) * longest[b] / (1 - margin) + center[b], b = patch / S. */
+PCCX_API int pccx_reassemble(const float *patches, int64_t P, int k, float scale, const float *centres, const float *nrm_center,
+                             const float *nrm_longest, int S, double margin, float *out, void *stream);
 /* out[r][c] = act(base[r / div][c] + sum_{k<Ks} x[(mod ? r % mod : r)][k] * w[c][k]), Ks <= 4, C % 4 == 0: the per-point part of a
  * layer whose input rows are [small per-point part | long per-patch part] (FoldingNet's [grid | latent] and [coarse | latent],
  * PPPF_AE.py:99-107); base = the per-patch part's Linear (bias included), one row per patch.  w is (C, Ks) row-major. */

@@ -377,16 +377,89 @@ extern "C" int pccx_rows_affine_small(const float *base, int C, int64_t div, con
     return PCCX_OK;
 }
 
+// softmax over the L levels of every (centre, latent dim) row of logits (rows, L) + pmf_to_cdf + torchac's integer CDF: the
+// epilogue of prob_forward_kernel (AE.py:121-123, pn_kit.py:452-461, torchac 0.9.3) for shapes its fused form does not cover
+// (--d > 16 or --d * --L > 128: compress.py:30-34 accepts any).  One thread per row; the same operation order as the epilogue.
+__global__ __launch_bounds__(256) void softmax_cdf_kernel(const float *__restrict__ logits, long rows, int L, float *__restrict__ pmf,
+                                                         float *__restrict__ cdf, int32_t *__restrict__ cdf_int)
+{
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float *lg = logits + row * L;
+    const int Lp = L + 1;
+    float mx = -INFINITY;
+    for (int l = 0; l < L; ++l) mx = fmaxf(mx, lg[l]);
+    float sum = 0.f;
+    for (int l = 0; l < L; ++l) sum += expf(lg[l] - mx);
+    float run_c = 0.f;
+    if (cdf) cdf[row * Lp] = 0.f;
+    if (cdf_int) cdf_int[row * Lp] = 0;
+    for (int l = 0; l < L; ++l) {
+        const float pv = expf(lg[l] - mx) / sum;
+        if (pmf) pmf[row * L + l] = pv;
+        run_c = run_c + pv;
+        const float cv = fminf(run_c, 1.0f);
+        if (cdf) cdf[row * Lp + l + 1] = cv;
+        if (cdf_int) cdf_int[row * Lp + l + 1] = ((int)rintf(cv * (float)(65536 - (Lp - 1))) + (l + 1)) & 0xFFFF;
+    }
+}
+
+extern "C" int pccx_softmax_cdf(const float *logits, int64_t rows, int L, float *pmf, float *cdf, int32_t *cdf_int, void *stream)
+{
+    if (rows == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(logits && (pmf || cdf || cdf_int), "pccx_softmax_cdf: null pointer / no output requested");
+    PCCX_CHECK_ARG(rows > 0 && L >= 1 && L <= 65535, "pccx_softmax_cdf: bad shape rows=%lld L=%d", (long long)rows, L);
+    hipLaunchKernelGGL(softmax_cdf_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, (long)rows, L, pmf, cdf,
+                       cdf_int);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// decompress.py:104-116 after the generic decoder: out[(patch * k + p)] = ((patches[patch][p] / scale) + centres[patch] - 0.5) * longest[b]
+// / (1 - margin) + center[b], b = patch / S -- the fused decoders' epilogue (decoder.hip) as an op of its own, same operation order.
+__global__ __launch_bounds__(256) void reassemble_kernel(const float *__restrict__ patches, long P, int k, float scale,
+                                                        const float *__restrict__ centres, const float *__restrict__ nrm_center,
+                                                        const float *__restrict__ nrm_longest, int S, float one_minus_margin,
+                                                        float *__restrict__ out)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= P * k) return;
+    const long patch = e / k;
+    const int b = (int)(patch / S);
+    const float lg = nrm_longest[b];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float t = __fdiv_rn(patches[3 * e + a], scale);
+        t = __fadd_rn(t, centres[patch * 3 + a]);
+        t = __fsub_rn(t, 0.5f);
+        t = __fdiv_rn(__fmul_rn(t, lg), one_minus_margin);
+        out[3 * e + a] = __fadd_rn(t, nrm_center[3 * b + a]);
+    }
+}
+
+extern "C" int pccx_reassemble(const float *patches, int64_t P, int k, float scale, const float *centres, const float *nrm_center,
+                               const float *nrm_longest, int S, double margin, float *out, void *stream)
+{
+    if (P == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(patches && centres && nrm_center && nrm_longest && out, "pccx_reassemble: null pointer");
+    PCCX_CHECK_ARG(P > 0 && k >= 1 && S >= 1 && scale != 0.f, "pccx_reassemble: bad arguments");
+    hipLaunchKernelGGL(reassemble_kernel, dim3((unsigned)((P * k + 255) / 256)), dim3(256), 0, (hipStream_t)stream, patches, (long)P, k, scale, centres,
+                       nrm_center, nrm_longest, S, (float)(1.0 - margin), out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 #define GM_THREADS 1024                    // 2 workgroups of 64 KB per CU = all 32 wave slots: the walk is a chain of dependent reads
 template <bool LDS_TILE>
-__global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__restrict__ y, int N, int C, const int64_t *__restrict__ idx, int M,
-                                                                int ns, int chunk, float *__restrict__ out)
+__global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__restrict__ y, int B, int N, int C, const int64_t *__restrict__ idx,
+                                                                int M, int ns, int chunk, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float gm_tile[];
-    const int b = blockIdx.y, c0 = blockIdx.x * chunk, tid = threadIdx.x;
+    const int c0 = blockIdx.x * chunk, tid = threadIdx.x;
     const int cw = min(chunk, C - c0), q4 = chunk >> 2;                      // chunk % 4 == 0, C % 4 == 0
-    const float4 *y4 = (const float4 *)(y + (size_t)b * N * C + c0);
     const int ldy4 = C >> 2;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {                          // more clouds than the grid's y range: walk them
+    const float4 *y4 = (const float4 *)(y + (size_t)b * N * C + c0);
     if (LDS_TILE) {
         float4 *t4 = (float4 *)gm_tile;
         for (int i = tid; i < N * q4; i += GM_THREADS) {
@@ -423,6 +496,8 @@ __global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__r
         }
         ((float4 *)(out + ((size_t)b * M + g) * C + c0))[q] = m;
     }
+    if (LDS_TILE) __syncthreads();                                            // the tile is rewritten for the next cloud
+  }
 }
 
 extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream)
@@ -431,18 +506,18 @@ extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_
     PCCX_CHECK_ARG(y && idx && out, "pccx_gather_max: null pointer");
     PCCX_CHECK_ARG(B > 0 && N >= 1 && M >= 1 && ns >= 1 && C >= 4 && C % 4 == 0, "pccx_gather_max: bad shape B=%d N=%d C=%d M=%d ns=%d (C %% 4 == 0)",
                    B, N, C, M, ns);
-    PCCX_CHECK_ARG(B <= 65535, "pccx_gather_max: B=%d exceeds the grid's y dimension", B);
+    const unsigned gy = (unsigned)(B < 65535 ? B : 65535);
     int chunk = (int)((size_t)65536 / ((size_t)N * 4)) & ~3;                  // channels of all N rows in 64 KB
     if (chunk > C) chunk = C;
     if (chunk >= 16) {
         PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_max_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            64 * 1024));
-        hipLaunchKernelGGL(gather_max_kernel<true>, dim3((C + chunk - 1) / chunk, B), dim3(GM_THREADS), (size_t)N * chunk * 4, (hipStream_t)stream, y,
-                           N, C, idx, M, ns, chunk, out);
+        hipLaunchKernelGGL(gather_max_kernel<true>, dim3((C + chunk - 1) / chunk, gy), dim3(GM_THREADS), (size_t)N * chunk * 4, (hipStream_t)stream, y,
+                           B, N, C, idx, M, ns, chunk, out);
     } else {
         chunk = C < 256 ? C : 256;                                            // rows through L2: a workgroup per 256 channels
-        hipLaunchKernelGGL(gather_max_kernel<false>, dim3((C + chunk - 1) / chunk, B), dim3(GM_THREADS), 0, (hipStream_t)stream, y, N, C, idx, M,
-                           ns, chunk, out);
+        hipLaunchKernelGGL(gather_max_kernel<false>, dim3((C + chunk - 1) / chunk, gy), dim3(GM_THREADS), 0, (hipStream_t)stream, y, B, N, C, idx,
+                           M, ns, chunk, out);
     }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;

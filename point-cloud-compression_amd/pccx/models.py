@@ -186,10 +186,14 @@ class AE(nn.Module):
 
     def __init__(self, K, k, d, L):
         super().__init__()
-        if d > 16 or d < 1 or d * L > 128 or K % 16 != 0 or not 16 <= K <= 1024:
+        if d < 1 or L < 1 or K % 16 != 0 or not 16 <= K <= 1024:
             raise _lib.PccxError(
-                f"pccx.AE: the fused kernels cover --d 1..16 (got {d}), --d * --L <= 128 (got {d * L}) and --K a multiple of 16 "
-                f"in 16..1024 (got {K}); the reference's defaults are --K 256 --d 16 --L 7 (compress.py:30-34)")
+                f"pccx.AE: --K must be a multiple of 16 in 16..1024 (got {K}; the reference's octree rate table pn_kit.py:17-23 has "
+                f"64..1024 only) and --d, --L positive (got {d}, {L}); the reference's defaults are --K 256 --d 16 --L 7 "
+                f"(compress.py:30-34)")
+        # the fused transforms cover the bottleneck widths --d 1..16; wider ones (compress.py:31 accepts any) run PointNet and the
+        # decoder through the generic layer kernels, chunked over the patches (correct and slow: encode_generic / decode_generic)
+        self.fused_d = d <= 16
         self.sa = SetAbstraction(npoint=K, K=16, in_channel=0, mlp=[32, 64, 128])
         self.pn = PointNet(3 + 128, [128, 256, 512, d], [True, True, True, False])
         self.inv_pool = LinearStack(nn.Linear(d, 256), nn.ReLU(), nn.Linear(256, 1024), nn.ReLU(),
@@ -218,7 +222,7 @@ class AE(nn.Module):
     def _pn_call(self, points):
         """ae.pn(cat(x_patches, features)): [P, 3 + 128, K] -> raw latent [P, d] (before the sigmoid of compress.py:126)."""
         x = _f32c(points, "ae.pn")
-        if x.dim() != 3 or x.shape[1] != 131 or x.shape[2] % 16 != 0 or not 16 <= x.shape[2] <= 1024:
+        if not self.fused_d or x.dim() != 3 or x.shape[1] != 131 or x.shape[2] % 16 != 0 or not 16 <= x.shape[2] <= 1024:
             return None                                   # not the fused kernel's shape: generic path
         P, _, K = x.shape
         patches = x[:, :3].permute(0, 2, 1).contiguous()
@@ -237,6 +241,19 @@ class AE(nn.Module):
         sd = self.state_dict()
         w = lambda key: sd[key].reshape(sd[key].shape[0], -1)
         lib = _lib.load()
+        if not self.fused_d:
+            # only the SetAbstraction part of the encoder blob is used (ae.sa does not depend on --d): pack it with a 16-wide stand-in
+            # for PointNet's last layer; PointNet and the decoder run through the generic layers (their own lazily packed weights)
+            pad_w, pad_b = torch.zeros(16, 512), torch.zeros(16)
+            enc = _pack("pccx_pack_ae_encoder", lib.pccx_ae_encoder_blob_floats(),
+                        [w("sa.conv0.weight"), sd["sa.conv0.bias"], w("sa.conv1.weight"), sd["sa.conv1.bias"],
+                         w("sa.conv2.weight"), sd["sa.conv2.bias"],
+                         w("pn.mlp_Modules.0.0.weight"), sd["pn.mlp_Modules.0.0.bias"],
+                         w("pn.mlp_Modules.1.0.weight"), sd["pn.mlp_Modules.1.0.bias"],
+                         w("pn.mlp_Modules.2.0.weight"), sd["pn.mlp_Modules.2.0.bias"], pad_w, pad_b], [16])
+            self._enc_blob, self._dec_blob = enc.to(device), None
+            self._dec_b3 = self._sa_b3 = self._pn_b3 = None
+            return self
         enc = _pack("pccx_pack_ae_encoder", lib.pccx_ae_encoder_blob_floats(),
                     [w("sa.conv0.weight"), sd["sa.conv0.bias"], w("sa.conv1.weight"), sd["sa.conv1.bias"],
                      w("sa.conv2.weight"), sd["sa.conv2.bias"],
@@ -307,6 +324,8 @@ class AE(nn.Module):
         None = pccx.DEFAULT_MATMUL.  fused=False forces the two-kernel path (feature map through HBM) in bf16x3 mode."""
         x = _f32c(patches, "AE.encode")
         P, K, _ = x.shape
+        if not self.fused_d:
+            return self.encode_generic(x)
         outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
         sa_matmul, pn_matmul = sa_matmul or _pccx_default_matmul(), pn_matmul or _pccx_default_matmul()
         if fused and sa_matmul == pn_matmul == "bf16x3" and _lib.load().pccx_ae_encode_b3_fused_ok(K):
@@ -328,6 +347,31 @@ class AE(nn.Module):
             self._launch_pn(x, ws, outs, pn_matmul)
         return tuple(outs)
 
+    def encode_generic(self, x, chunk=1024):
+        """encode() for bottleneck widths the fused PointNet does not cover (--d > 16): ae.sa on its kernel (it does not depend on d),
+        ae.pn through the generic layers (pccx_linear* + pccx_group_max), sigmoid spread and round by their kernels -- the statement
+        sequence of compress.py:113-127, ``chunk`` patches at a time (the (chunk, K, 131) rows are the memory bound)."""
+        from .families import sigmoid_spread, round_
+        raws = []
+        for i in range(0, x.shape[0], chunk):
+            xt = x[i:i + chunk].permute(0, 2, 1).contiguous()                  # (p, 3, K)
+            _, feat = self.sa(xt)                                              # compress.py:113-115
+            raws.append(self.pn(torch.cat((xt, feat), dim=1)))                 # compress.py:116-121
+        raw = torch.cat(raws) if raws else torch.empty(0, self.d, device=x.device)
+        latent = sigmoid_spread(raw, self.L)                                   # AE.py:43-44
+        return raw, latent, round_(latent)                                     # AE.py:45
+
+    def decode_generic(self, q, chunk=1024):
+        """latent_q (P, d) -> raw decoder output (P, k, 3) through ae.inv_pool / ae.inv_mlp on the generic layers
+        (decompress.py:97-102), ``chunk`` patches at a time (inv_pool's (chunk, k * 128) rows are the memory bound)."""
+        outs = []
+        for i in range(0, q.shape[0], chunk):
+            lq = q[i:i + chunk]
+            lin = self.inv_pool(lq).view(lq.shape[0], -1, self.k)                                  # :97-98
+            mlp_in = torch.cat((lin, lq.unsqueeze(-1).tile((1, 1, self.k))), dim=1)                # :99-100
+            outs.append(self.inv_mlp(mlp_in).transpose(2, 1).contiguous())                         # :101-102
+        return torch.cat(outs) if outs else torch.empty(0, self.k, 3, device=q.device)
+
     def _b3_blob(self, device):
         """bf16x3 planes of the decoder's big Linear, built on the device from the packed fp32 blob."""
         _, dec = self._blobs(device)
@@ -344,6 +388,16 @@ class AE(nn.Module):
         matmul = matmul or _pccx_default_matmul()
         q = _f32c(latent_q, "AE.decode")
         P = q.shape[0]
+        if not self.fused_d:
+            raw = self.decode_generic(q)
+            if centres is None:
+                return raw
+            B = P // S
+            pc = torch.empty(B, S * self.k, 3, device=q.device, dtype=torch.float32)
+            _lib.call("pccx_reassemble", raw.data_ptr(), P, self.k, float(scale), _f32c(centres.reshape(P, 3), "AE.decode.centres").data_ptr(),
+                      _f32c(center.reshape(B, 3), "AE.decode.center").data_ptr(), _f32c(longest.reshape(B), "AE.decode.longest").data_ptr(),
+                      int(S), float(margin), pc.data_ptr(), _stream())
+            return pc
         _, dec = self._blobs(q.device)
         if matmul == "bf16x3":
             fn, extra = "pccx_ae_decode_b3", (self._b3_blob(q.device).data_ptr(),)
@@ -389,7 +443,15 @@ class ConditionalProbabilityModel(nn.Module):
         self._blob = None
         return r
 
+    def fused_ok(self, S=16):
+        """The fused kernel covers d <= 16, L <= 15, d * L <= 128 and S a multiple of 16; everything else takes the generic layers."""
+        return self.d <= 16 and self.L <= 15 and self.d * self.L <= 128 and S % 16 == 0 and S >= 16
+
     def pack(self, device="cuda"):
+        if not self.fused_ok():
+            self._blob = None
+            self._generic = None
+            return self
         sd = self.state_dict()
         w = lambda key: sd[key].reshape(sd[key].shape[0], -1)
         blob = _pack("pccx_pack_prob", _lib.load().pccx_prob_blob_floats(),
@@ -405,6 +467,8 @@ class ConditionalProbabilityModel(nn.Module):
         """sampled_xyz (B,S,3) -> dict with any of pmf (B,S,d,L), cdf (B,S,d,L+1), cdf_int (int32)."""
         x = _f32c(sampled_xyz, "ConditionalProbabilityModel")
         B, S, _ = x.shape
+        if not self.fused_ok(S):
+            return self._run_generic(x, want)
         if self._blob is None or self._blob.device != x.device:
             self.pack(x.device)
         r = {}
@@ -417,6 +481,35 @@ class ConditionalProbabilityModel(nn.Module):
         p = lambda k: r[k].data_ptr() if k in r else None
         _lib.call("pccx_prob_forward", x.data_ptr(), B, S, self.d, self.L, self._blob.data_ptr(), p("pmf"), p("cdf"),
                   p("cdf_int"), _stream())
+        return r
+
+    def _run_generic(self, x, want):
+        """AE.ConditionalProbabilityModel.forward (AE.py:107-123) + pmf_to_cdf + torchac's integer CDF through the generic layers,
+        for --d / --L / S outside the fused kernel's shapes: model_pn (generic PointNet), the three 1x1 convolutions as generic
+        layers on the (B*S, 259) rows, then pccx_softmax_cdf."""
+        from .families import FoldedLinear
+        B, S, _ = x.shape
+        if getattr(self, "_generic", None) is None or self._generic[0] != x.device:
+            mods = list(self.model_mlp)
+            layers = [FoldedLinear(m.weight, m.bias, i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU), None, x.device)
+                      for i, m in enumerate(mods) if isinstance(m, nn.Conv2d)]
+            object.__setattr__(self, "_generic", (x.device, layers))
+        feature = self.model_pn(x.transpose(1, 2).contiguous())                                    # AE.py:111-112  (B, 256)
+        rows = torch.cat((x, feature[:, None, :].expand(B, S, feature.shape[1])), dim=2).reshape(B * S, -1)   # :113-115
+        buf = torch.zeros(B * S, (rows.shape[1] + 3) // 4 * 4, device=x.device, dtype=torch.float32)           # 16-byte rows
+        buf[:, :rows.shape[1]] = rows
+        rows = buf[:, :rows.shape[1]]
+        for layer in self._generic[1]:
+            rows = layer(rows)                                                                     # :117  (B*S, d*L)
+        r = {}
+        if "pmf" in want:
+            r["pmf"] = torch.empty(B, S, self.d, self.L, device=x.device, dtype=torch.float32)
+        if "cdf" in want:
+            r["cdf"] = torch.empty(B, S, self.d, self.L + 1, device=x.device, dtype=torch.float32)
+        if "cdf_int" in want:
+            r["cdf_int"] = torch.empty(B, S, self.d, self.L + 1, device=x.device, dtype=torch.int32)
+        p = lambda k_: r[k_].data_ptr() if k_ in r else None
+        _lib.call("pccx_softmax_cdf", rows.contiguous().data_ptr(), B * S * self.d, self.L, p("pmf"), p("cdf"), p("cdf_int"), _stream())   # :119-123
         return r
 
     def forward(self, sampled_xyz):

@@ -49,11 +49,13 @@ def test_version_and_error_string():
 
 
 def test_model_limits_name_the_reference_flags():
-    """compress.py:30-34 accepts any --K / --d / --L; the fused kernels cover --d <= 16, --d * --L <= 128 and --K % 16 == 0 in
-    16..1024 (known limits).  Outside that range the constructor refuses loudly and names the flags, before any GPU work."""
+    """compress.py:30-34 accepts any --K / --d / --L.  --d and --L are unrestricted here too (widths beyond the fused kernels' 16 /
+    d * L <= 128 take the generic layers, tests/test_gpu_model.py); --K must be a multiple of 16 in 16..1024 (the reference's own
+    octree rate table, pn_kit.py:17-23, stops at 1024): refused loudly, naming the flag, before any GPU work."""
     import pytest as _pt
     from pccx import models
-    for K, k, d, L, word in ((256, 128, 32, 7, "--d"), (256, 128, 16, 9, "--L"), (250, 125, 16, 7, "--K"), (2048, 1024, 16, 7, "--K")):
-        with _pt.raises(_lib.PccxError, match=word):
+    for K, k, d, L in ((250, 125, 16, 7), (2048, 1024, 16, 7), (256, 128, 0, 7)):
+        with _pt.raises(_lib.PccxError, match="--K"):
             models.AE(K, k, d, L)
-    models.AE(512, 256, 8, 16)          # d * L = 128: the edge is inside
+    assert models.AE(256, 128, 32, 7).fused_d is False and models.AE(512, 256, 8, 16).fused_d is True
+    assert models.ConditionalProbabilityModel(9, 16).fused_ok(64) is False and models.ConditionalProbabilityModel(7, 16).fused_ok(64) is True

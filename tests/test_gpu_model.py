@@ -443,3 +443,56 @@ def test_patch_knn16_table_equals_the_oracle_sets_and_feeds_the_fused_encoder(Kx
         _lib.call("pccx_ae_encode_b3_ws", x.data_ptr(), P, Kx, enc.data_ptr(), ae._sa_b3_blob(x.device).data_ptr(), ae._pn_b3_blob(x.device).data_ptr(),
                   d, L, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), tab.data_ptr(), st)
         assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+@pytest.mark.parametrize("dx,Lx", [(20, 9), (32, 7), (16, 9)])
+def test_bottleneck_widths_beyond_the_fused_kernels_take_the_generic_layers(dx, Lx, matmul_mode):
+    """compress.py:30-34 accepts any --d / --L.  The fused PointNet / decoder cover d <= 16 and the fused probability model
+    d * L <= 128; beyond that models.AE / ConditionalProbabilityModel run the same statements through the generic layer kernels
+    (encode_generic / decode_generic / _run_generic + pccx_softmax_cdf + pccx_reassemble).  Against the oracle modules at the
+    tolerances of the fused path: latents 5e-5, symbols equal away from rounding boundaries, decoder output 2e-5, pmf 2e-6, integer
+    CDF within +-1; and a whole compress -> decompress of one cloud reproduces the oracle's reconstruction."""
+    from oracle import ref_pipeline
+    from pccx import codec
+    from pccx import synth as cloud_synth
+    Kx, kx = 64, 32
+    ae = models.AE(Kx, kx, dx, Lx)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    prob = models.ConditionalProbabilityModel(Lx, dx)
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, synth.PROB_SEED, gain=synth.PROB_GAIN))
+    oae = ref_model.AE(Kx, kx, dx, Lx).eval()
+    oae.load_state_dict(ae.state_dict())
+    oprob = ref_model.ConditionalProbabilityModel(Lx, dx).eval()
+    oprob.load_state_dict(prob.state_dict())
+    ae.pack("cuda")
+    prob.pack("cuda")
+    assert ae.fused_d == (dx <= 16) and not prob.fused_ok(64)
+    rng = np.random.default_rng(dx * 100 + Lx)
+    x = (rng.random((7, Kx, 3)).astype(np.float32) - 0.5)
+    raw, latent, q = ae.encode(torch.from_numpy(x).cuda())
+    with torch.no_grad():
+        olat = oae.encode(torch.from_numpy(x))
+        oq = olat.round()
+        odec = oae.decode(oq)
+    np.testing.assert_allclose(latent.cpu().numpy(), olat.numpy(), rtol=0, atol=5e-5)
+    _symbols_agree(q.cpu().numpy(), olat.numpy(), oq.numpy())
+    np.testing.assert_allclose(ae.decode(oq.cuda()).cpu().numpy(), odec.numpy(), rtol=1e-4, atol=2e-5)
+    cent = ((rng.integers(0, 64, size=(2, 64, 3)) + 0.5) / 64).astype(np.float32)
+    r = prob.run(torch.from_numpy(cent).cuda(), ("pmf", "cdf", "cdf_int"))
+    with torch.no_grad():
+        opmf = oprob(torch.from_numpy(cent))
+    np.testing.assert_allclose(r["pmf"].cpu().numpy(), opmf.numpy(), rtol=0, atol=2e-6)
+    want = ref_model.cdf_float_to_int(ref_model.pmf_to_cdf(opmf))
+    diff = ((r["cdf_int"].cpu().numpy().astype(np.int64) - want.astype(np.int64) + 32768) % 65536) - 32768
+    assert np.abs(diff).max() <= 1
+    # the whole path on one cloud (N = 2048, K = 64: S = 64 patches), against the oracle loop
+    pc = cloud_synth.cad_cloud(77, 2048)
+    cd = codec.Codec(ae, prob, K=Kx)
+    comp = cd.compress(torch.from_numpy(pc)[None].cuda(), [5], keep_extras=True)
+    out = cd.decompress(comp)
+    o, _ = ref_pipeline.compress_one(pc, oae, oprob, 5, K=Kx)
+    s_, p_, c_ = comp.files(0)
+    assert s_ == o["s"] and c_ == o["c"]
+    qg = comp.extras["latent_q"].view(64, dx).cpu().numpy()
+    want_pc, _ = ref_pipeline.decompress_one(s_, p_, c_, oae, oprob, latent_q_override=qg.copy())
+    np.testing.assert_allclose(out[0].cpu().numpy(), want_pc, rtol=0, atol=2e-5 * float(comp.c[0, 3]))
