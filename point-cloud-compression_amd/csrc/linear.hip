@@ -337,28 +337,37 @@ __global__ void group_max_kernel(const float *__restrict__ x, long long G, int K
 // product on every one of the B x 256 rows (0.8 of the decoder's matrix work) and the planes of their concatenation (3 GB per 2048
 // patches).  fp32 fmaf chain on top of base; not bit-identical to the single long dot product (summation order), well inside the
 // 1e-5 parity bar of the family tests.
-__global__ __launch_bounds__(256) void rows_affine_small_kernel(const float *__restrict__ base, int C, long long div, const float *__restrict__ x,
-                                                               int ldx, int Ks, long long mod, const float *__restrict__ w, int relu,
-                                                               long long M, float *__restrict__ out)
+__global__ __launch_bounds__(256) void rows_affine_small_kernel(const float *__restrict__ base, int C, unsigned div, const float *__restrict__ x,
+                                                               int ldx, int Ks, unsigned mod, const float *__restrict__ w, int relu,
+                                                               unsigned M, unsigned rows_per_block, float *__restrict__ out)
 {
+    // a thread keeps FOUR fixed channels (its Ks x 4 weights in registers) and walks the rows of its block: no per-element division
     const int c4n = C >> 2;
-    const long long total = M * c4n;
-    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
-        const long long r = it / c4n;
-        const int c = (int)(it - r * c4n) * 4;
-        const float *xr = x + (mod ? r % mod : r) * ldx;
-        float4 v = *(const float4 *)(base + (r / div) * C + c);
-        float a[4] = {v.x, v.y, v.z, v.w};
-        for (int k = 0; k < Ks; ++k) {
-            const float xk = xr[k];
+    const int cq = threadIdx.x % c4n, rl = threadIdx.x / c4n, rstep = 256 / c4n;      // 256 % c4n == 0 (checked by the launcher)
+    const int c = 4 * cq;
+    float wk[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = fmaf(xk, w[(size_t)(c + u) * Ks + k], a[u]);
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wk[k][u] = k < Ks ? w[(size_t)(c + u) * Ks + k] : 0.f;
+    const unsigned r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    for (unsigned r = r0 + rl; r < r1; r += rstep) {
+        const float *xr = x + (size_t)(mod ? r % mod : r) * ldx;
+        const float4 v = *(const float4 *)(base + (size_t)(r / div) * C + c);
+        float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < Ks) {
+                const float xk = xr[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = fmaf(xk, wk[k][u], a[u]);
+            }
         }
         if (relu) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[u] = fmaxf(a[u], 0.f);
         }
-        *(float4 *)(out + r * C + c) = make_float4(a[0], a[1], a[2], a[3]);
+        *(float4 *)(out + (size_t)r * C + c) = make_float4(a[0], a[1], a[2], a[3]);
     }
 }
 
@@ -367,12 +376,16 @@ extern "C" int pccx_rows_affine_small(const float *base, int C, int64_t div, con
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(base && x && w && out, "pccx_rows_affine_small: null pointer");
-    PCCX_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0 && Ks >= 1 && Ks <= 4 && ldx >= Ks && div >= 1 && mod >= 0,
-                   "pccx_rows_affine_small: bad arguments (C=%d Ks=%d)", C, Ks);
-    long long blocks = (M * (C >> 2) + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(rows_affine_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, base, C, (long long)div, x, ldx, Ks,
-                       (long long)mod, w, relu, (long long)M, out);
+    const int c4n = C >> 2;
+    PCCX_CHECK_ARG(M > 0 && M < 0x7fffffffLL && C >= 4 && C % 4 == 0 && c4n <= 256 && 256 % c4n == 0 && Ks >= 1 && Ks <= 4 && ldx >= Ks && div >= 1 &&
+                       div < 0x7fffffffLL && mod >= 0 && mod < 0x7fffffffLL,
+                   "pccx_rows_affine_small: bad arguments (C=%d must be 4 x a power of two <= 1024, Ks=%d in 1..4)", C, Ks);
+    const unsigned rstep = 256 / c4n;
+    unsigned rpb = (unsigned)((M + 8191) / 8192);                              // about 32 workgroups per CU
+    if (rpb < 8 * rstep) rpb = 8 * rstep;
+    rpb = (rpb + rstep - 1) / rstep * rstep;
+    hipLaunchKernelGGL(rows_affine_small_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, base, C, (unsigned)div, x, ldx,
+                       Ks, (unsigned)mod, w, relu, (unsigned)M, rpb, out);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -431,7 +431,8 @@ class PPPF_AE(_Packable):
         q = round_(pk["enc"](latent))                                               # :139-142
         lat_dec = pk["dec"](q)                                                      # :145
         P = self.decoder.num_points
-        if self.split_fold and B > 0 and pk["mlp1"][0].N % 4 == 0 and pk["mlp2"][0].N % 4 == 0:
+        pow2x4 = lambda n: n % 4 == 0 and n <= 1024 and (n // 4) & (n // 4 - 1) == 0     # widths pccx_rows_affine_small takes
+        if self.split_fold and B > 0 and pow2x4(pk["mlp1"][0].N) and pow2x4(pk["mlp2"][0].N):
             # The folding inputs [grid | latent] and [coarse | latent] (:99-106) are never built: their 1024-wide latent part is the
             # same for the P points of a patch, so the first layer of each MLP is W_lat latent + bias once per PATCH (a Linear on B
             # rows) plus a 2- / 3-term per-point update with ReLU (pccx_rows_affine_small); the remaining layers run on the P rows.

@@ -95,6 +95,18 @@ def main():
     row("nn_dist as unfused bytes", ms, "hbm", B * N * N * 12, "GB/s", HBM_PEAK, "8192^2*12 B per cloud per direction if read from HBM "
         "per pair (SURVEY 8d) -- served from LDS tiles instead")
 
+    # ---- round 3: the in-patch 16-NN selection as a kernel of its own (csrc/patch_knn.hip): vector-ALU bound
+    from pccx import _lib
+    pt0 = patches.reshape(B * S, K, 3)
+    tab = torch.empty(_lib.load().pccx_patch_knn16_bytes(B * S, K), dtype=torch.uint8, device=dev)
+    st_ = torch.cuda.current_stream().cuda_stream
+    ms = timed(lambda: _lib.call("pccx_patch_knn16", pt0.data_ptr(), B * S, K, tab.data_ptr(), st_), args.iters)
+    winst = B * S * K * K * 27.0 / 64                                          # 27 vector instructions per (point, candidate) pair
+    rows.append({"kernel": "patch_knn16 (16-NN inside every 256-point patch)", "ms_per_launch": round(ms, 4), "bound": "valu",
+                 "achieved": round(winst / (ms * 1e-3) / 1e9, 1), "peak": round(1024 * 2.4 / 2, 1), "unit": "G wave-instr/s",
+                 "frac": round(winst / (ms * 1e-3) / 1e9 / (1024 * 2.4 / 2), 4), "algorithmic_work_per_launch": winst,
+                 "note": "pn_kit.py:186-190; peak = 1024 SIMDs x one wave64 instruction per 2 cycles at 2.4 GHz; 8 waves per SIMD"})
+
     ae = models.AE(K, k, d, L)
     prob = models.ConditionalProbabilityModel(L, d)
     ae.pack(dev)
@@ -161,6 +173,40 @@ def main():
         row(f"planes_gemm {K_}->{N_} on {M3} rows" + (" + max over 128" if epi == 2 else ""), ms, "mfma", 2.0 * M3 * K_ * N_, "TFLOP/s",
             round(MFMA_B3_PEAK, 1), "sa3 of PPPF_AE.py:32-34; 6 B per activation in" + ("" if epi == 2 else " and out"))
         del pin
+    # ---- round 3: PointnetSAModule on source rows (families.PointnetSAModule.dedup): the group maxima and FoldingNet's per-point update
+    for name, nsrc, Cc, npoint, ns in (("sa1", 512, 128, 512, 32), ("sa2", 512, 256, 128, 64), ("sa3", 128, 1024, 32, 128)):
+        y = torch.randn(PB, nsrc, Cc, device=dev)
+        idx = torch.randint(-1, nsrc, (PB, npoint, ns), device=dev)
+        ms = timed(lambda: families.gather_max(y, idx), args.iters)
+        row(f"gather_max {name}: {npoint} groups x {ns} samples x {Cc} ch from {nsrc} rows, 2048 patches", ms, "lds", PB * npoint * ns * Cc * 4.0,
+            "GB/s", 256 * 256 * 2.4, "pointnet_sa_module.py:27-28,91 without the gathered tensor; bytes read from the LDS tile (peak 256 B/clk/CU "
+            "at 2.4 GHz); HBM minimum is the (B, N, C) input once")
+        del y, idx
+    base_ = torch.randn(PB, 512, device=dev)
+    grid_ = torch.rand(256, 2, device=dev)
+    wsm = torch.randn(512, 2, device=dev)
+    ms = timed(lambda: families.rows_affine_small(base_, 256, grid_, 256, wsm, True, PB * 256), args.iters)
+    row("rows_affine_small (FoldingNet layer 0, per-point part) 524288 x 512", ms, "hbm", PB * 256 * 512 * 4.0, "GB/s", HBM_PEAK,
+        "PPPF_AE.py:99-104: one write of the (B*P, 512) rows; the per-patch part is a Linear on B rows")
+    # ---- round 3: the training step's weight-stream Linears and column reductions (csrc/train.hip)
+    Wb = torch.randn(24576, 1024, device=dev)
+    xb = torch.randn(4, 1024, device=dev)
+    ob = torch.empty(4, 24576, device=dev)
+    ms = timed(lambda: _lib.call("pccx_linear_skinny", xb.data_ptr(), 4, 1024, 1024, Wb.data_ptr(), None, 24576, 0, ob.data_ptr(), 24576, st_), args.iters)
+    row("linear_skinny forward 4 x 1024 -> 24576 (pppe expansion layer)", ms, "hbm", 24576 * 1024 * 4.0, "GB/s", HBM_PEAK, "pppe_pcd_ae.py:706-714: the "
+        "100 MB weight read once")
+    dzb = torch.randn(4, 24576, device=dev)
+    dxb = torch.zeros(4, 1024, device=dev)
+    ms = timed(lambda: _lib.call("pccx_linear_skinny_dx", dzb.data_ptr(), 4, 24576, 24576, Wb.data_ptr(), 1024, 0, dxb.data_ptr(), 1024, st_), args.iters)
+    row("linear_skinny dX 4 x 24576 . (24576 x 1024), split-K", ms, "hbm", 24576 * 1024 * 4.0, "GB/s", HBM_PEAK, "the same weight read once; round 2's "
+        "generic layer took 2.2 ms for this call")
+    zb = torch.randn(131072, 64, device=dev)
+    mean_, rstd_ = torch.empty(64, device=dev), torch.empty(64, device=dev)
+    sums_ = torch.zeros(128, device=dev, dtype=torch.float64)
+    ms = timed(lambda: _lib.call("pccx_bn_train_stats", zb.data_ptr(), 131072, 64, 1e-5, 0.1, sums_.data_ptr(), mean_.data_ptr(), rstd_.data_ptr(), None,
+                                 None, st_), args.iters)
+    row("bn_train_stats (column moments) 131072 x 64", ms, "hbm", 131072 * 64 * 4.0, "GB/s", HBM_PEAK, "one read of the activation; zero-fill + reduce "
+        "+ finalize launches included")
     print(json.dumps({"device": torch.cuda.get_device_name(0), "clouds_per_launch": B, "points_per_cloud": N, "rows": rows}, indent=1))
 
 
