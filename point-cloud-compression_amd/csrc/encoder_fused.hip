@@ -306,6 +306,13 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         }
         f32x4 a3[1][1];
         a3[0][0] = *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
+#ifdef FU_CACHE_PLANES
+        // layer 1's activation kept as its bf16 planes (96 registers) instead of as fp32 (64) and split again for each half of
+        // layer 2: 8 splits per pass instead of 16, the same values
+        bf16x8 p1[8][3];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) b3_split8(relu4(a1p[0][2 * kt]), relu4(a1p[0][2 * kt + 1]), p1[kt]);
+#endif
 #pragma clang loop unroll(full)
         for (int h = 0; h < 2; ++h) {                     // layer 2 in two halves of 16 output tiles
             f32x4 a2p[1][16];
@@ -314,7 +321,11 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
 #pragma clang loop unroll(full)
             for (int kt = 0; kt < 8; ++kt) {
                 bf16x8 pl[1][1][3];
+#ifdef FU_CACHE_PLANES
+                pl[0][0][0] = p1[kt][0]; pl[0][0][1] = p1[kt][1]; pl[0][0][2] = p1[kt][2];
+#else
                 b3_split8(relu4(a1p[0][2 * kt]), relu4(a1p[0][2 * kt + 1]), pl[0][0]);
+#endif
                 dense_b3_stream<1, 16, 1>(ws, f, pl, a2p);
             }
 #pragma clang loop unroll(full)

@@ -351,8 +351,12 @@ static int launch_col_reduce(int mode, const float *A, const float *Y, const flo
         if (rpb < 8 * rstep) rpb = 8 * rstep;
         rpb = (rpb + rstep - 1) / rstep * rstep;
         const unsigned blocks = (unsigned)((M + rpb - 1) / rpb);
-        PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
-        if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
+        if (o1 == o0 + C) {
+            PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * 2 * C, st));          // both sums in one launch
+        } else {
+            PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
+            if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
+        }
         if (mode == 0) hipLaunchKernelGGL(col_reduce4_kernel<0>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1);
         else if (mode == 1) hipLaunchKernelGGL(col_reduce4_kernel<1>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1);
         else hipLaunchKernelGGL(col_reduce4_kernel<2>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1);
@@ -447,6 +451,14 @@ __global__ void cast_d2f_kernel(const double *__restrict__ a, int n, float *__re
     if (i < n) o[i] = accumulate ? o[i] + (float)a[i] : (float)a[i];
 }
 
+// g_gamma[i] += sums[i], g_beta[i] += sums[C + i] in one launch
+__global__ void cast2_d2f_kernel(const double *__restrict__ a, int C, float *__restrict__ o0, float *__restrict__ o1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) o0[i] = o0[i] + (float)a[i];
+    else if (i < 2 * C) o1[i - C] = o1[i - C] + (float)a[i];
+}
+
 extern "C" int pccx_bn_relu_backward(const float *dY, const float *Y, const float *Z, int64_t M, int C, const float *mean,
                                      const float *rstd, const float *gamma, double *sums, float *dZ, float *g_gamma,
                                      float *g_beta, void *stream)
@@ -460,8 +472,7 @@ extern "C" int pccx_bn_relu_backward(const float *dY, const float *Y, const floa
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dY, Y, Z, (long)M * C, C, (long)M, mean,
                        rstd, gamma, sums, sums + C, dZ);
-    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, g_gamma, 1);
-    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums + C, C, g_beta, 1);
+    hipLaunchKernelGGL(cast2_d2f_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, sums, C, g_gamma, g_beta);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
