@@ -29,6 +29,11 @@ static_assert(((PN_B3_STREAM_FRAGS + FU_CHUNK - 1) / FU_CHUNK) * FU_CHUNK <= PN_
 #ifndef FU_NB
 #define FU_NB 2                                          // ring buffers (chunks in flight + the one being read)
 #endif
+#ifdef FU_COUNTED_WAITS
+#define FU_DENSE dense_b3_stream_pw                      // ring reads as inline assembly with counted lgkmcnt waits (mfma_chain.h): measured
+#else                                                    // equal to the compiler's full waits (48.29 / 48.59 against 48.44 / 48.62 ms): with
+#define FU_DENSE dense_b3_stream                         // two waves per SIMD the partner covers the exposed LDS latency.  Default: the compiler's
+#endif
 #define FU_STAGE_STRIDE 132                               // floats per staged point: 128 channels + 4 (bank rotation)
 #define FU_STAGE_WAVE (16 * FU_STAGE_STRIDE)              // floats per wave
 #define FU_W1_FRAGS (1 * 4 * 3)
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
         f32x4 a0[1][8];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) a0[0][mt] = *(const f32x4 *)(blob + ENC_PN_B0 + 16 * mt + 4 * g);
-        dense_b3_stream<5, 8, 1>(ws, f, i0p, a0);
+        FU_DENSE<5, 8, 1>(ws, f, i0p, a0);
         f32x4 a1p[1][16];
         {
             bf16x8 i1p[1][4][3];
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
             for (int t = 0; t < 4; ++t) b3_split8(relu4(a0[0][2 * t]), relu4(a0[0][2 * t + 1]), i1p[0][t]);
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) a1p[0][mt] = *(const f32x4 *)(blob + ENC_PN_B1 + 16 * mt + 4 * g);
-            dense_b3_stream<4, 16, 1>(ws, f, i1p, a1p);
+            FU_DENSE<4, 16, 1>(ws, f, i1p, a1p);
         }
         f32x4 a3[1][1];
         a3[0][0] = *(const f32x4 *)(blob + ENC_PN_B3 + 4 * g);
@@ -326,13 +331,13 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_b3_kernel(const float *_
 #else
                 b3_split8(relu4(a1p[0][2 * kt]), relu4(a1p[0][2 * kt + 1]), pl[0][0]);
 #endif
-                dense_b3_stream<1, 16, 1>(ws, f, pl, a2p);
+                FU_DENSE<1, 16, 1>(ws, f, pl, a2p);
             }
 #pragma clang loop unroll(full)
             for (int kt = 0; kt < 8; ++kt) {              // layer 3 over these 256 channels (no ReLU after it, AE.py:17)
                 bf16x8 pl[1][1][3];
                 b3_split8(relu4(a2p[0][2 * kt]), relu4(a2p[0][2 * kt + 1]), pl[0][0]);
-                dense_b3_stream<1, 1, 1>(ws, f, pl, a3);
+                FU_DENSE<1, 1, 1>(ws, f, pl, a3);
             }
         }
         ws.drain();

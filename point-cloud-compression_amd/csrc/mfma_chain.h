@@ -194,6 +194,7 @@ typedef __attribute__((address_space(3))) unsigned int lds_u32;
 // has just vacated (NB = 2: one chunk ahead).
 template <int CH, int NB = 2, int NW = 4>
 struct WStreamT {
+    static constexpr int chunk_frags = CH, buffers = NB;
     const float *g;                       // global stream, NCH * CH fragments, wave-uniform
     f32x4 *lds;                           // [NB][CH][64]
     int nch;                              // chunks per pass (a multiple of NB when wrap)
@@ -227,7 +228,10 @@ struct WStreamT {
     }
     __device__ __forceinline__ void boundary(int c) const     // before the first read of chunk c
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // vmcnt(0): the wave's own DMA pieces of chunk c have landed.  lgkmcnt(0): its LDS reads of chunk c - 1's buffer have
+        // RETURNED before the barrier lets anyone refill that buffer -- the compiler adds this itself for reads it tracks, but the
+        // counted-wait readers (dense_b3_stream_pw) issue theirs as inline assembly, which it does not see
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         issue_ahead(c);
     }
@@ -350,3 +354,80 @@ __device__ __forceinline__ void dense_b3_stream(const WS &ws, int &f, const bf16
     f += 3 * KT * MT;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// dense_b3_stream with the LDS reads of the weight blocks issued as inline assembly and waited for by COUNT.
+// Why: while an LDS-DMA (global_load_lds) is in flight -- i.e. during every chunk of the weight ring -- hipcc (ROCm 7.2) answers each
+// use of a ds_read result with s_waitcnt lgkmcnt(0).  With the loads of block group g+1 issued ahead of group g's MFMAs, as here,
+// that drains the six reads it has JUST issued before the first MFMA of every other group (the alternate groups then need no wait):
+// the full LDS latency exposed once per 24 MFMAs.  Without a DMA in the kernel the same source compiles to the counted waits
+// lgkmcnt(9) / lgkmcnt(6) (tools/experiments/r3: -DK_NODMA).  The compiler does not track these reads at all, so the wait is placed by
+// hand: LDS returns in order, lgkmcnt(n) = "all but the youngest n LDS/SMEM operations are done", and any further operation the
+// compiler puts in flight only makes the wait longer, never shorter.  The wait asm names the registers it guards as in/out operands,
+// so no MFMA that reads them can be scheduled above it.
+// ------------------------------------------------------------------------------------------
+// base = LDS byte address of the ring's fragment 0 for this lane (one VGPR for every read); byte_off: a compile-time constant after
+// unrolling (the ring is at most 64 KiB, the instruction's offset field 16 bits)
+__device__ __forceinline__ bf16x8 lds_read_frag_async(unsigned base, int byte_off)
+{
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(byte_off) : "memory");
+    return v;
+}
+
+template <int N, int MG>
+__device__ __forceinline__ void lds_wait_keep(bf16x8 (&c)[MG][3])
+{
+    if constexpr (MG == 2)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]) : "n"(N) : "memory");
+}
+
+template <int KT, int MT, int NT, class WS>
+__device__ __forceinline__ void dense_b3_stream_pw(const WS &ws, int &f, const bf16x8 (&in)[NT][KT][3], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= 2 ? 2 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    constexpr int CH = WS::chunk_frags, NB = WS::buffers;
+    static_assert(NB * CH * 1024 <= 65536, "the ring must fit the 16-bit offset field of ds_read");
+    unsigned base = (unsigned)(uintptr_t)(ws.lds + ws.lane);         // LDS offset = low half of the generic address
+    asm volatile("" : "+v"(base));                                   // ONE address register; offsets are immediates
+    auto frag = [&](int fi) {                                        // fragment fi of the pass: ring boundary, then the read
+        if ((fi % CH) == 0) ws.boundary(fi / CH);
+        return lds_read_frag_async(base, (((fi / CH) % NB) * CH + (fi % CH)) * 1024);
+    };
+    bf16x8 cur[MG][3], nxt[MG][3];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) cur[m][p] = frag(f + 3 * m + p);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) nxt[m][p] = frag(f + 3 * ((gi + 1) * MG + m) + p);
+            lds_wait_keep<3 * MG, MG>(cur);                          // cur has landed; the 3 * MG reads of nxt may still fly
+        } else
+            lds_wait_keep<0, MG>(cur);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) cur[m][p] = nxt[m][p];
+    }
+    f += 3 * KT * MT;
+}

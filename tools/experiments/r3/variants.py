@@ -18,3 +18,4 @@ VARIANTS["ch8nb8"] = (PRODUCT, ["-fno-honor-nans", "-DFU_CHUNK=8", "-DFU_NB=8"])
 VARIANTS["round2"] = (KN, [])                     # the round-2 kernel as it was (in-kernel selection, canonicalising v_max)
 VARIANTS["product"] = (PRODUCT, ["-fno-honor-nans"])   # what libpccx.so builds
 VARIANTS["cachepl"] = (PRODUCT, ["-fno-honor-nans", "-DFU_CACHE_PLANES"])
+VARIANTS["pwait"] = (PRODUCT, ["-fno-honor-nans", "-DFU_COUNTED_WAITS"])       # counted lgkmcnt waits on the ring reads (inline-asm ds_read)
