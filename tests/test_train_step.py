@@ -446,3 +446,82 @@ def test_data_parallel_graphed_step_is_two_graphs_around_the_allreduce():
     l3 = train.train_step(g3, train.Adam(g3.parameters(), lr=1e-4), x, starts, lam=1e-3, data_parallel=True)
     l4 = train.train_step(g4, train.Adam(g4.parameters(), lr=1e-4), x, starts, lam=1e-3)
     assert abs(l3[0] - l4[0]) <= 1e-5 * abs(l4[0])
+
+
+@pytest.mark.gpu
+def test_round3_training_kernels_against_float64():
+    """The kernels the round-3 training step added, each alone against float64 torch: Linears on 1..8 rows as weight streams
+    (forward, split-K dX, with and without bias, the bf16 autocast rounding), the block-reduced column sums at the narrowest and widest
+    layouts and at row counts that do not divide the row step, clip + Adam over many tensors in two launches (tensors shorter and
+    longer than a workgroup's 1024 elements, with and without clipping), and FoldingNet's per-point update."""
+    from pccx import _lib, families, train
+    rng = np.random.default_rng(3)
+    st = torch.cuda.current_stream().cuda_stream
+    for M, K, N, bias in [(1, 8, 5, True), (8, 1024, 300, False), (4, 24576 // 8, 1000, True), (3, 260, 17, True)]:
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32) if bias else None
+        gz = rng.standard_normal((M, N)).astype(np.float32)
+        xg, Wg = torch.from_numpy(x).cuda().requires_grad_(True), torch.from_numpy(W).cuda().requires_grad_(True)
+        bg = torch.from_numpy(b).cuda().requires_grad_(True) if bias else None
+        z = train.LinearFn.apply(xg, Wg, bg)
+        z.backward(torch.from_numpy(gz).cuda())
+        xr, Wr = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(W).double().requires_grad_(True)
+        zr = xr @ Wr.T + (torch.from_numpy(b).double() if bias else 0.0)
+        zr.backward(torch.from_numpy(gz).double())
+        np.testing.assert_allclose(z.detach().cpu().numpy(), zr.detach().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4 * float(xr.grad.abs().max()))
+        np.testing.assert_allclose(Wg.grad.cpu().numpy(), Wr.grad.numpy(), rtol=1e-4, atol=1e-4 * float(Wr.grad.abs().max()))
+        # the autocast form: operands rounded to bf16, exact products, fp32 accumulation, result rounded to bf16
+        out = torch.empty(M, N, device="cuda")
+        _lib.call("pccx_linear_skinny", xg.detach().data_ptr(), M, K, K, Wg.detach().data_ptr(), bg.detach().data_ptr() if bias else None, N, 2,
+                  out.data_ptr(), N, st)
+        r16 = lambda t: torch.from_numpy(t).to(torch.bfloat16).double()
+        want = (r16(x) @ r16(W).T + (torch.from_numpy(b).double() if bias else 0.0)).float().to(torch.bfloat16).float()
+        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2 ** -7, atol=1e-6)       # one bf16 ulp: the last rounding may tie differently
+    # column sums through BatchNorm(train) + ReLU at the layouts col_reduce4 takes and one it does not
+    for M, Cc in [(5, 4), (1000, 1024), (131, 32), (77, 36)]:
+        z = (rng.standard_normal((M, Cc)) * 2 + 0.3).astype(np.float32)
+        gam, bet = (rng.random(Cc).astype(np.float32) + 0.5), (rng.standard_normal(Cc) * 0.1).astype(np.float32)
+        gy = rng.standard_normal((M, Cc)).astype(np.float32)
+        bn, bnr = torch.nn.BatchNorm1d(Cc).cuda(), torch.nn.BatchNorm1d(Cc).double()
+        zg, gg, bgm = (torch.from_numpy(t).cuda().requires_grad_(True) for t in (z, gam, bet))
+        y = train.BnReluFn.apply(zg, gg, bgm, bn)
+        y.backward(torch.from_numpy(gy).cuda())
+        zr = torch.from_numpy(z).double().requires_grad_(True)
+        with torch.no_grad():
+            bnr.weight.copy_(torch.from_numpy(gam)); bnr.bias.copy_(torch.from_numpy(bet))
+        yr = torch.relu(bnr(zr))
+        yr.backward(torch.from_numpy(gy).double())
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(zg.grad.cpu().numpy(), zr.grad.numpy(), rtol=1e-3, atol=1e-4 * float(zr.grad.abs().max()))
+        np.testing.assert_allclose(gg.grad.cpu().numpy(), bnr.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(bgm.grad.cpu().numpy(), bnr.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # clip_grad_norm_ + Adam over several tensors in two launches, three steps, against torch.optim.Adam in float64
+    shapes = [(3,), (1024,), (1025,), (7, 300), (64, 64), (1,)]
+    for max_norm in (None, 0.05):
+        ps = [torch.nn.Parameter(torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()) for s in shapes]
+        rs = [torch.nn.Parameter(p.detach().cpu().double()) for p in ps]
+        opt, ropt = train.Adam(ps, lr=1e-2), torch.optim.Adam(rs, lr=1e-2)
+        for it in range(3):
+            for p, r in zip(ps, rs):
+                g = rng.standard_normal(tuple(p.shape)).astype(np.float32) * (0.1 if it else 1.0)
+                p.grad, r.grad = torch.from_numpy(g).cuda(), torch.from_numpy(g).double()
+            ps[2].grad, rs[2].grad = None, None                         # a tensor that never gets a gradient stays out of the table
+            opt.step(max_norm=max_norm)
+            if max_norm is not None:
+                torch.nn.utils.clip_grad_norm_([r for r in rs if r.grad is not None], max_norm)
+            ropt.step()
+            for p, r in zip(ps, rs):
+                np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-5, atol=2e-6)
+    # FoldingNet's per-point update: act(base[r // div] + x[r % mod or r] @ w.T)
+    for Cc, Ks, mod in [(512, 2, 256), (128, 3, 0), (4, 1, 0), (1024, 4, 7)]:
+        Bn, Pn = 5, 256
+        base = torch.from_numpy(rng.standard_normal((Bn, Cc)).astype(np.float32)).cuda()
+        xs = torch.from_numpy(rng.standard_normal((mod if mod else Bn * Pn, Ks)).astype(np.float32)).cuda()
+        w = torch.from_numpy(rng.standard_normal((Cc, Ks)).astype(np.float32)).cuda()
+        got = families.rows_affine_small(base, Pn, xs, mod, w, True, Bn * Pn)
+        xn, bn_, wn = xs.cpu().numpy().astype(np.float64), base.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64)
+        rows = xn[np.arange(Bn * Pn) % mod] if mod else xn               # float64 on the host (no library GEMM on the GPU in a test)
+        want = np.maximum(np.repeat(bn_, Pn, axis=0) + rows @ wn.T, 0.0)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
