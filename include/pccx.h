@@ -249,6 +249,38 @@ PCCX_API int pccx_ae_decode_b3(const float *latent_q, int P, int d, int k, const
                                const float *centres, const float *nrm_center, const float *nrm_longest,
                                int S, double margin, float *pc_out, void *stream);
 
+/* The f16x2 arithmetic mode: the same two transforms with every fp32 product formed from TWO fp16 pieces
+ * per operand (hi = rn16(x), lo = rn16(x - hi): 22-23 significant bits, the operand precision of "3xTF32") and three
+ * v_mfma_f32_16x16x32_f16 passes, fp32 accumulate -- half the matrix instructions of bf16x3.  fp16's narrow exponent is handled by
+ * exact power-of-two scales: static ones per layer from rigorous interval bounds of the layers (computed when the weights are
+ * packed) and one per patch from the data (largest |coordinate| / head activation), so no operand can overflow and the lo piece
+ * keeps its bits; powers of two commute with fp32 rounding, so the scaled chain computes what the unscaled one would.
+ * The blobs are built on the HOST from the same state_dict tensors as pccx_pack_ae_encoder / pccx_pack_ae_decoder (HOST pointers,
+ * same argument order) and uploaded by the caller.
+ * pccx_ae_encode_h2_ws replaces compress.py:113-127 (ae.sa, ae.pn, sigmoid spread, round) like pccx_ae_encode_b3_ws; enc_blob is
+ * the fp32 blob (conv0 of SetAbstraction stays an fp32 MFMA), workspace holds the neighbour tables of pccx_patch_knn16.
+ * pccx_ae_decode_h2 replaces AE.py:48-53 / decompress.py:97-116 like pccx_ae_decode_b3; dec_blob is the fp32 blob (the two head
+ * Linears stay fp32 MFMAs). */
+PCCX_API size_t pccx_ae_encoder_h2_blob_floats(void);
+PCCX_API int pccx_pack_ae_encoder_h2(const float *sa_w0, const float *sa_b0, const float *sa_w1, const float *sa_b1,
+                                     const float *sa_w2, const float *sa_b2, const float *pn_w0, const float *pn_b0,
+                                     const float *pn_w1, const float *pn_b1, const float *pn_w2, const float *pn_b2,
+                                     const float *pn_w3, const float *pn_b3, int d, float *h2_blob);
+PCCX_API int pccx_ae_encode_h2_fused_ok(int K);
+PCCX_API size_t pccx_ae_encode_h2_workspace_bytes(int P, int K);
+PCCX_API int pccx_ae_encode_h2_ws(const float *patches, int P, int K, const float *enc_blob, const float *h2_blob, int d, int L,
+                                  float *latent_raw, float *latent, float *latent_q, void *workspace, void *stream);
+PCCX_API size_t pccx_ae_decoder_h2_blob_floats(int k);
+PCCX_API int pccx_pack_ae_decoder_h2(const float *ip_w0, const float *ip_b0, const float *ip_w1, const float *ip_b1,
+                                     const float *ip_w2, const float *ip_b2, const float *m_w0, const float *m_b0,
+                                     const float *m_w1, const float *m_b1, const float *m_w2, const float *m_b2,
+                                     const float *m_w3, const float *m_b3, int k, int d, float *h2_blob);
+PCCX_API size_t pccx_ae_decode_h2_workspace_floats(int P);
+PCCX_API int pccx_ae_decode_h2(const float *latent_q, int P, int d, int k, const float *dec_blob, const float *h2_blob,
+                               float *workspace, float *patches_out, float scale, const float *centres,
+                               const float *nrm_center, const float *nrm_longest, int S, double margin, float *pc_out,
+                               void *stream);
+
 /* AE.ConditionalProbabilityModel.forward (AE.py:107-123) + pn_kit.pmf_to_cdf (pn_kit.py:452-461)
  * + torchac's float-CDF -> 16-bit conversion.  centres: (B,S,3), S % 16 == 0.  Any of the outputs
  * may be NULL: pmf (B,S,d,L) f32; cdf (B,S,d,L+1) f32; cdf_int (B,S,d,L+1) int32 holding uint16. */

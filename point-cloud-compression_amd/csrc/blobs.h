@@ -102,3 +102,55 @@
 #define PRB_STREAM_CHUNKS (4 * ((PRB_STREAM_FRAGS + 4 * PRB_WS_CHUNK - 1) / (4 * PRB_WS_CHUNK)))      // multiple of the ring depth
 #define PRB_BLOB_FLOATS (PRB_STREAM + (size_t)PRB_STREAM_CHUNKS * PRB_WS_CHUNK * 256)
 
+
+// ---- f16x2 mode (mfma_chain.h: two fp16 pieces per operand, three products; pack_h2.hip builds these blobs on the HOST from the
+// state_dict tensors, with the power-of-two scales that keep every operand inside fp16's range).
+// Encoder: [meta][biases, pre-multiplied by their layer's sigma * tau][SetAbstraction conv1 [1][4][2], conv2 [2][8][2] fragments]
+// [PointNet stream: L0 [5][8][2], L1 [4][16][2], per half h of layer 2's outputs L2 [8][16][2] + L3 [8][1][2]], [kt32][mt][plane] each.
+#define ENC_H2_META 0                          // [16] floats, indices H2E_*
+#define H2E_RHO0 0                             // multiplier of the split in front of SetAbstraction conv1 (= sigma0)
+#define H2E_RHO1 1                             // ... in front of conv2 (= sigma1 / (sigma0 tau1))
+#define H2E_INV2 2                             // conv2 accumulator -> feature in patch-scaled units (= 1 / (sigma1 tau2))
+#define H2E_RHO_IN 3                           // split of PointNet's input (= sigma_in)
+#define H2E_RHO_P1 4                           // splits in front of PointNet layers 1, 2, 3
+#define H2E_RHO_P2 5
+#define H2E_RHO_P3 6
+#define H2E_INV_OUT 7                          // last accumulator -> latent in patch-scaled units
+#define ENC_H2_SA_B1 16                        // [64]   b1 * sigma0 * tau1
+#define ENC_H2_SA_B2 (ENC_H2_SA_B1 + 64)       // [128]  b2 (unscaled: added after the neighbour max)
+#define ENC_H2_PN_B0 (ENC_H2_SA_B2 + 128)      // [128]  b * sigma * tau of its layer, likewise below
+#define ENC_H2_PN_B1 (ENC_H2_PN_B0 + 128)      // [256]
+#define ENC_H2_PN_B2 (ENC_H2_PN_B1 + 256)      // [512]
+#define ENC_H2_PN_B3 (ENC_H2_PN_B2 + 512)      // [16]
+#define ENC_H2_PN_BIAS_FLOATS (128 + 256 + 512 + 16)
+#define ENC_H2_SA_W (ENC_H2_PN_B3 + 16)        // 8 + 32 fragments
+#define ENC_H2_SA_W1_FRAGS (1 * 4 * 2)
+#define ENC_H2_SA_W2_FRAGS (2 * 8 * 2)
+#define ENC_H2_PN_STREAM (ENC_H2_SA_W + (ENC_H2_SA_W1_FRAGS + ENC_H2_SA_W2_FRAGS) * 256)
+#define PN_H2_CHUNK 32
+#define PN_H2_STREAM_FRAGS (80 + 128 + 2 * (256 + 16))
+#define PN_H2_STREAM_CHUNKS ((PN_H2_STREAM_FRAGS + PN_H2_CHUNK - 1) / PN_H2_CHUNK)
+#define ENC_H2_BLOB_FLOATS (ENC_H2_PN_STREAM + (size_t)PN_H2_STREAM_CHUNKS * PN_H2_CHUNK * 256)
+
+// Decoder: [meta][biases][one weight stream per point p: GEMM [32 k-steps][8 m-tiles][2 planes], then inv_mlp L0 [5][8][2],
+// L1 [4][4][2], L2 [2][2][2], L3 [1][1][2], padded to chunks of 8 (= 4 m-tiles x 2 planes: half a k-step)]
+#define DEC_H2_META 0
+#define H2D_SIG_H 0                            // scale of the (per-patch normalised) head activation planes
+#define H2D_RHO0 1                             // split in front of inv_mlp layer 0 (GEMM accumulators)
+#define H2D_SIG_Q 2                            // scale of the latent channels of that layer's input (= sigma of layer 0's input)
+#define H2D_RHO1 3
+#define H2D_RHO2 4
+#define H2D_RHO3 5
+#define H2D_INV_OUT 6
+#define DEC_H2_M_B0 16                         // [128]
+#define DEC_H2_M_B1 (DEC_H2_M_B0 + 128)        // [64]
+#define DEC_H2_M_B2 (DEC_H2_M_B1 + 64)         // [32]
+#define DEC_H2_M_B3 (DEC_H2_M_B2 + 32)         // [16]
+#define DEC_H2_G_B (DEC_H2_M_B3 + 16)          // [k*128], rows permuted to p*128+c
+#define DEC_H2_CHUNK 8
+#define DEC_H2_GEMM_FRAGS (32 * 8 * 2)
+#define DEC_H2_TAIL_FRAGS ((40 + 16 + 4 + 1) * 2)
+#define DEC_H2_STREAM_FRAGS (DEC_H2_GEMM_FRAGS + DEC_H2_TAIL_FRAGS)
+#define DEC_H2_STREAM_CHUNKS (4 * ((DEC_H2_STREAM_FRAGS + 4 * DEC_H2_CHUNK - 1) / (4 * DEC_H2_CHUNK)))      // a multiple of the ring depth
+#define DEC_H2_G_W(k) (DEC_H2_G_B + (size_t)(k) * 128)
+#define DEC_H2_BLOB_FLOATS(k) (DEC_H2_G_W(k) + (size_t)(k) * DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK * 256)

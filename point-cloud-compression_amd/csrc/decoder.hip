@@ -48,6 +48,14 @@ __global__ __launch_bounds__(256, 2) void dec_head_kernel(const float *__restric
     }
 }
 
+// the head for decoder_h2.hip (same kernel, same fp32 result; that file adds its own operand preparation)
+int pccx_dec_head_launch(const float *latent_q, int P, int d, int ntiles, const float *dec_blob, float *h2p, hipStream_t st)
+{
+    hipLaunchKernelGGL(dec_head_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, latent_q, P, d, ntiles, dec_blob, (f32x4 *)h2p);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 #ifndef DEC_GROUP
 #define DEC_GROUP 64                       // patch blocks per group of the block order (dec_main_kernel)
 #endif

@@ -1,0 +1,292 @@
+// encoder_fused_h2.hip -- the analysis transform of AE.AE (AE.py:34-45) in one kernel, f16x2 arithmetic:
+//   SetAbstraction (pn_kit.py:146-211) -> PointNet (pn_kit.py:98-144) -> sigmoid spread + round (AE.py:43-45)
+// The structure is encoder_fused.hip's (one patch per workgroup of eight waves; per pass of 128 points: SetAbstraction units handed
+// out from an LDS counter, the channel maxima staged in LDS, read back as PointNet's B operand, the PointNet weight stream through
+// an LDS-DMA ring); what differs is the arithmetic of the matrix products: every fp32 product is formed from TWO fp16 pieces per
+// operand and three v_mfma_f32_16x16x32_f16 passes instead of three bf16 pieces and six passes (mfma_chain.h, "f16x2 operands"),
+// with the exact power-of-two operand scales of pack_h2.hip.  Per patch the kernel adds one more: s = 2^-e <= 1 such that the
+// patch's largest |coordinate| times s is at most 1.  Coordinates and biases are multiplied by s when they are staged (the stack is
+// positively homogeneous in the two), the latent is divided by it at the end; since s is a power of two nothing rounds differently.
+//
+// The in-patch neighbour tables come from patch_knn.hip (pccx_patch_knn16), as in the default bf16x3 form.
+#include <math.h>
+
+#include "blobs.h"
+#include "common.h"
+#include "mfma_chain.h"
+
+#define FH_CHUNK PN_H2_CHUNK                             // fragments per ring chunk
+#ifndef FH_NB
+#define FH_NB 2
+#endif
+#ifndef FH_MG
+#define FH_MG 2                                          // weight blocks in flight per group of the streamed layers
+#endif
+#define FH_STAGE_STRIDE 132                               // floats per staged point: 128 channels + 4 (bank rotation)
+#define FH_STAGE_WAVE (16 * FH_STAGE_STRIDE)
+
+__host__ __device__ inline size_t fh_region_bytes()
+{
+    const size_t ring = (size_t)FH_NB * FH_CHUNK * 1024, stage = (size_t)8 * FH_STAGE_WAVE * 4;
+    return ring > stage ? ring : stage;
+}
+// LDS map (bytes): [sw1 8 KiB][sw2 32 KiB][sb1 256][sb2 512][spb 3648][sx 12K][nbr 32K][region][smax 512][sa_next 32][scal 16]
+__host__ __device__ inline size_t fh_lds_bytes(int K)
+{
+    return (size_t)(ENC_H2_SA_W1_FRAGS + ENC_H2_SA_W2_FRAGS) * 1024 + (64 + 128 + ENC_H2_PN_BIAS_FLOATS) * 4 + (size_t)K * 12 + (size_t)K * 32 +
+           fh_region_bytes() + 8 * 16 * 4 + 32 + 16;
+}
+
+__global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *__restrict__ x, int npatches, int K, const float *__restrict__ blob,
+                                                                  const float *__restrict__ h2, int d, float spread, float half_spread,
+                                                                  float *__restrict__ latent_raw, float *__restrict__ latent,
+                                                                  float *__restrict__ latent_q, const unsigned char *__restrict__ nbr_tab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4 *sw1 = (f32x4 *)smem;
+    f32x4 *sw2 = sw1 + ENC_H2_SA_W1_FRAGS * 64;
+    float *sb1 = (float *)(sw2 + ENC_H2_SA_W2_FRAGS * 64);
+    float *sb2 = sb1 + 64;
+    float *spb = sb2 + 128;                                             // PointNet biases [128 | 256 | 512 | 16], times s
+    float *sx = spb + ENC_H2_PN_BIAS_FLOATS;
+    unsigned short *nbr16 = (unsigned short *)(sx + 3 * K);
+    unsigned char *region = (unsigned char *)(nbr16 + 16 * K);          // 16-byte aligned: K % 16 == 0
+    f32x4 *swt = (f32x4 *)region;                                       // PointNet weight ring
+    float *stage_all = (float *)region;                                 // ... or the eight staging blocks
+    float (*smax)[16] = (float (*)[16])(region + fh_region_bytes());
+    int *sa_next = (int *)(region + fh_region_bytes() + 8 * 16 * 4);
+    unsigned *srmax = (unsigned *)(sa_next + 8);                        // bits of the patch's largest |coordinate|
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntiles = K >> 4;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const float rho0 = h2[ENC_H2_META + H2E_RHO0], rho1 = h2[ENC_H2_META + H2E_RHO1], inv2 = h2[ENC_H2_META + H2E_INV2];
+    const float rho_in = h2[ENC_H2_META + H2E_RHO_IN], rho_p1 = h2[ENC_H2_META + H2E_RHO_P1], rho_p2 = h2[ENC_H2_META + H2E_RHO_P2];
+    const float rho_p3 = h2[ENC_H2_META + H2E_RHO_P3], inv_out = h2[ENC_H2_META + H2E_INV_OUT];
+
+    {   // the SetAbstraction weight planes, once per workgroup
+        const f32x4 *gw = (const f32x4 *)(h2 + ENC_H2_SA_W);
+        for (int i = tid; i < (ENC_H2_SA_W1_FRAGS + ENC_H2_SA_W2_FRAGS) * 64; i += 512) sw1[i] = gw[i];
+    }
+    if (tid == 0) *srmax = 0u;
+    __syncthreads();
+  for (size_t P = blockIdx.x; P < (size_t)npatches; P += gridDim.x) {
+    const float *xp = x + P * (size_t)K * 3;
+    {   // the patch's power-of-two normalisation
+        unsigned m = 0u;
+        for (int i = tid; i < 3 * K; i += 512) m = max(m, __float_as_uint(xp[i]) & 0x7FFFFFFFu);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (lane == 0) atomicMax(srmax, m);
+    }
+    if (tid < 8) sa_next[tid] = 0;
+    {
+        const uint4 *tab = (const uint4 *)nbr_tab + P * (size_t)K * (K <= 256 ? 1 : 2);
+        if (K <= 256) {
+            for (int i = tid; i < K; i += 512) {
+                const uint4 v = tab[i];
+                const unsigned b[4] = {v.x, v.y, v.z, v.w};
+                unsigned wd[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    wd[2 * q] = (b[q] & 0xFFu) | ((b[q] & 0xFF00u) << 8);
+                    wd[2 * q + 1] = ((b[q] >> 16) & 0xFFu) | ((b[q] >> 8) & 0xFF0000u);
+                }
+                ((uint4 *)nbr16)[2 * i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                ((uint4 *)nbr16)[2 * i + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+            }
+        } else {
+            for (int i = tid; i < 2 * K; i += 512) ((uint4 *)nbr16)[i] = tab[i];
+        }
+    }
+    __syncthreads();
+    // s = 1 while the largest |coordinate| is below 1, else 2^-(e + 1) for a largest magnitude in [2^e, 2^(e+1))
+    const int rexp = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)*srmax) >> 23) - 127;
+    const float s = rexp >= 0 ? __uint_as_float((unsigned)(126 - rexp) << 23) : 1.0f;
+    const float inv_s = rexp >= 0 ? __uint_as_float((unsigned)(128 + rexp) << 23) : 1.0f;
+    for (int i = tid; i < 3 * K; i += 512) sx[i] = xp[i] * s;
+    if (tid < 64) sb1[tid] = h2[ENC_H2_SA_B1 + tid] * s;
+    if (tid < 128) sb2[tid] = h2[ENC_H2_SA_B2 + tid] * s;
+    for (int i = tid; i < ENC_H2_PN_BIAS_FLOATS; i += 512) spb[i] = h2[ENC_H2_PN_B0 + i] * s;
+    __syncthreads();
+    if (tid == 0) *srmax = 0u;                             // for the next patch (read above by everyone already)
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (lane < 16) smax[wu][lane] = -INFINITY;            // running channel maximum of this wave, kept in LDS between passes
+    const int lane0 = lane;
+
+    const int passes = (ntiles + 7) / 8;                  // identical for all waves: barriers inside
+    for (int it = 0; it < passes; ++it) {
+        const int tile = it * 8 + wu;
+        const bool valid = tile < ntiles;
+        const int p0 = (valid ? tile : 0) * 16;           // an idle wave recomputes tile 0 and discards it
+        // each phase derives its lane indices from a freshly laundered lane id (encoder_fused.hip: keeps the phases' address
+        // registers from being carried through each other)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        int g = lane >> 4, n = lane & 15;
+        const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
+
+        // ---- SetAbstraction for the pass's points, two per unit, units taken from the LDS counter
+        const int pass_base = it * 128;
+        const int units = ((K - pass_base < 128 ? K - pass_base : 128) + 1) >> 1;
+        for (;;) {
+            int unit = 0;
+            if (lane0 == 0) unit = atomicAdd(&sa_next[it & 7], 1);
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            if (unit >= units) break;
+            const int i0 = pass_base + 2 * unit;
+            f32x4 h0[2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int i = i0 + nt;
+                const int j = nbr16[i * 16 + n];
+                const float rel = g < 3 ? __fsub_rn(sx[3 * j + g], sx[3 * i + g]) : s;        // grouped_xyz -= new_xyz; bias input (times s)
+                h0[nt][0] = relu4(mfma16(w0a, rel, zero4));
+                h0[nt][1] = relu4(mfma16(w0b, rel, zero4));
+            }
+            f32x4 a1[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a1[0][mt] = a1[1][mt] = *(const f32x4 *)(sb1 + 16 * mt + 4 * g);
+            f32x4 a2[2][8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) a2[0][mt] = a2[1][mt] = zero4;      // conv2's bias is added after the neighbour max
+            f16x8 i1[2][1][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) h2_split8(h0[nt][0], h0[nt][1], rho0, i1[nt][0]);
+            dense_h2<1, 4, 2>(sw1, lane, i1, a1);                                    // conv1
+            f16x8 i2[2][2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) h2_split8(relu4(a1[nt][2 * t]), relu4(a1[nt][2 * t + 1]), rho1, i2[nt][t]);
+            dense_h2<2, 8, 2, true>(sw2, lane, i2, a2);                              // conv2, transposed
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float mx[2];
+                max16_of_8_transposed_tiles(a2[nt], mx);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {         // lane (row g, j = n) holds channel 16*(2g + s2) + n of point i0 + nt
+                    const int ch = 16 * (2 * g + s2) + n;
+                    stage_all[(i0 + nt - pass_base) * FH_STAGE_STRIDE + ch] = fmaxf(__fadd_rn(__fmul_rn(mx[s2], inv2), sb2[ch]), 0.f);
+                }
+            }
+        }
+
+        __syncthreads();                                  // every row of the pass is staged
+        // ---- hand-over: the rows of this wave's tile, read back as PointNet's B operand and split into planes
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        g = lane >> 4; n = lane & 15;
+        f16x8 i0p[1][5][2];
+        {
+            f32x4 in[9];
+            const float *stage_t = stage_all + (valid ? p0 - pass_base : 0) * FH_STAGE_STRIDE;   // an idle wave: block 0, discarded
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) in[kt] = *(const f32x4 *)(stage_t + n * FH_STAGE_STRIDE + 16 * kt + 4 * g);
+            const int p = p0 + n;
+            in[8][0] = g == 0 ? sx[3 * p] : 0.f;          // channels 128,129,130 = x,y,z (g == 0, r = 0..2)
+            in[8][1] = g == 0 ? sx[3 * p + 1] : 0.f;
+            in[8][2] = g == 0 ? sx[3 * p + 2] : 0.f;
+            in[8][3] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h2_split8(in[2 * t], in[2 * t + 1], rho_in, i0p[0][t]);
+            h2_split8(in[8], zero4, rho_in, i0p[0][4]);
+        }
+        __syncthreads();                                  // every wave has its tile in registers: the region becomes the weight ring
+
+        // ---- PointNet pass, ring started cold
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        g = lane >> 4; n = lane & 15;
+        WStreamT<FH_CHUNK, FH_NB, 8> ws{opaque_uniform(h2) + ENC_H2_PN_STREAM, swt, PN_H2_STREAM_CHUNKS, lane, wu, false};
+        ws.prologue();
+        int f = 0;                                        // fragment cursor of this pass (constant-folds)
+        f32x4 a0[1][8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a0[0][mt] = *(const f32x4 *)(spb + 16 * mt + 4 * g);
+        dense_h2_stream<5, 8, 1, decltype(ws), FH_MG>(ws, f, i0p, a0);
+        f32x4 a1p[1][16];
+        {
+            f16x8 i1p[1][4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h2_split8(relu4(a0[0][2 * t]), relu4(a0[0][2 * t + 1]), rho_p1, i1p[0][t]);
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a1p[0][mt] = *(const f32x4 *)(spb + 128 + 16 * mt + 4 * g);
+            dense_h2_stream<4, 16, 1, decltype(ws), FH_MG>(ws, f, i1p, a1p);
+        }
+        f32x4 a3[1][1];
+        a3[0][0] = *(const f32x4 *)(spb + 128 + 256 + 512 + 4 * g);
+#pragma clang loop unroll(full)
+        for (int h = 0; h < 2; ++h) {                     // layer 2 in two halves of 16 output tiles
+            f32x4 a2p[1][16];
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) a2p[0][mt] = *(const f32x4 *)(spb + 128 + 256 + 16 * (16 * h + mt) + 4 * g);
+#pragma clang loop unroll(full)
+            for (int kt = 0; kt < 8; ++kt) {
+                f16x8 pl[1][1][2];
+                h2_split8(relu4(a1p[0][2 * kt]), relu4(a1p[0][2 * kt + 1]), rho_p2, pl[0][0]);
+                dense_h2_stream<1, 16, 1, decltype(ws), FH_MG>(ws, f, pl, a2p);
+            }
+#pragma clang loop unroll(full)
+            for (int kt = 0; kt < 8; ++kt) {              // layer 3 over these 256 channels (no ReLU after it, AE.py:17)
+                f16x8 pl[1][1][2];
+                h2_split8(relu4(a2p[0][2 * kt]), relu4(a2p[0][2 * kt + 1]), rho_p3, pl[0][0]);
+                dense_h2_stream<1, 1, 1>(ws, f, pl, a3);
+            }
+        }
+        ws.drain();
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row16_max(a3[0][0][r]);
+                if (n == 0) smax[wu][4 * g + r] = fmaxf(smax[wu][4 * g + r], v);
+            }
+        }
+        __syncthreads();                                  // every wave is done reading the ring: the region is staging again
+    }
+    __syncthreads();
+    if (tid < 16 && tid < d) {
+        float m = smax[0][tid];
+#pragma unroll
+        for (int k8 = 1; k8 < 8; ++k8) m = fmaxf(m, smax[k8][tid]);                                    // torch.max(points, 2)
+        m = __fmul_rn(__fmul_rn(m, inv_out), inv_s);                                                 // undo the operand scales (exact)
+        const float sg = 1.0f / (1.0f + expf(-m));
+        const float y = __fsub_rn(__fmul_rn(sg, spread), half_spread);
+        latent_raw[P * d + tid] = m;
+        latent[P * d + tid] = y;
+        latent_q[P * d + tid] = rintf(y);
+    }
+    __syncthreads();                                      // smax / sx / nbr16 / biases are rewritten for the next patch
+  }
+}
+
+// 1 when the fused f16x2 kernel can hold a K-point patch, 0 otherwise (the caller then uses another mode's kernels)
+extern "C" int pccx_ae_encode_h2_fused_ok(int K)
+{
+    return (K >= 16 && K <= 1024 && K % 16 == 0 && fh_lds_bytes(K) <= (size_t)160 * 1024) ? 1 : 0;
+}
+
+extern "C" size_t pccx_ae_encode_h2_workspace_bytes(int P, int K) { return pccx_patch_knn16_bytes(P, K); }
+
+// patches (P, K, 3) -> latent_raw / latent / latent_q (P, d) each.  enc_blob: pccx_pack_ae_encoder (conv0 runs in fp32 from it),
+// h2_blob: pccx_pack_ae_encoder_h2, both on the device; workspace: pccx_ae_encode_h2_workspace_bytes(P, K) bytes for the in-patch
+// neighbour tables (filled here by pccx_patch_knn16).
+extern "C" int pccx_ae_encode_h2_ws(const float *patches, int P, int K, const float *enc_blob, const float *h2_blob, int d, int L,
+                                    float *latent_raw, float *latent, float *latent_q, void *workspace, void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(patches && enc_blob && h2_blob && latent_raw && latent && latent_q && workspace, "pccx_ae_encode_h2_ws: null pointer");
+    PCCX_CHECK_ARG(P >= 0 && pccx_ae_encode_h2_fused_ok(K), "pccx_ae_encode_h2_ws: K=%d does not fit the fused kernel (pccx_ae_encode_h2_fused_ok)", K);
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode_h2_ws: unsupported d=%d L=%d", d, L);
+    const int rc = pccx_patch_knn16(patches, P, K, workspace, stream);
+    if (rc != PCCX_OK) return rc;
+    const float spread = (float)((double)L - 0.2);
+    const float half = (float)(((double)L - 0.2) / 2);
+    const int grid = P < 2048 ? P : 2048;
+    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_pn_forward_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(sa_pn_forward_h2_kernel, dim3(grid), dim3(512), fh_lds_bytes(K), (hipStream_t)stream, patches, P, K, enc_blob, h2_blob, d,
+                       spread, half, latent_raw, latent, latent_q, (const unsigned char *)workspace);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}

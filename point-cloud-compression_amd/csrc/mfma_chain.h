@@ -431,3 +431,114 @@ __device__ __forceinline__ void dense_b3_stream_pw(const WS &ws, int &f, const b
     }
     f += 3 * KT * MT;
 }
+
+// ------------------------------------------------------------------------------------------
+// f16x2 operands ("f16x2"): fp32 products formed on the fp16 matrix cores from TWO fp16 pieces per operand,
+// x ~ hi + lo with hi = rn16(x), lo = rn16(x - hi) (22-23 significant bits: the mantissa budget of "3xTF32"), and the three
+// products hi*hi + hi*lo + lo*hi accumulated in fp32 -- half the MFMAs of bf16x3.  fp16 has 5 exponent bits, so every operand
+// is brought into the format's range by an exact power-of-two scale chosen from RIGOROUS bounds (pack_h2.hip): activations to
+// at most 2^15 (no overflow; the lo piece stays a normal number down to 2^-18 of the bound and degrades gracefully, as an
+// absolute error of 2^-40 of the bound, below that), weights to 2^14.  The scales travel with the accumulators
+// (acc = sigma * tau * (W y + b)) and are undone by the multiplier `rho` of the next split or of the epilogue: powers of two
+// commute with fp32 rounding, so the scaled chain computes exactly what the unscaled one would.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+// split of two fp32 C tiles (8 values per lane = one K=32 B operand), multiplied by rho first, into the two fp16 planes
+__device__ __forceinline__ void h2_split8(const f32x4 &v0, const f32x4 &v1, float rho, f16x8 (&pl)[2])
+{
+    unsigned w[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2v x = q < 2 ? f32x2v{v0[2 * q], v0[2 * q + 1]} : f32x2v{v1[2 * q - 4], v1[2 * q - 3]};
+        x = x * rho;                                                    // exact (power of two)
+        const f16x2v h = __builtin_convertvector(x, f16x2v);           // round to nearest even
+        w[0][q] = __builtin_bit_cast(unsigned, h);
+        x = x - __builtin_convertvector(h, f32x2v);                     // exact residual
+        w[1][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2v));
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) pl[p] = __builtin_bit_cast(f16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+}
+
+#define H2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+// dense layer on f16x2 operands with the weight blocks RESIDENT in LDS as [kt][mt][plane] fragments (K = 32 per kt); the three
+// products smallest first: (lo,hi) (hi,lo) (hi,hi).  SWAP as in dense_b3.
+template <int KT, int MT, int NT, bool SWAP = false, int MGW = 2>
+__device__ __forceinline__ void dense_h2(const f32x4 *w, int lane, const f16x8 (&in)[NT][KT][2], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= MGW ? MGW : MT;
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    f16x8 cur[MG][2], nxt[MG][2];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) cur[m][p] = __builtin_bit_cast(f16x8, w[(size_t)(m * 2 + p) * 64 + lane]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) nxt[m][p] = __builtin_bit_cast(f16x8, w[(size_t)(((gi + 1) * MG + m) * 2 + p) * 64 + lane]);
+        }
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = SWAP ? H2_MFMA(in[nt][kt][PB[q]], cur[m][PA[q]], acc[nt][m0 + m])
+                                           : H2_MFMA(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) cur[m][p] = nxt[m][p];
+    }
+}
+
+// the same layer with its weight blocks ([kt][mt][plane], two 1 KiB A fragments each) taken from the LDS ring in stream order
+template <int KT, int MT, int NT, class WS, int MGW = 2>
+__device__ __forceinline__ void dense_h2_stream(const WS &ws, int &f, const f16x8 (&in)[NT][KT][2], f32x4 (&acc)[NT][MT])
+{
+    constexpr int MG = MT >= MGW ? MGW : MT;
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    static_assert(MT % MG == 0, "MT must be a multiple of the block group");
+    constexpr int NG = KT * (MT / MG);
+    f16x8 cur[MG][2], nxt[MG][2];
+#pragma unroll
+    for (int m = 0; m < MG; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) cur[m][p] = __builtin_bit_cast(f16x8, ws.get(f + 2 * m + p));
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) nxt[m][p] = __builtin_bit_cast(f16x8, ws.get(f + 2 * ((gi + 1) * MG + m) + p));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int m = 0; m < MG; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][m0 + m] = H2_MFMA(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) cur[m][p] = nxt[m][p];
+    }
+    f += 2 * KT * MT;
+}

@@ -60,6 +60,15 @@ _SIGNATURES = {
     "pccx_pack_ae_decoder_b3": [_P, C.c_int, _P, _P],
     "pccx_ae_decode_b3_workspace_floats": [C.c_int],
     "pccx_ae_decode_b3": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_double, _P, _P],
+    "pccx_ae_encoder_h2_blob_floats": [],
+    "pccx_pack_ae_encoder_h2": [_P] * 14 + [C.c_int, _P],
+    "pccx_ae_encode_h2_fused_ok": [C.c_int],
+    "pccx_ae_encode_h2_workspace_bytes": [C.c_int, C.c_int],
+    "pccx_ae_encode_h2_ws": [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "pccx_ae_decoder_h2_blob_floats": [C.c_int],
+    "pccx_pack_ae_decoder_h2": [_P] * 14 + [C.c_int, C.c_int, _P],
+    "pccx_ae_decode_h2_workspace_floats": [C.c_int],
+    "pccx_ae_decode_h2": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int, C.c_double, _P, _P],
     "pccx_prob_forward": [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_range_encode": [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_range_decode": [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P],
@@ -114,7 +123,9 @@ _SIGNATURES = {
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
-_RESTYPES = {"pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
+_RESTYPES = {"pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
+             "pccx_ae_encode_h2_workspace_bytes": C.c_size_t, "pccx_ae_decode_h2_workspace_floats": C.c_size_t,
+             "pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
              "pccx_packed_linear_floats": C.c_size_t, "pccx_ball_query_grid_workspace_ints": C.c_size_t, "pccx_packed_linear_b3_floats": C.c_size_t, "pccx_dec_b3_blob_floats": C.c_size_t, "pccx_sa_b3_blob_floats": C.c_size_t, "pccx_pn_b3_blob_floats": C.c_size_t,
              "pccx_ae_decode_b3_workspace_floats": C.c_size_t, "pccx_planes_floats": C.c_size_t,

@@ -27,7 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # canonicalising v_max_f32 x, x, x in front of the real one (sNaN quieting) -- 90 of the 430 vector instructions per pair of
 # points in the SetAbstraction phase were such no-ops.  Results are bit-identical (NaN inputs are outside the contract).
 FILE_FLAGS = {name: ["-fno-honor-nans"] for name in
-              ("encoder_fused.hip", "encoder.hip", "decoder.hip", "planes.hip", "prob.hip")}
+              ("encoder_fused.hip", "encoder_fused_h2.hip", "encoder.hip", "decoder.hip", "decoder_h2.hip", "planes.hip", "prob.hip")}
 
 
 def _newer(a, b):

@@ -102,8 +102,8 @@ class Codec:
         self.decoder_matmul = decoder_matmul or matmul
         self.sa_matmul, self.pn_matmul = sa_matmul or matmul, pn_matmul or matmul
         for m in (self.decoder_matmul, self.sa_matmul, self.pn_matmul):
-            if m not in ("f32", "bf16x3"):
-                raise ValueError(f"matmul={m!r}: expected 'f32' or 'bf16x3'")
+            if m not in ("f32", "bf16x3", "f16x2"):
+                raise ValueError(f"matmul={m!r}: expected 'f32', 'bf16x3' or 'f16x2'")
         self.K, self.ALPHA, self.N0 = K, ALPHA, N0
         self.k = K // ALPHA                                  # compress.py:46
         self.octree_mode = octree_mode

@@ -42,7 +42,8 @@ class FoldedLinear:
 
     def mode(self):
         from . import DEFAULT_MATMUL
-        return self.matmul or DEFAULT_MATMUL
+        m = self.matmul or DEFAULT_MATMUL
+        return "bf16x3" if m == "f16x2" else m              # f16x2 exists for the fused AE transforms only (pccx/__init__.py)
 
     def _planes3(self):
         if self.wp3 is None:
@@ -86,7 +87,7 @@ class FoldedLinear:
         from . import DEFAULT_MATMUL
         M = x.shape[0]
         out = torch.empty(M, self.N, device=x.device, dtype=torch.float32)
-        if (self.matmul or DEFAULT_MATMUL) == "bf16x3":
+        if self.mode() == "bf16x3":
             _lib.call("pccx_linear_b3", x.data_ptr(), M, self.K, x.stride(0), self._planes3().data_ptr(), self.b.data_ptr(), self.N,
                       self.relu, out.data_ptr(), self.N, _stream())
             return out

@@ -252,7 +252,7 @@ class AE(nn.Module):
                          w("pn.mlp_Modules.1.0.weight"), sd["pn.mlp_Modules.1.0.bias"],
                          w("pn.mlp_Modules.2.0.weight"), sd["pn.mlp_Modules.2.0.bias"], pad_w, pad_b], [16])
             self._enc_blob, self._dec_blob = enc.to(device), None
-            self._dec_b3 = self._sa_b3 = self._pn_b3 = None
+            self._dec_b3 = self._sa_b3 = self._pn_b3 = self._enc_h2 = self._dec_h2 = None
             return self
         enc = _pack("pccx_pack_ae_encoder", lib.pccx_ae_encoder_blob_floats(),
                     [w("sa.conv0.weight"), sd["sa.conv0.bias"], w("sa.conv1.weight"), sd["sa.conv1.bias"],
@@ -269,8 +269,43 @@ class AE(nn.Module):
                      w("inv_mlp.mlp_Modules.2.0.weight"), sd["inv_mlp.mlp_Modules.2.0.bias"],
                      w("inv_mlp.mlp_Modules.3.0.weight"), sd["inv_mlp.mlp_Modules.3.0.bias"]], [self.k, self.d])
         self._enc_blob, self._dec_blob = enc.to(device), dec.to(device)
-        self._dec_b3 = self._sa_b3 = self._pn_b3 = None
+        self._dec_b3 = self._sa_b3 = self._pn_b3 = self._enc_h2 = self._dec_h2 = None
         return self
+
+    def _enc_tensors(self):
+        sd = self.state_dict()
+        w = lambda key: sd[key].reshape(sd[key].shape[0], -1)
+        return [w("sa.conv0.weight"), sd["sa.conv0.bias"], w("sa.conv1.weight"), sd["sa.conv1.bias"],
+                w("sa.conv2.weight"), sd["sa.conv2.bias"],
+                w("pn.mlp_Modules.0.0.weight"), sd["pn.mlp_Modules.0.0.bias"],
+                w("pn.mlp_Modules.1.0.weight"), sd["pn.mlp_Modules.1.0.bias"],
+                w("pn.mlp_Modules.2.0.weight"), sd["pn.mlp_Modules.2.0.bias"],
+                w("pn.mlp_Modules.3.0.weight"), sd["pn.mlp_Modules.3.0.bias"]]
+
+    def _dec_tensors(self):
+        sd = self.state_dict()
+        w = lambda key: sd[key].reshape(sd[key].shape[0], -1)
+        return [sd["inv_pool.0.weight"], sd["inv_pool.0.bias"], sd["inv_pool.2.weight"], sd["inv_pool.2.bias"],
+                sd["inv_pool.4.weight"], sd["inv_pool.4.bias"],
+                w("inv_mlp.mlp_Modules.0.0.weight"), sd["inv_mlp.mlp_Modules.0.0.bias"],
+                w("inv_mlp.mlp_Modules.1.0.weight"), sd["inv_mlp.mlp_Modules.1.0.bias"],
+                w("inv_mlp.mlp_Modules.2.0.weight"), sd["inv_mlp.mlp_Modules.2.0.bias"],
+                w("inv_mlp.mlp_Modules.3.0.weight"), sd["inv_mlp.mlp_Modules.3.0.bias"]]
+
+    def _enc_h2_blob(self, device):
+        """f16x2 operand planes, scaled biases and layer scales of the encoder (csrc/pack_h2.hip), packed on the host."""
+        enc, _ = self._blobs(device)
+        if getattr(self, "_enc_h2", None) is None or self._enc_h2.device != enc.device:
+            self._enc_h2 = _pack("pccx_pack_ae_encoder_h2", _lib.load().pccx_ae_encoder_h2_blob_floats(), self._enc_tensors(),
+                                 [self.d]).to(enc.device)
+        return self._enc_h2
+
+    def _dec_h2_blob(self, device):
+        _, dec = self._blobs(device)
+        if getattr(self, "_dec_h2", None) is None or self._dec_h2.device != dec.device:
+            self._dec_h2 = _pack("pccx_pack_ae_decoder_h2", _lib.load().pccx_ae_decoder_h2_blob_floats(self.k), self._dec_tensors(),
+                                 [self.k, self.d]).to(dec.device)
+        return self._dec_h2
 
     def _blobs(self, device):
         if self._enc_blob is None or self._enc_blob.device != torch.device(device):
@@ -296,25 +331,25 @@ class AE(nn.Module):
     def _launch_sa(self, x, feat, matmul):
         P, K, _ = x.shape
         enc, _ = self._blobs(x.device)
-        if matmul == "bf16x3":
+        if matmul in ("bf16x3", "f16x2"):                 # f16x2 exists for the fused transforms only: the module alone runs bf16x3
             _lib.call("pccx_sa_forward_b3", x.data_ptr(), P, K, enc.data_ptr(), self._sa_b3_blob(x.device).data_ptr(),
                       feat.data_ptr(), _stream())
         elif matmul == "f32":
             _lib.call("pccx_sa_forward", x.data_ptr(), P, K, enc.data_ptr(), feat.data_ptr(), _stream())
         else:
-            raise ValueError(f"sa_matmul={matmul!r}: expected 'f32' or 'bf16x3'")
+            raise ValueError(f"sa_matmul={matmul!r}: expected 'f32', 'bf16x3' or 'f16x2'")
 
     def _launch_pn(self, x, feat, outs, matmul):
         P, K, _ = x.shape
         enc, _ = self._blobs(x.device)
-        if matmul == "bf16x3":
+        if matmul in ("bf16x3", "f16x2"):
             _lib.call("pccx_pn_forward_b3", x.data_ptr(), feat.data_ptr(), P, K, enc.data_ptr(), self._pn_b3_blob(x.device).data_ptr(),
                       self.d, self.L, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
         elif matmul == "f32":
             _lib.call("pccx_pn_forward", x.data_ptr(), feat.data_ptr(), P, K, enc.data_ptr(), self.d, self.L,
                       outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream())
         else:
-            raise ValueError(f"pn_matmul={matmul!r}: expected 'f32' or 'bf16x3'")
+            raise ValueError(f"pn_matmul={matmul!r}: expected 'f32', 'bf16x3' or 'f16x2'")
 
     def encode(self, patches, sa_matmul=None, pn_matmul=None, fused=True):
         """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
@@ -328,6 +363,18 @@ class AE(nn.Module):
             return self.encode_generic(x)
         outs = [torch.empty(P, self.d, device=x.device, dtype=torch.float32) for _ in range(3)]
         sa_matmul, pn_matmul = sa_matmul or _pccx_default_matmul(), pn_matmul or _pccx_default_matmul()
+        if fused and sa_matmul == pn_matmul == "f16x2" and _lib.load().pccx_ae_encode_h2_fused_ok(K):
+            # the fused kernel on f16x2 operands (csrc/encoder_fused_h2.hip): two fp16 pieces per operand, three MFMA passes
+            enc, _ = self._blobs(x.device)
+            nbytes = _lib.load().pccx_ae_encode_h2_workspace_bytes(P, K)
+            ws = workspace("patch_knn16", (nbytes + 3) // 4, x.device)
+            with stage("sa_pn_forward"):
+                _lib.call("pccx_ae_encode_h2_ws", x.data_ptr(), P, K, enc.data_ptr(), self._enc_h2_blob(x.device).data_ptr(), self.d, self.L,
+                          outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), ws.data_ptr(), _stream())
+            return tuple(outs)
+        if sa_matmul == "f16x2" or pn_matmul == "f16x2":      # K beyond the fused kernel, or fused=False: the bf16x3 kernels
+            sa_matmul = "bf16x3" if sa_matmul == "f16x2" else sa_matmul
+            pn_matmul = "bf16x3" if pn_matmul == "f16x2" else pn_matmul
         if fused and sa_matmul == pn_matmul == "bf16x3" and _lib.load().pccx_ae_encode_b3_fused_ok(K):
             # one kernel, the (P,128,K) feature map never leaves the CU (csrc/encoder_fused.hip)
             # (csrc/encoder_fused.hip); the in-patch 16-NN tables come from a kernel of their own (csrc/patch_knn.hip) through
@@ -402,11 +449,14 @@ class AE(nn.Module):
         if matmul == "bf16x3":
             fn, extra = "pccx_ae_decode_b3", (self._b3_blob(q.device).data_ptr(),)
             ws = workspace("dec_h2_b3", _lib.load().pccx_ae_decode_b3_workspace_floats(P), q.device)
+        elif matmul == "f16x2":
+            fn, extra = "pccx_ae_decode_h2", (self._dec_h2_blob(q.device).data_ptr(),)
+            ws = workspace("dec_h2_h2", _lib.load().pccx_ae_decode_h2_workspace_floats(P), q.device)
         elif matmul == "f32":
             fn, extra = "pccx_ae_decode", ()
             ws = workspace("dec_h2", _lib.load().pccx_ae_decode_workspace_floats(P), q.device)
         else:
-            raise ValueError(f"matmul={matmul!r}: expected 'f32' or 'bf16x3'")
+            raise ValueError(f"matmul={matmul!r}: expected 'f32', 'bf16x3' or 'f16x2'")
         if centres is None:
             out = torch.empty(P, self.k, 3, device=q.device, dtype=torch.float32)
             _lib.call(fn, q.data_ptr(), P, self.d, self.k, dec.data_ptr(), *extra, ws.data_ptr(), out.data_ptr(),
