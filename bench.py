@@ -42,6 +42,7 @@ PROB_GAIN = 2.0
 F32_MATRIX_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_DENSE_PEAK_TFLOPS = 16 * F32_MATRIX_PEAK_TFLOPS  # same table: the f32 MFMA runs at 1/16 of BF16 (~2.5 PF dense)
 B3_PRODUCTS = 6                                     # bf16 MFMA products per fp32 product in the three-way split
+H2_PRODUCTS = 3                                     # fp16 MFMA products per fp32 product in the two-way split (fp16 dense peak = bf16's)
 
 # algorithmic FLOPs per PATCH (2*MACs), from the layer shapes of AE.py:16-27
 FLOP_SA = K_PATCH * 16 * (3 * 32 + 32 * 64 + 64 * 128) * 2
@@ -51,9 +52,17 @@ FLOP_DEC = (D_LAT * 256 + 256 * 1024 + 1024 * K_SMALL * 128) * 2 + K_SMALL * (14
 STAGE_FLOP = {"sa_forward": FLOP_SA, "pn_forward": FLOP_PN, "ae_decode": FLOP_DEC, "sa_pn_forward": FLOP_SA + FLOP_PN}
 STAGE_KERNEL = {"sa_forward": "sa_forward_kernel", "pn_forward": "pn_forward_kernel", "ae_decode": "dec_main_kernel",
                 "sa_pn_forward": "sa_pn_forward_b3_kernel"}
+STAGE_KERNEL_H2 = {"ae_decode": "dec_main_h2_kernel", "sa_pn_forward": "sa_pn_forward_h2_kernel"}
+MODE_DTYPE = {"f32": "f32",
+              "bf16x3": "f32 (operands split into three bf16 pieces, six bf16-MFMA products per fp32 product, fp32 accumulate)",
+              "f16x2": "f32 (operands split into two scaled fp16 pieces of 22-23 bits together, three fp16-MFMA products per fp32 product, fp32 accumulate)"}
 
 
-def committed_traffic(stage, batch):
+def stage_kernel(stage, matmul):
+    return STAGE_KERNEL_H2.get(stage, STAGE_KERNEL[stage]) if matmul == "f16x2" else STAGE_KERNEL[stage]
+
+
+def committed_traffic(stage, batch, matmul="bf16x3"):
     """HBM bytes per launch of the stage's kernel, NOT measured in this run: read from the newest committed rocprofv3
     --pmc pass (profiles/round*_traffic.json, separate passes, gfx950 corrections applied) and scaled linearly from the
     batch that pass ran at.  Returns (bytes or None, source)."""
@@ -61,20 +70,20 @@ def committed_traffic(stage, batch):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
         try:
             j = json.load(open(path))
-            t = j["kernels"][STAGE_KERNEL[stage]]
+            t = j["kernels"][stage_kernel(stage, matmul)]
             return int(t["hbm_bytes_per_launch"] * batch / j.get("batch", 256)), "scaled from committed PMC pass " + os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
     return None, None
 
 
-def committed_pmc(stage):
+def committed_pmc(stage, matmul="bf16x3"):
     """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over the cycles of all SIMDs) and the clock the chip held during the
     stage's kernel (GRBM_GUI_ACTIVE / 8 / duration), from the same committed PMC passes -- NOT measured in this run."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
         try:
-            t = json.load(open(path))["kernels"][STAGE_KERNEL[stage]]
+            t = json.load(open(path))["kernels"][stage_kernel(stage, matmul)]
             if "mfma_pipe_busy" in t:
                 return {"mfma_pipe_busy": round(t["mfma_pipe_busy"], 4), "clock_ghz_under_load": round(t.get("clock_ghz_under_load", 0.0), 3) or None,
                         "peak_quoted_at_ghz": 2.4, "source": "committed PMC pass " + os.path.relpath(path, ROOT)}
@@ -344,13 +353,18 @@ def roofline_of(stages, steps, P, matmul, batch):
         note = ("fp32-equivalent TFLOP/s: each fp32 product = %d bf16 MFMA products (three-way split), so peak = bf16 dense "
                 "%.0f / %d; the same fraction as real bf16 FLOP/s (%.0f) over %.0f" %
                 (B3_PRODUCTS, BF16_DENSE_PEAK_TFLOPS, B3_PRODUCTS, achieved * B3_PRODUCTS, BF16_DENSE_PEAK_TFLOPS))
+    elif matmul == "f16x2":
+        peak = BF16_DENSE_PEAK_TFLOPS / H2_PRODUCTS
+        note = ("fp32-equivalent TFLOP/s: each fp32 product = %d fp16 MFMA products (two-way split), so peak = fp16 dense "
+                "%.0f / %d; the same fraction as real fp16 FLOP/s (%.0f) over %.0f" %
+                (H2_PRODUCTS, BF16_DENSE_PEAK_TFLOPS, H2_PRODUCTS, achieved * H2_PRODUCTS, BF16_DENSE_PEAK_TFLOPS))
     else:
         peak, note = F32_MATRIX_PEAK_TFLOPS, "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) against the fp32 matrix peak"
-    traffic, src = committed_traffic(dom, batch)
-    rf = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+    traffic, src = committed_traffic(dom, batch, matmul)
+    rf = {"kernel": dom, "kernel_name": stage_kernel(dom, matmul), "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
           "traffic": traffic, "traffic_source": src, "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P,
           "arithmetic": matmul, "note": note, "window": "resident leg (single stream; HIP events per stage)",
-          "pmc": committed_pmc(dom)}
+          "pmc": committed_pmc(dom, matmul)}
     tfl = {k: STAGE_FLOP[k] * P / (stages[k][0] * 1e-3) / 1e12 for k in STAGE_FLOP if k in stages}
     return rf, per_step_ms, tfl
 
@@ -374,7 +388,7 @@ def bench_ipdae(args, rk):
     starts = torch.from_numpy((np.arange(B) * 97 + rk.rank) % N_POINTS).to(dev)
     P = B * S_PATCH
     sync = torch.cuda.synchronize
-    modes = [args.matmul] + [m for m in ("f32", "bf16x3") if m != args.matmul and not args.one_mode]
+    modes = [args.matmul] + [m for m in ("f32", "bf16x3", "f16x2") if m != args.matmul and not args.one_mode]
     res_by_mode = {}
     for mode in modes:
         cd, _, _ = build_codec(rk, mode, args.octree_mode)
@@ -497,7 +511,7 @@ def bench_ipdae(args, rk):
     summ = rk.summaries([main["bits"], B * N_POINTS, main["psnr_sum"], main["chamfer_sum"], B, main["dt_host"]])
     if rk.rank == 0:
         rf, per_step_ms, tfl = roofline_of(main["stages"], args.steps, P, args.matmul, B)
-        dtype = "f32" if args.matmul == "f32" else "f32 (operands split into three bf16 pieces, six bf16-MFMA products per fp32 product, fp32 accumulate)"
+        dtype = MODE_DTYPE[args.matmul]
         res = {
             "metric": "points/sec compress+decompress (ModelNet40-shaped 8192 K=256)",
             "value": rk.world * pts / main["dt_host"], "unit": "points/s",
@@ -596,7 +610,7 @@ def bench_s3dis(args, rk):
             "metric": "points/sec compress+decompress, room-scale clouds in 8192-pt Morton blocks", "value": n_pts * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split operands)", "data": "synthetic",
+            "dtype": MODE_DTYPE[args.matmul], "data": "synthetic",
             "window": "resident; the block partition (Morton keys + torch.sort) and the inverse permutation are inside the step",
             "config": {"workload": f"S3DIS-like rooms (configs[3]): {args.rooms} rooms, {n_pts} points, IPDAE K=256 per 8192-pt block",
                        "sharding": f"block-sharded x{rk.world}", "matmul": args.matmul, "blocks_per_launch": args.batch},
@@ -648,7 +662,7 @@ def bench_pppf(args, rk):
         rf = None
         if flop:
             ach = flop * B * S * args.steps / dt / 1e12
-            peak = F32_MATRIX_PEAK_TFLOPS if args.matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS
+            peak = F32_MATRIX_PEAK_TFLOPS if args.matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS   # f16x2: the PointNet++ layers run bf16x3
             rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                   "frac": ach / peak, "traffic": None, "flop_per_patch": flop, "arithmetic": args.matmul,
                   "reference_flop_per_patch": flop_ref, "reference_counted_tflops": flop_ref * B * S * args.steps / dt / 1e12,
@@ -661,7 +675,7 @@ def bench_pppf(args, rk):
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.matmul == "f32" else "f32 (bf16x3 split operands)", "data": "synthetic",
+            "dtype": MODE_DTYPE["bf16x3" if args.matmul == "f16x2" else args.matmul], "data": "synthetic",      # no f16x2 form of these layers
             "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": args.matmul,
                        "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
             "roofline": rf, "cpu_baseline": cpu,
@@ -732,7 +746,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="clouds per GPU per step")
     ap.add_argument("--octree-mode", default="reference", choices=["reference", "full"])
-    ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3"],
+    ap.add_argument("--matmul", default=None, choices=["f32", "bf16x3", "f16x2"],
                     help="how the three transforms form their fp32 products (pccx.DEFAULT_MATMUL when omitted); the other mode is "
                          "measured beside it (resident leg) unless --one-mode")
     ap.add_argument("--one-mode", action="store_true", help="skip the second arithmetic mode")

@@ -133,6 +133,13 @@ void h2_planes(const float *src, int KT16, int W, int src_w, double tau, float *
             }
 }
 
+bool all_finite(const float *p, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (!isfinite(p[i])) return false;
+    return true;
+}
+
 void scaled_copy(float *dst, const float *src, int n, int padded, double s)
 {
     for (int i = 0; i < padded; ++i) dst[i] = i < n ? (float)((double)src[i] * s) : 0.f;
@@ -151,6 +158,11 @@ extern "C" int pccx_pack_ae_encoder_h2(const float *sa_w0, const float *sa_b0, c
     const int rc = pccx_pack_ae_encoder(sa_w0, sa_b0, sa_w1, sa_b1, sa_w2, sa_b2, pn_w0, pn_b0, pn_w1, pn_b1, pn_w2, pn_b2, pn_w3, pn_b3, d, enc.data());
     if (rc != PCCX_OK) return rc;
     PCCX_CHECK_ARG(blob, "pccx_pack_ae_encoder_h2: null pointer");
+    PCCX_CHECK_ARG(all_finite(sa_w0, 96) && all_finite(sa_b0, 32) && all_finite(sa_w1, 64 * 32) && all_finite(sa_b1, 64) &&
+                       all_finite(sa_w2, 128 * 64) && all_finite(sa_b2, 128) && all_finite(pn_w0, 128 * 131) && all_finite(pn_b0, 128) &&
+                       all_finite(pn_w1, 256 * 128) && all_finite(pn_b1, 256) && all_finite(pn_w2, 512 * 256) && all_finite(pn_b2, 512) &&
+                       all_finite(pn_w3, (size_t)d * 512) && all_finite(pn_b3, d),
+                   "pccx_pack_ae_encoder_h2: non-finite weight or bias (the f16x2 scales need finite layer bounds)");
     memset(blob, 0, sizeof(float) * ENC_H2_BLOB_FLOATS);
     float *meta = blob + ENC_H2_META;
 
@@ -219,6 +231,10 @@ extern "C" int pccx_pack_ae_decoder_h2(const float *ip_w0, const float *ip_b0, c
     const int rc = pccx_pack_ae_decoder(ip_w0, ip_b0, ip_w1, ip_b1, ip_w2, ip_b2, m_w0, m_b0, m_w1, m_b1, m_w2, m_b2, m_w3, m_b3, k, d, dec.data());
     if (rc != PCCX_OK) return rc;
     PCCX_CHECK_ARG(blob, "pccx_pack_ae_decoder_h2: null pointer");
+    PCCX_CHECK_ARG(all_finite(ip_w2, (size_t)k * 128 * 1024) && all_finite(ip_b2, (size_t)k * 128) && all_finite(m_w0, (size_t)128 * (128 + d)) &&
+                       all_finite(m_b0, 128) && all_finite(m_w1, 64 * 128) && all_finite(m_b1, 64) && all_finite(m_w2, 32 * 64) &&
+                       all_finite(m_b2, 32) && all_finite(m_w3, 3 * 32) && all_finite(m_b3, 3),
+                   "pccx_pack_ae_decoder_h2: non-finite weight or bias (the f16x2 scales need finite layer bounds)");
     memset(blob, 0, sizeof(float) * (size_t)DEC_H2_BLOB_FLOATS(k));
     float *meta = blob + DEC_H2_META;
     // the head activation (relu(inv_pool.2), 1024 channels) and the latent arrive normalised per patch to at most 1

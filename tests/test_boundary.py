@@ -68,7 +68,7 @@ def nets():
     return ae, prob, oae, oprob
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "f16x2"])
 def matmul_mode(request):
     import pccx
     old = pccx.DEFAULT_MATMUL

@@ -20,10 +20,11 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 K, k, d, L = synth.MODEL_CFG
 
 
-@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["f32", "bf16x3", "f16x2"])
 def matmul_mode(request):
-    """Every test of this module runs in BOTH arithmetic modes of the three transforms at the SAME tolerances against
-    the oracle / golden fixtures: exact-fp32 MFMA, and fp32 products formed from three bf16 pieces per operand."""
+    """Every test of this module runs in ALL arithmetic modes of the three transforms at the SAME tolerances against
+    the oracle / golden fixtures: exact-fp32 MFMA, fp32 products formed from three bf16 pieces per operand, and fp32 products
+    formed from two scaled fp16 pieces per operand (the fused encoder / decoder; other kernels run bf16x3 in that mode)."""
     import pccx
     old = pccx.DEFAULT_MATMUL
     pccx.DEFAULT_MATMUL = request.param
@@ -372,6 +373,81 @@ def test_bf16x3_other_patch_sizes(Kx, kx, P):
     a = ae.decode(q0, matmul="f32").cpu().numpy()
     b = ae.decode(q0, matmul="bf16x3").cpu().numpy()
     assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max())
+
+
+def _seeded_ae(Kx, kx, bias_gain=1.0):
+    ae = models.AE(Kx, kx, d, L)
+    sd = ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN)
+    if bias_gain != 1.0:
+        sd = {n: (v * bias_gain if n.endswith("bias") else v) for n, v in sd.items()}
+    ae.load_state_dict(sd)
+    return ae.pack("cuda")
+
+
+@pytest.mark.parametrize("Kx,kx,P", [(256, 128, 37), (64, 32, 5), (512, 256, 3), (16, 8, 2), (48, 24, 3)])
+def test_f16x2_matches_fp32_path(Kx, kx, P):
+    """The f16x2 kernels (csrc/encoder_fused_h2.hip, decoder_h2.hip: two scaled fp16 pieces per operand, three MFMA passes per
+    fp32 product) against the exact-fp32 kernels at the bars of the bf16x3 tests above: pre-sigmoid latents within 2e-5 relative,
+    latents within 5e-6, symbols equal except at a rounding boundary, decoder output within 2e-6; and against the oracle at the
+    golden tolerances."""
+    ae = _seeded_ae(Kx, kx)
+    rng = np.random.default_rng(Kx * 7 + P)
+    x = torch.from_numpy((rng.random((P, Kx, 3)).astype(np.float32) - 0.5)).cuda()
+    x[0, : Kx // 2] = x[0, Kx // 2:]                                  # duplicated points
+    raw0, lat0, q0 = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
+    raw1, lat1, q1 = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    assert torch.isfinite(raw1).all()
+    assert np.abs(raw0.cpu().numpy() - raw1.cpu().numpy()).max() <= 2e-5 * max(1.0, float(raw0.abs().max()))
+    assert np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max() <= 5e-6
+    _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
+    a = ae.decode(q0, matmul="f32").cpu().numpy()
+    b = ae.decode(q0, matmul="f16x2").cpu().numpy()
+    assert np.isfinite(b).all()
+    assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max())
+    if Kx == K:
+        oae = ref_model.AE(K, k, d, L).eval()
+        oae.load_state_dict(ae.state_dict())
+        with torch.no_grad():
+            olat = oae.encode(x.cpu())
+            want = oae.decode(q0.cpu()).numpy()
+        np.testing.assert_allclose(lat1.cpu().numpy(), olat.numpy(), rtol=0, atol=5e-5)
+        np.testing.assert_allclose(b, want.reshape(b.shape), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 0.99999994, 2.0, 37.0, 3000.0, 1e6])
+def test_f16x2_per_patch_normalisation_over_input_magnitudes(scale):
+    """fp16 has five exponent bits; the f16x2 kernels bring every operand into range with exact power-of-two scales, one of them
+    per patch from the data (largest |coordinate| for the encoder; largest head activation or |latent| for the decoder).  Patches
+    and latents of very different magnitudes in ONE launch (each row scaled by its own factor around `scale`, one row all-zero,
+    one with a single far outlier) must stay finite and agree with the exact-fp32 kernels as closely as at scale 1."""
+    ae = _seeded_ae(K, k, bias_gain=4.0)                               # large biases: the scaled-bias path carries weight
+    rng = np.random.default_rng(11)
+    P = 48
+    x = (rng.random((P, K, 3)).astype(np.float32) - 0.5)
+    row = (scale * np.exp2(rng.integers(-3, 4, size=(P, 1, 1)))).astype(np.float32)
+    x = x * row
+    x[1] = 0.0                                                       # degenerate patch: every point at the centre
+    x[2, 5] = 50.0 * row[2, 0]                                        # one far outlier sets the patch's scale
+    x = torch.from_numpy(x).cuda()
+    raw0, lat0, q0 = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
+    raw1, lat1, q1 = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    raw3, lat3, _ = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3")
+    assert torch.isfinite(raw1).all()
+    assert np.abs(raw0.cpu().numpy() - raw1.cpu().numpy()).max() <= 2e-5 * max(1.0, float(raw0.abs().max()))
+    # the biases are four times the usual ones here, and the pre-sigmoid values with them: twice the latent bar of the other tests,
+    # and no further from the exact-fp32 kernel than 1.5 x what the bf16x3 kernel is on the same input
+    e1 = np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max()
+    e3 = np.abs(lat0.cpu().numpy() - lat3.cpu().numpy()).max()
+    assert e1 <= 1e-5 and e1 <= max(5e-6, 1.5 * e3), (e1, e3)
+    _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
+    lq = rng.integers(-3, 4, size=(P, d)).astype(np.float32) * row[:, 0]
+    lq[1] = 0.0
+    lq = torch.from_numpy(lq).cuda()
+    a = ae.decode(lq, matmul="f32").cpu().numpy()
+    b = ae.decode(lq, matmul="f16x2").cpu().numpy()
+    assert np.isfinite(b).all()
+    per = np.abs(a).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(a - b) <= 2e-6 * np.maximum(per, 1.0)).all(), float((np.abs(a - b) / np.maximum(per, 1.0)).max())
 
 
 @pytest.mark.parametrize("Kx,P", [(256, 7), (64, 5), (16, 3), (48, 2), (512, 3), (1024, 1)])

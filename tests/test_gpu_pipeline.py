@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 K, k, d, L = synth.MODEL_CFG
 
 
-@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["f32", "bf16x3", "f16x2"])
 def matmul_mode(request):
-    """Every test of this module runs in BOTH arithmetic modes of the three transforms at the SAME tolerances against
-    the oracle / golden fixtures: exact-fp32 MFMA, and fp32 products formed from three bf16 pieces per operand."""
+    """Every test of this module runs in ALL arithmetic modes of the three transforms at the SAME tolerances against
+    the oracle / golden fixtures: exact-fp32 MFMA, fp32 products formed from three bf16 pieces per operand, and fp32 products
+    formed from two scaled fp16 pieces per operand (the fused encoder / decoder; other kernels run bf16x3 in that mode)."""
     import pccx
     old = pccx.DEFAULT_MATMUL
     pccx.DEFAULT_MATMUL = request.param
@@ -380,14 +381,15 @@ def test_modelnet40_test_set_scale_round_trip(nets):
     assert len(hashlib.sha256(b"".join(digests)).hexdigest()) == 64
 
 
-def test_bf16x3_agrees_with_fp32_at_scale(nets):
-    """The bf16x3 kernels (SetAbstraction, PointNet, decoder on bf16x3 operands) against the exact-fp32 product
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_split_operand_modes_agree_with_fp32_at_scale(nets, mode):
+    """The split-operand kernels (SetAbstraction, PointNet, decoder on bf16x3 or f16x2 operands) against the exact-fp32 product
     path on 512 full-size clouds (524 288 symbols): a symbol may differ only where the fp32 latent sits within 1e-5 of a
     rounding boundary, at most a few per million do, the streams of every other cloud are byte-identical, and the
     reconstructions agree to 1e-5 of the cloud size wherever the symbols agree."""
     ae, prob, _, _ = nets
     f32 = codec.Codec(ae, prob, K=K, octree_mode="reference", matmul="f32")
-    b3 = codec.Codec(ae, prob, K=K, octree_mode="reference", matmul="bf16x3")
+    b3 = codec.Codec(ae, prob, K=K, octree_mode="reference", matmul=mode)
     n = 512
     base = cloud_synth.cad_batch(3000, 64, 8192)
     rng = np.random.default_rng(3)
@@ -399,7 +401,7 @@ def test_bf16x3_agrees_with_fp32_at_scale(nets):
     q0, q1 = c0.extras["latent_q"].cpu().numpy(), c1.extras["latent_q"].cpu().numpy()
     lat0 = c0.extras["latent"].cpu().numpy() if "latent" in c0.extras else None
     diff = q0 != q1
-    print(f"bf16x3 vs fp32: {int(diff.sum())} of {diff.size} symbols differ")
+    print(f"{mode} vs fp32: {int(diff.sum())} of {diff.size} symbols differ")
     assert diff.mean() <= 1e-5, diff.sum()
     if diff.any() and lat0 is not None:
         frac = np.abs(lat0[diff] - np.floor(lat0[diff]) - 0.5)
