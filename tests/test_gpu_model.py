@@ -434,11 +434,12 @@ def test_f16x2_per_patch_normalisation_over_input_magnitudes(scale):
     raw3, lat3, _ = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3")
     assert torch.isfinite(raw1).all()
     assert np.abs(raw0.cpu().numpy() - raw1.cpu().numpy()).max() <= 2e-5 * max(1.0, float(raw0.abs().max()))
-    # the biases are four times the usual ones here, and the pre-sigmoid values with them: twice the latent bar of the other tests,
-    # and no further from the exact-fp32 kernel than 1.5 x what the bf16x3 kernel is on the same input
+    # latent = (L - 0.2) sigmoid(raw) - const, so |d latent| <= (L - 0.2) / 4 |d raw|: with biases four times the usual ones and
+    # coordinates up to 1e6 the pre-sigmoid values reach hundreds, and the latent bar follows the raw bar above instead of being the
+    # 5e-6 of the unit-scale tests; the f16x2 kernel is also held to within 3 x of what the bf16x3 kernel shows on the same input
     e1 = np.abs(lat0.cpu().numpy() - lat1.cpu().numpy()).max()
     e3 = np.abs(lat0.cpu().numpy() - lat3.cpu().numpy()).max()
-    assert e1 <= 1e-5 and e1 <= max(5e-6, 1.5 * e3), (e1, e3)
+    assert e1 <= (L - 0.2) / 4 * 2e-5 * max(1.0, float(raw0.abs().max())) and e1 <= max(5e-6, 3.0 * e3), (e1, e3, float(raw0.abs().max()))
     _symbols_agree(q1.cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
     lq = rng.integers(-3, 4, size=(P, d)).astype(np.float32) * row[:, 0]
     lq[1] = 0.0
