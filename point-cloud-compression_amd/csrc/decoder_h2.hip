@@ -7,7 +7,6 @@
 // Head activations and latents are multiplied by s_n when their planes are formed, every bias by s_n when it initialises an
 // accumulator (inv_pool.4 -> inv_mlp is positively homogeneous in (input, biases)), and the output is divided by s_n.
 #include <math.h>
-#include <stdlib.h>
 
 #include "blobs.h"
 #include "common.h"
@@ -61,8 +60,7 @@ __device__ __forceinline__ uint4 h2_load_async(const uint4 *p)    // placed exac
 
 // grid: groups of DEC_GROUP patch blocks outermost, then the point p, then the block inside the group (decoder.hip); 4 waves, wave w
 // owns patch tiles NT w .. NT w + NT - 1 of its block.
-// CH = fragments per ring chunk: 16 = one whole k-step (8 m-tiles x 2 planes), one barrier per k-step; 8 = half a k-step, two.
-template <int NT, int CH>
+template <int NT>
 __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__restrict__ h3, const float *__restrict__ pscale,
                                                              const float *__restrict__ latent_q, int P, int d, int k, int ntiles,
                                                              const float *__restrict__ hb, float *__restrict__ patches_out,
@@ -78,12 +76,11 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
     const int p = rem / GRP, blk = grp * GRP + rem % GRP;
     if (blk >= nblk) return;                                  // whole workgroup (before any barrier)
     const int tile0 = blk * 4 * NT + NT * w;
-    constexpr int NB = 4;
+    constexpr int CH = DEC_H2_CHUNK, NB = 4;
     constexpr int DPW = CH / 4;                               // DMA loads per wave per chunk
-    static_assert((DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK) % (CH * NB) == 0 && DEC_H2_GEMM_FRAGS % CH == 0, "the padded stream must be whole ring turns");
     __shared__ __attribute__((aligned(16))) f32x4 swt[NB * CH * 64];
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const WStreamT<CH, NB> ws{hb + DEC_H2_G_W(k) + (size_t)p * DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK * 256, swt, DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK / CH, lane, wu, false};
+    const WStreamT<CH, NB> ws{hb + DEC_H2_G_W(k) + (size_t)p * DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK * 256, swt, DEC_H2_STREAM_CHUNKS, lane, wu, false};
     ws.prologue();
     const float rho0 = hb[DEC_H2_META + H2D_RHO0], sig_q = hb[DEC_H2_META + H2D_SIG_Q], rho1 = hb[DEC_H2_META + H2D_RHO1];
     const float rho2 = hb[DEC_H2_META + H2D_RHO2], rho3 = hb[DEC_H2_META + H2D_RHO3], inv_out = hb[DEC_H2_META + H2D_INV_OUT];
@@ -119,23 +116,13 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
         auto kstep = [&](int t, const uint4 (&bc)[NT][2], uint4 (&bload)[NT][2], bool first) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const f32x4 *buf;
-                if constexpr (CH == 8) {
-                    const int c = 2 * t + half;
-                    if (half == 0) {
-                        if (first) ws.boundary(c); else ws.template boundary_keep<2 * DPW + 2 * NT>(c);
-                        load_b(bload, t + 2);
-                    } else
-                        ws.template boundary_keep<2 * DPW + 4 * NT>(c);
-                    buf = ws.chunk(c);
-                } else {
-                    // one chunk per k-step: boundary(t) needs DMA(t) and B(t); younger than B(t) are DMA(t+2) and B(t+1)
-                    if (half == 0) {
-                        if (first) ws.boundary(t); else ws.template boundary_keep<DPW + 2 * NT>(t);
-                        load_b(bload, t + 2);
-                    }
-                    buf = ws.chunk(t) + half * 8 * 64;
-                }
+                const int c = 2 * t + half;
+                if (half == 0) {
+                    if (first) ws.boundary(c); else ws.template boundary_keep<2 * DPW + 2 * NT>(c);
+                    load_b(bload, t + 2);
+                } else
+                    ws.template boundary_keep<2 * DPW + 4 * NT>(c);
+                const f32x4 *buf = ws.chunk(c);
                 f16x8 a[4][2];
 #pragma unroll
                 for (int mq = 0; mq < 4; ++mq)
@@ -280,13 +267,8 @@ extern "C" int pccx_ae_decode_h2(const float *latent_q, int P, int d, int k, con
     if (rc != PCCX_OK) return rc;
     hipLaunchKernelGGL(dec_h2_prep_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const f32x4 *)h2p, latent_q, P, d, ntiles, 32768.0f, h3, pscale);
     PCCX_CHECK_LAUNCH();
-    static const int ring_ch = []() { const char *e = getenv("PCCX_DEC_H2_CH"); return e && atoi(e) == 8 ? 8 : 16; }();
-    if (ring_ch == 16)
-        hipLaunchKernelGGL((dec_main_h2_kernel<2, 16>), dim3(dec_h2_grid(ntiles, k, 2)), dim3(256), 0, st, (const uint4 *)h3, (const float *)pscale, latent_q,
-                           P, d, k, ntiles, h2_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
-    else
-        hipLaunchKernelGGL((dec_main_h2_kernel<2, 8>), dim3(dec_h2_grid(ntiles, k, 2)), dim3(256), 0, st, (const uint4 *)h3, (const float *)pscale, latent_q,
-                           P, d, k, ntiles, h2_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
+    hipLaunchKernelGGL((dec_main_h2_kernel<2>), dim3(dec_h2_grid(ntiles, k, 2)), dim3(256), 0, st, (const uint4 *)h3, (const float *)pscale, latent_q, P,
+                       d, k, ntiles, h2_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -30,6 +30,10 @@ VARIANTS = {
     "prev": ([], [("@git", "HEAD")]),              # the committed kernels (before the working-tree edits)
     "mg4": (["-DFH_MG=4"], []),
     "nb3": (["-DFH_NB=3"], []),
+    "ch16": (["-DFH_CHUNK=16"], []),
+    "ch48": (["-DFH_CHUNK=48"], []),
+    "ch16nb4": (["-DFH_CHUNK=16", "-DFH_NB=4"], []),
+    "samg4": (["-DFH_SA_MG=4"], []),
     "nosplit": ([], [("encoder_fused_h2.hip", '#define FH_CHUNK', FAKE_DEF + '#define FH_CHUNK'), ("encoder_fused_h2.hip",) + FAKE_SPLIT,
                      ("decoder_h2.hip", '#ifndef DEC_GROUP', FAKE_DEF + '#ifndef DEC_GROUP'), ("decoder_h2.hip",) + FAKE_SPLIT]),
 }
