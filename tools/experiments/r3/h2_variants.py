@@ -30,6 +30,9 @@ VARIANTS = {
     "prev": ([], [("@git", "HEAD")]),              # the committed kernels (before the working-tree edits)
     "mg4": (["-DFH_MG=4"], []),
     "nb3": (["-DFH_NB=3"], []),
+    "noreader": (["-DFH_READER=0"], []),
+    "fifo12": (["-DFH_FIFO=12"], []),
+    "fifo16": (["-DFH_FIFO=16"], []),
     "ch16": (["-DFH_CHUNK=16"], []),
     "ch48": (["-DFH_CHUNK=48"], []),
     "ch16nb4": (["-DFH_CHUNK=16", "-DFH_NB=4"], []),

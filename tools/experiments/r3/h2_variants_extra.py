@@ -1,0 +1,13 @@
+# diagnostic builds of the f16x2 encoder (exec'd by h2_variants.py): garbage results, timing only
+_NODMA = ("mfma_chain.h", "__builtin_amdgcn_global_load_lds((const void *)(src + voff), (lds_u32 *)(uintptr_t)dst, 16, 0, 0);", "(void)src; (void)dst;")
+_NOBAR = ("mfma_chain.h", 'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");\n        __syncthreads();\n        issue_ahead(c);',
+          'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");\n        issue_ahead(c);')
+_ONLYPN = ("encoder_fused_h2.hip", "if (unit >= units) break;", "break;")
+_NOSPLIT = [("encoder_fused_h2.hip", '#ifndef FH_CHUNK', FAKE_DEF + '#ifndef FH_CHUNK'), ("encoder_fused_h2.hip",) + FAKE_SPLIT]
+VARIANTS["nosplit"] = ([], _NOSPLIT + [("decoder_h2.hip", '#ifndef DEC_GROUP', FAKE_DEF + '#ifndef DEC_GROUP'), ("decoder_h2.hip",) + FAKE_SPLIT])
+VARIANTS["nodma"] = ([], [_NODMA])
+VARIANTS["nodma_nobar"] = ([], [_NODMA, _NOBAR])
+VARIANTS["onlypn"] = ([], [_ONLYPN])
+VARIANTS["onlypn_nodma_nobar"] = ([], [_ONLYPN, _NODMA, _NOBAR])
+VARIANTS["onlypn_floor"] = ([], [_ONLYPN, _NODMA, _NOBAR] + _NOSPLIT)
+VARIANTS["nosplit_nodma_nobar"] = ([], [_NODMA, _NOBAR] + _NOSPLIT)
