@@ -5,9 +5,11 @@ _NOBAR = ("mfma_chain.h", 'asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "mem
 _ONLYPN = ("encoder_fused_h2.hip", "if (unit >= units) break;", "break;")
 _NOSPLIT = [("encoder_fused_h2.hip", '#ifndef FH_CHUNK', FAKE_DEF + '#ifndef FH_CHUNK'), ("encoder_fused_h2.hip",) + FAKE_SPLIT]
 VARIANTS["nosplit"] = ([], _NOSPLIT + [("decoder_h2.hip", '#ifndef DEC_GROUP', FAKE_DEF + '#ifndef DEC_GROUP'), ("decoder_h2.hip",) + FAKE_SPLIT])
-VARIANTS["nodma"] = ([], [_NODMA])
-VARIANTS["nodma_nobar"] = ([], [_NODMA, _NOBAR])
+# (builds that removed the LDS-DMA itself faulted on the box -- the ring is then never written and the compiler is free to treat its reads as undefined --
+#  and are not kept; the phases are separated instead)
+_ONLYSA = ("encoder_fused_h2.hip", "#define FH_DENSE(KT, MT, in, acc) dense_h2_rd<KT, MT, 1>(rd, f, in, acc)", "#define FH_DENSE(KT, MT, in, acc) (void)0")
 VARIANTS["onlypn"] = ([], [_ONLYPN])
-VARIANTS["onlypn_nodma_nobar"] = ([], [_ONLYPN, _NODMA, _NOBAR])
-VARIANTS["onlypn_floor"] = ([], [_ONLYPN, _NODMA, _NOBAR] + _NOSPLIT)
-VARIANTS["nosplit_nodma_nobar"] = ([], [_NODMA, _NOBAR] + _NOSPLIT)
+VARIANTS["onlysa"] = ([], [_ONLYSA])
+VARIANTS["onlypn_nosplit"] = ([], [_ONLYPN] + _NOSPLIT)
+VARIANTS["onlysa_nosplit"] = ([], [_ONLYSA] + _NOSPLIT)
+VARIANTS["onlypn_nobar"] = ([], [_ONLYPN, _NOBAR])
