@@ -354,9 +354,12 @@ class AE(nn.Module):
     def encode(self, patches, sa_matmul=None, pn_matmul=None, fused=True):
         """patches (BS,K,3), centred and scaled -> (latent_raw, latent, latent_quantized), each (BS,d).
         = ae.sa + ae.pn + sigmoid spread + round (compress.py:113-127, AE.py:37-45).
-        sa_matmul / pn_matmul: "f32" (exact-fp32 MFMA) or "bf16x3" (fp32 products of three bf16 pieces per operand on the
-        bf16 matrix cores: fp32-level error; a latent within ~1e-6 of a rounding boundary may round the other way);
-        None = pccx.DEFAULT_MATMUL.  fused=False forces the two-kernel path (feature map through HBM) in bf16x3 mode."""
+        sa_matmul / pn_matmul: "f32" (exact-fp32 MFMA), "bf16x3" (fp32 products of three bf16 pieces per operand on the
+        bf16 matrix cores) or "f16x2" (two exactly scaled fp16 pieces per operand, three products on the fp16 matrix cores;
+        both split modes: fp32-level error, a latent within ~1e-6 of a rounding boundary may round the other way);
+        None = pccx.DEFAULT_MATMUL.  "f16x2" exists as the fused kernel only: with fused=False, a K the fused kernel does not hold
+        (> 512) or different modes for the two modules, an "f16x2" request runs the bf16x3 kernels.  fused=False forces the
+        two-kernel path (feature map through HBM)."""
         x = _f32c(patches, "AE.encode")
         P, K, _ = x.shape
         if not self.fused_d:
@@ -430,8 +433,8 @@ class AE(nn.Module):
     def decode(self, latent_q, centres=None, center=None, longest=None, S=None, scale=None, margin=0.01, matmul=None):
         """latent_q (BS,d) -> decoded patches (BS,k,3) (AE.py:48-53).  With centres/center/longest/S/scale
         it returns instead the reassembled, denormalised cloud (B,S*k,3) of decompress.py:104-116.
-        matmul="bf16x3" evaluates the matrix products as fp32 products of three bf16 pieces per operand on the bf16
-        matrix cores (fp32-level error, not bit-identical to "f32"); None = pccx.DEFAULT_MATMUL."""
+        matmul="bf16x3" / "f16x2" evaluate the matrix products as fp32 products of three bf16 / two exactly scaled fp16 pieces
+        per operand on the matrix cores (fp32-level error, not bit-identical to "f32"); None = pccx.DEFAULT_MATMUL."""
         matmul = matmul or _pccx_default_matmul()
         q = _f32c(latent_q, "AE.decode")
         P = q.shape[0]

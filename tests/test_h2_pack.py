@@ -165,3 +165,30 @@ def test_pack_rejects_non_finite_weights():
     ae.load_state_dict(sd)
     with pytest.raises(_lib.PccxError):
         models._pack("pccx_pack_ae_encoder_h2", _lib.load().pccx_ae_encoder_h2_blob_floats(), ae._enc_tensors(), [d])
+
+
+def test_two_piece_split_arithmetic_property():
+    """The arithmetic behind the mode, in numpy (IEEE binary16, round to nearest even -- what v_cvt_pk_f16_f32 does): for operands
+    scaled into fp16's normal range, hi = rn16(x), lo = rn16(x - hi) reproduce x to 2^-22 |x|, the residual x - hi is exact in fp32,
+    and hi*hi + hi*lo + lo*hi (each product exact in fp32: 11 x 11 bits) differs from x*y by at most 3 * 2^-22 |x y|."""
+    rng = np.random.default_rng(9)
+    mag = lambda emax: rng.uniform(0.25, 2.0, 200000) * np.exp2(rng.integers(0, emax, 200000)) * rng.choice([-1.0, 1.0], 200000)
+    x, y = mag(14).astype(np.float32), mag(13).astype(np.float32)          # |x| >= 2^-2: the lo piece is a normal fp16 number
+
+    def split(v):
+        hi = v.astype(np.float16)
+        assert np.isfinite(hi).all()
+        r = v - hi.astype(np.float32)                                   # fp32 subtraction
+        assert np.array_equal(r.astype(np.float64), v.astype(np.float64) - hi.astype(np.float64))     # ... is exact
+        lo = r.astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    xh, xl = split(x)
+    yh, yl = split(y)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    assert (np.abs(x64 - xh - xl) <= 2.0 ** -22 * np.abs(x64)).all()
+    for a, b in ((xh, yh), (xh, yl), (xl, yh)):
+        p = a * b
+        assert np.array_equal(p, p.astype(np.float32).astype(np.float64))       # every partial product is an fp32 number
+    approx = xh * yh + xh * yl + xl * yh
+    assert (np.abs(approx - x64 * y64) <= 3 * 2.0 ** -22 * np.abs(x64 * y64)).all()
