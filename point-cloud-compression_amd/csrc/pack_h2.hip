@@ -218,6 +218,20 @@ extern "C" int pccx_pack_ae_encoder_h2(const float *sa_w0, const float *sa_b0, c
         f += (size_t)((segs[l].kt16 + 1) / 2) * segs[l].w * 2;
     }
     if (f != PN_H2_STREAM_FRAGS) { pccx_set_error("pccx_pack_ae_encoder_h2: stream has %zu fragments", f); return PCCX_ERR_ARG; }
+    {   // the order of the two-tiles-per-wave form (blobs.h: ENC_H2_PN_STREAM2)
+        float *st = blob + ENC_H2_PN_STREAM2;
+        h2_planes(enc.data() + ENC_PN_W0, 9, 8, 8, tp0, st);
+        size_t g = PN_H2_S2_L0_FRAGS;
+        h2_planes(enc.data() + ENC_PN_W1, 8, 16, 16, tp1, st + g * 256);
+        g += 128;
+        for (int e = 0; e < 8; ++e) {
+            h2_planes(enc.data() + ENC_PN_W2 + (size_t)4 * e * 256, 16, 4, 32, tp2, st + g * 256);
+            g += 64;
+            h2_planes(enc.data() + ENC_PN_W3 + (size_t)4 * e * 256, 4, 1, 1, tp3, st + g * 256);
+            g += 4;
+        }
+        if (g != PN_H2_S2_L0_FRAGS + PN_H2_S2_MAIN_FRAGS) { pccx_set_error("pccx_pack_ae_encoder_h2: second stream has %zu fragments", g); return PCCX_ERR_ARG; }
+    }
     for (int i = 0; i < 8; ++i)
         if (!(meta[i] > 0.f) || !isfinite(meta[i])) { pccx_set_error("pccx_pack_ae_encoder_h2: scale %d is not a positive finite number (non-finite weights?)", i); return PCCX_ERR_ARG; }
     return PCCX_OK;

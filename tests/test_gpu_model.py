@@ -414,6 +414,24 @@ def test_f16x2_matches_fp32_path(Kx, kx, P):
         np.testing.assert_allclose(b, want.reshape(b.shape), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("Kx,P", [(256, 300), (512, 9)])
+def test_f16x2_two_tile_pointnet_equals_one_tile_form_bit_for_bit(Kx, P, monkeypatch):
+    """K a multiple of 256 runs PointNet's layers 1-3 with TWO point tiles per wave (csrc/encoder_fused_h2.hip, NT2: the weight stream
+    once per 256 points, layer 2 in eight slices); PCCX_ENC_H2_NT=1 forces the one-tile form.  Every accumulator sees the same products
+    in the same order, so raw latents, latents and symbols are IDENTICAL."""
+    ae = _seeded_ae(Kx, Kx // 2)
+    rng = np.random.default_rng(Kx + P)
+    x = torch.from_numpy((rng.random((P, Kx, 3)).astype(np.float32) - 0.5) * np.exp2(rng.integers(-2, 3, size=(P, 1, 1))).astype(np.float32)).cuda()
+    monkeypatch.delenv("PCCX_ENC_H2_NT", raising=False)
+    a = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    monkeypatch.setenv("PCCX_ENC_H2_NT", "1")
+    b = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    monkeypatch.delenv("PCCX_ENC_H2_NT", raising=False)
+    c = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    for u, v, w_ in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u, w_)
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 0.99999994, 2.0, 37.0, 3000.0, 1e6])
 def test_f16x2_per_patch_normalisation_over_input_magnitudes(scale):
     """fp16 has five exponent bits; the f16x2 kernels bring every operand into range with exact power-of-two scales, one of them

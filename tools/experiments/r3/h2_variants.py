@@ -31,6 +31,8 @@ VARIANTS = {
     "mg4": (["-DFH_MG=4"], []),
     "nb3": (["-DFH_NB=3"], []),
     "noreader": (["-DFH_READER=0"], []),
+    "f2_4": (["-DFH_FIFO2=4"], []),
+    "f2_12": (["-DFH_FIFO2=12"], []),
     "fifo12": (["-DFH_FIFO=12"], []),
     "fifo16": (["-DFH_FIFO=16"], []),
     "ch16": (["-DFH_CHUNK=16"], []),
@@ -122,6 +124,13 @@ def run(clouds, tags):
     ref = None
     V = C.c_void_p
     for t in tags:
+        if t.endswith("@nt1"):                   # tag@nt1: the one-tile-per-wave PointNet form of the same build (PCCX_ENC_H2_NT=1, read per call)
+            os.environ["PCCX_ENC_H2_NT"] = "1"
+            t = t[:-4]
+            label = t + "@nt1"
+        else:
+            os.environ.pop("PCCX_ENC_H2_NT", None)
+            label = t
         lib = C.CDLL(os.path.join(OUT, f"libh2_{t}.so"))
         lib.encv_last_error.restype = C.c_char_p
         fe = lib.pccx_ae_encode_h2_ws
@@ -138,7 +147,7 @@ def run(clouds, tags):
         od = torch.zeros(P, k, 3, device="cuda")
         calls = {"enc": lambda: fe(patches.data_ptr(), P, K, enc.data_ptr(), eh2.data_ptr(), d, L, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), wsb.data_ptr(), st),
                  "dec": lambda: fd(q.data_ptr(), P, d, k, dec.data_ptr(), dh2.data_ptr(), wsd.data_ptr(), od.data_ptr(), 0.0, None, None, None, 1, 0.01, None, st)}
-        line = f"{t:14s}"
+        line = f"{label:14s}"
         for name, call in calls.items():
             for _ in range(2):
                 rc = call()

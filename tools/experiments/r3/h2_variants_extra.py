@@ -13,3 +13,10 @@ VARIANTS["onlysa"] = ([], [_ONLYSA])
 VARIANTS["onlypn_nosplit"] = ([], [_ONLYPN] + _NOSPLIT)
 VARIANTS["onlysa_nosplit"] = ([], [_ONLYSA] + _NOSPLIT)
 VARIANTS["onlypn_nobar"] = ([], [_ONLYPN, _NOBAR])
+# DIAGNOSTIC: only every second weight fragment is actually read from the LDS ring (the others keep stale registers): is the PointNet phase
+# bound by LDS bandwidth?
+_HALFREADS = ("mfma_chain.h", 'asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[fi % D])', 'if (!(fi & 1)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[fi % D])')
+_NOREADS = ("mfma_chain.h", 'asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[fi % D])', 'if (fi < 8) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[fi % D])')
+VARIANTS["onlypn_halfreads"] = ([], [_ONLYPN, _HALFREADS])
+VARIANTS["onlypn_noreads"] = ([], [_ONLYPN, _NOREADS])
+VARIANTS["onlypn_noreads_nosplit"] = ([], [_ONLYPN, _NOREADS] + _NOSPLIT)
