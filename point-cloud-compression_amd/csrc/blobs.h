@@ -156,7 +156,7 @@
 #define DEC_H2_CHUNK 8
 #define DEC_H2_GEMM_FRAGS (32 * 8 * 2)
 #define DEC_H2_TAIL_FRAGS ((40 + 16 + 4 + 1) * 2)
-#define DEC_H2_STREAM_FRAGS (DEC_H2_GEMM_FRAGS + DEC_H2_TAIL_FRAGS)
+#define DEC_H2_STREAM_FRAGS (DEC_H2_GEMM_FRAGS + 2 * DEC_H2_TAIL_FRAGS)     // the tail twice: inv_mlp runs once per pair of a wave's four patch tiles
 #define DEC_H2_STREAM_CHUNKS (4 * ((DEC_H2_STREAM_FRAGS + 4 * DEC_H2_CHUNK - 1) / (4 * DEC_H2_CHUNK)))      // a multiple of the ring depth
 #define DEC_H2_G_W(k) (DEC_H2_G_B + (size_t)(k) * 128)
 #define DEC_H2_BLOB_FLOATS(k) (DEC_H2_G_W(k) + (size_t)(k) * DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK * 256)

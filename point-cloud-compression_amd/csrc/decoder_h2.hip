@@ -7,6 +7,7 @@
 // Head activations and latents are multiplied by s_n when their planes are formed, every bias by s_n when it initialises an
 // accumulator (inv_pool.4 -> inv_mlp is positively homogeneous in (input, biases)), and the output is divided by s_n.
 #include <math.h>
+#include <stdlib.h>
 
 #include "blobs.h"
 #include "common.h"
@@ -60,6 +61,10 @@ __device__ __forceinline__ uint4 h2_load_async(const uint4 *p)    // placed exac
 
 // grid: groups of DEC_GROUP patch blocks outermost, then the point p, then the block inside the group (decoder.hip); 4 waves, wave w
 // owns patch tiles NT w .. NT w + NT - 1 of its block.
+// NT = 2: the shape of decoder.hip's bf16x3 kernel.  NT = 4 (the default): FOUR patch tiles per wave in the GEMM -- every weight block read
+// from the ring feeds 12 MFMAs instead of 6 and point p's stream enters LDS once per 256 patches instead of once per 128 (the two fp16 planes of
+// four tiles' operands fit the two-waves-per-SIMD register budget where three bf16 planes did not: decoder.hip's NT = 4 needs one wave per SIMD);
+// inv_mlp then runs twice on two tiles each, from the tail's fragments stored twice in the stream (blobs.h).  Same products in the same order.
 template <int NT>
 __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__restrict__ h3, const float *__restrict__ pscale,
                                                              const float *__restrict__ latent_q, int P, int d, int k, int ntiles,
@@ -68,6 +73,9 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
                                                              const float *__restrict__ nrm_center, const float *__restrict__ nrm_longest, int S,
                                                              float one_minus_margin, float *__restrict__ pc_out)
 {
+    static_assert(NT == 2 || NT == 4, "two or four patch tiles per wave");
+    constexpr int NP = NT / 2;                                // tile pairs: inv_mlp runs once per pair
+    constexpr int SETS = NT == 2 ? 3 : 2;                     // rotating B register sets (NT = 4: one k-step ahead, 64 registers)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     constexpr int GRP = DEC_GROUP * 2 / NT;
@@ -92,20 +100,21 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
         tq[nt] = tile0 + nt < ntiles ? tile0 + nt : ntiles - 1;
         sn[nt] = pscale[tq[nt] * 16 + n];
     }
-    f32x4 acc[NT][8];
+    f32x4 acc[NP][2][8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const f32x4 b = *(const f32x4 *)(hb + DEC_H2_G_B + (size_t)p * 128 + 16 * mt + 4 * g);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = b * sn[nt];
+        for (int nt = 0; nt < NT; ++nt) acc[nt >> 1][nt & 1][mt] = b * sn[nt];
     }
     {
         // ---- GEMM over K = 1024 as 32 k-steps of 32.  A planes through the 4-deep LDS ring (chunk = 4 m-tiles x 2 planes, DMA
-        // three chunks ahead); the B planes of this wave's patch tiles in three rotating register sets, loaded two k-steps ahead by
+        // three chunks ahead); the B planes of this wave's patch tiles in SETS rotating register sets, loaded SETS - 1 k-steps ahead by
         // asm loads whose completion rides on the ring's waits.  VMEM issue order per wave:
-        //   boundary(2t):   DMA(2t+3) [DPW loads], B(t+2) [2 NT loads]        boundary(2t+1): DMA(2t+4) [DPW loads]
-        // so boundary(2t) needs all but its 2 DPW + 2 NT youngest loads and boundary(2t+1) all but its 2 DPW + 4 NT youngest.
-        uint4 bs[3][NT][2];
+        //   boundary(2t):   DMA(2t+3) [DPW loads], B(t + SETS - 1) [2 NT loads]        boundary(2t+1): DMA(2t+4) [DPW loads]
+        // three sets: boundary(2t) needs all but its 2 DPW + 2 NT youngest loads, boundary(2t+1) all but its 2 DPW + 4 NT youngest;
+        // two sets:   boundary(2t) needs B(t), issued one k-step ago: all but the DPW loads of DMA(2t+2); boundary(2t+1) as above.
+        uint4 bs[SETS][NT][2];
         auto load_b = [&](uint4 (&dst)[NT][2], int t) {
             const int tc = t < 32 ? t : 31;
 #pragma unroll
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
             for (int half = 0; half < 2; ++half) {
                 const int c = 2 * t + half;
                 if (half == 0) {
-                    if (first) ws.boundary(c); else ws.template boundary_keep<2 * DPW + 2 * NT>(c);
-                    load_b(bload, t + 2);
+                    if (first) ws.boundary(c); else ws.template boundary_keep<SETS == 3 ? 2 * DPW + 2 * NT : DPW>(c);
+                    load_b(bload, t + SETS - 1);
                 } else
                     ws.template boundary_keep<2 * DPW + 4 * NT>(c);
                 const f32x4 *buf = ws.chunk(c);
@@ -136,113 +145,128 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[nt][4 * half + mq] = H2_MFMA(a[mq][PA[q]], __builtin_bit_cast(f16x8, bc[nt][PB[q]]), acc[nt][4 * half + mq]);
+                            acc[nt >> 1][nt & 1][4 * half + mq] =
+                                H2_MFMA(a[mq][PA[q]], __builtin_bit_cast(f16x8, bc[nt][PB[q]]), acc[nt >> 1][nt & 1][4 * half + mq]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        load_b(bs[0], 0);
-        load_b(bs[1], 1);
-        kstep(0, bs[0], bs[2], true);                     // boundary(0) waits for everything issued so far
-        kstep(1, bs[1], bs[0], false);
+        if constexpr (SETS == 3) {
+            load_b(bs[0], 0);
+            load_b(bs[1], 1);
+            kstep(0, bs[0], bs[2], true);                     // boundary(0) waits for everything issued so far
+            kstep(1, bs[1], bs[0], false);
 #pragma unroll 1
-        for (int t = 2; t < 32; t += 3) {                 // t = 2, 5, ..., 29: three k-steps per trip, static register sets
-            kstep(t, bs[2], bs[1], false);
-            kstep(t + 1, bs[0], bs[2], false);
-            kstep(t + 2, bs[1], bs[0], false);
+            for (int t = 2; t < 32; t += 3) {                 // t = 2, 5, ..., 29: three k-steps per trip, static register sets
+                kstep(t, bs[2], bs[1], false);
+                kstep(t + 1, bs[0], bs[2], false);
+                kstep(t + 2, bs[1], bs[0], false);
+            }
+        } else {
+            load_b(bs[0], 0);
+            kstep(0, bs[0], bs[1], true);
+            kstep(1, bs[1], bs[0], false);
+#pragma unroll 1
+            for (int t = 2; t < 32; t += 2) {                 // two k-steps per trip, static register sets
+                kstep(t, bs[0], bs[1], false);
+                kstep(t + 1, bs[1], bs[0], false);
+            }
         }
-        // The last B loads (k-steps 32 and 33, clamped, unused) are still in flight.  Their registers are dead to the compiler, which is
+        // The last B loads (clamped, unused) are still in flight.  Their registers are dead to the compiler, which is
         // free to reuse them -- and to hoist register-only work of the tail above a bare wait: a build of this kernel with a larger
         // ring chunk did exactly that and had its tail's operands overwritten by the late loads (tools/asm_load_lint.py finds it).
         // Naming the registers after the wait keeps them allocated until the loads have landed.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < SETS; ++i)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) asm volatile("" ::"v"(__builtin_bit_cast(f32x4, bs[i][nt][pl])));
     }
-    // ---- inv_mlp as an f16x2 chain on registers: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent
-    f32x4 m3[NT][1];
-    {
-        int f = DEC_H2_GEMM_FRAGS;
-        f16x8 i0[NT][5][2];
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // ---- inv_mlp as an f16x2 chain on registers, two tiles at a time: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent.
+    // Pair pr reads the tail's fragments from their pr-th copy in the stream, which simply continues.
+    int f = DEC_H2_GEMM_FRAGS;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+    for (int pr = 0; pr < NP; ++pr) {
+        f32x4 m3[2][1];
+        {
+            f16x8 i0[2][5][2];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) h2_split8(relu4(acc[nt][2 * t]), relu4(acc[nt][2 * t + 1]), rho0, i0[nt][t]);
-            const int patch = (tile0 + nt) * 16 + n;
-            f32x4 lat;
+            for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lat[r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
-            h2_split8(lat, zero, sn[nt] * sig_q, i0[nt][4]);
+                for (int t = 0; t < 4; ++t) h2_split8(relu4(acc[pr][nt][2 * t]), relu4(acc[pr][nt][2 * t + 1]), rho0, i0[nt][t]);
+                const int patch = (tile0 + 2 * pr + nt) * 16 + n;
+                f32x4 lat;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lat[r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
+                h2_split8(lat, zero, sn[2 * pr + nt] * sig_q, i0[nt][4]);
+            }
+            f32x4 m0[2][8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B0 + 16 * mt + 4 * g) * sn[2 * pr + nt];
+            dense_h2_stream<5, 8, 2>(ws, f, i0, m0);
+            f16x8 i1[2][4][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h2_split8(relu4(m0[nt][2 * t]), relu4(m0[nt][2 * t + 1]), rho1, i1[nt][t]);
+            f32x4 m1[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B1 + 16 * mt + 4 * g) * sn[2 * pr + nt];
+            dense_h2_stream<4, 4, 2>(ws, f, i1, m1);
+            f16x8 i2[2][2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) h2_split8(relu4(m1[nt][2 * t]), relu4(m1[nt][2 * t + 1]), rho2, i2[nt][t]);
+            f32x4 m2[2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B2 + 16 * mt + 4 * g) * sn[2 * pr + nt];
+            dense_h2_stream<2, 2, 2>(ws, f, i2, m2);
+            f16x8 i3[2][1][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) h2_split8(relu4(m2[nt][0]), relu4(m2[nt][1]), rho3, i3[nt][0]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(hb + DEC_H2_M_B3 + 4 * g) * sn[2 * pr + nt];
+            dense_h2_stream<1, 1, 2>(ws, f, i3, m3);          // last layer: no ReLU (AE.py:27)
         }
-        f32x4 m0[NT][8];
+        // ---- epilogue of the pair: rows 0..2 of the last tile (g == 0, r = 0..2) are x,y,z of (patch, point p)
+        if (g == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
+                const int tile = tile0 + 2 * pr + nt, patch = tile * 16 + n;
+                if (tile < ntiles && patch < P) {
+                    const float un = __fmul_rn(inv_out, __fdiv_rn(1.0f, sn[2 * pr + nt]));       // undo the operand scales (exact)
+                    float v[3] = {__fmul_rn(m3[nt][0][0], un), __fmul_rn(m3[nt][0][1], un), __fmul_rn(m3[nt][0][2], un)};
+                    if (patches_out) {
+                        float *o = patches_out + ((size_t)patch * k + p) * 3;       // new_xyz.transpose(2,1)
+                        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+                    }
+                    if (pc_out) {
+                        const int b = patch / S;
+                        const float lg = nrm_longest[b];
+                        float *o = pc_out + ((size_t)patch * k + p) * 3;            // (B, S*k, 3): index s*k + p
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B0 + 16 * mt + 4 * g) * sn[nt];
-        dense_h2_stream<5, 8, NT>(ws, f, i0, m0);
-        f16x8 i1[NT][4][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) h2_split8(relu4(m0[nt][2 * t]), relu4(m0[nt][2 * t + 1]), rho1, i1[nt][t]);
-        f32x4 m1[NT][4];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B1 + 16 * mt + 4 * g) * sn[nt];
-        dense_h2_stream<4, 4, NT>(ws, f, i1, m1);
-        f16x8 i2[NT][2][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) h2_split8(relu4(m1[nt][2 * t]), relu4(m1[nt][2 * t + 1]), rho2, i2[nt][t]);
-        f32x4 m2[NT][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B2 + 16 * mt + 4 * g) * sn[nt];
-        dense_h2_stream<2, 2, NT>(ws, f, i2, m2);
-        f16x8 i3[NT][1][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) h2_split8(relu4(m2[nt][0]), relu4(m2[nt][1]), rho3, i3[nt][0]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) m3[nt][0] = *(const f32x4 *)(hb + DEC_H2_M_B3 + 4 * g) * sn[nt];
-        dense_h2_stream<1, 1, NT>(ws, f, i3, m3);          // last layer: no ReLU (AE.py:27)
-    }
-    ws.drain();
-
-    // ---- epilogue: rows 0..2 of the last tile (g == 0, r = 0..2) are x,y,z of (patch, point p)
-    if (g == 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int patch = (tile0 + nt) * 16 + n;
-            if (tile0 + nt < ntiles && patch < P) {
-                const float un = __fmul_rn(inv_out, __fdiv_rn(1.0f, sn[nt]));                    // undo the operand scales (exact)
-                float v[3] = {__fmul_rn(m3[nt][0][0], un), __fmul_rn(m3[nt][0][1], un), __fmul_rn(m3[nt][0][2], un)};
-                if (patches_out) {
-                    float *o = patches_out + ((size_t)patch * k + p) * 3;       // new_xyz.transpose(2,1)
-                    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-                }
-                if (pc_out) {
-                    const int b = patch / S;
-                    const float lg = nrm_longest[b];
-                    float *o = pc_out + ((size_t)patch * k + p) * 3;            // (B, S*k, 3): index s*k + p
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        float t = __fdiv_rn(v[a], inv_scale_div);                            // decompress.py:107
-                        t = __fadd_rn(t, centres[(size_t)patch * 3 + a]);                     // decompress.py:110
-                        t = __fsub_rn(t, 0.5f);                                               // pn_kit.py:63
-                        t = __fdiv_rn(__fmul_rn(t, lg), one_minus_margin);                   // pn_kit.py:64
-                        o[a] = __fadd_rn(t, nrm_center[3 * b + a]);                           // pn_kit.py:65
+                        for (int a = 0; a < 3; ++a) {
+                            float t = __fdiv_rn(v[a], inv_scale_div);                            // decompress.py:107
+                            t = __fadd_rn(t, centres[(size_t)patch * 3 + a]);                     // decompress.py:110
+                            t = __fsub_rn(t, 0.5f);                                               // pn_kit.py:63
+                            t = __fdiv_rn(__fmul_rn(t, lg), one_minus_margin);                   // pn_kit.py:64
+                            o[a] = __fadd_rn(t, nrm_center[3 * b + a]);                           // pn_kit.py:65
+                        }
                     }
                 }
             }
         }
     }
+    ws.drain();
 }
 
 static unsigned dec_h2_grid(int ntiles, int k, int NT)
@@ -277,8 +301,14 @@ extern "C" int pccx_ae_decode_h2(const float *latent_q, int P, int d, int k, con
     if (rc != PCCX_OK) return rc;
     hipLaunchKernelGGL(dec_h2_prep_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const f32x4 *)h2p, latent_q, P, d, ntiles, 32768.0f, h3, pscale);
     PCCX_CHECK_LAUNCH();
-    hipLaunchKernelGGL((dec_main_h2_kernel<2>), dim3(dec_h2_grid(ntiles, k, 2)), dim3(256), 0, st, (const uint4 *)h3, (const float *)pscale, latent_q, P,
-                       d, k, ntiles, h2_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
+    // four patch tiles per wave unless PCCX_DEC_H2_NT=2 asks for the two-tile form (same results; read per call for A/B and tests)
+    const char *e = getenv("PCCX_DEC_H2_NT");
+    if (e && atoi(e) == 2)
+        hipLaunchKernelGGL((dec_main_h2_kernel<2>), dim3(dec_h2_grid(ntiles, k, 2)), dim3(256), 0, st, (const uint4 *)h3, (const float *)pscale, latent_q, P,
+                           d, k, ntiles, h2_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
+    else
+        hipLaunchKernelGGL((dec_main_h2_kernel<4>), dim3(dec_h2_grid(ntiles, k, 4)), dim3(256), 0, st, (const uint4 *)h3, (const float *)pscale, latent_q, P,
+                           d, k, ntiles, h2_blob, patches_out, scale, centres, nrm_center, nrm_longest, S > 0 ? S : 1, (float)(1.0 - margin), pc_out);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -303,6 +303,7 @@ extern "C" int pccx_pack_ae_decoder_h2(const float *ip_w0, const float *ip_b0, c
         float *st = blob + DEC_H2_G_W(k) + (size_t)p * dst_stride;
         h2_planes(dec.data() + DEC_G_W(k) + (size_t)p * src_stride, 64, 8, 8, tau_g, st);
         memcpy(st + (size_t)DEC_H2_GEMM_FRAGS * 256, tail.data(), tail.size() * sizeof(float));
+        memcpy(st + (size_t)(DEC_H2_GEMM_FRAGS + DEC_H2_TAIL_FRAGS) * 256, tail.data(), tail.size() * sizeof(float));       // second copy (blobs.h)
     }
     for (int i = 0; i < 7; ++i)
         if (!(meta[i] > 0.f) || !isfinite(meta[i])) { pccx_set_error("pccx_pack_ae_decoder_h2: scale %d is not a positive finite number (non-finite weights?)", i); return PCCX_ERR_ARG; }

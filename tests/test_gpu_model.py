@@ -432,6 +432,25 @@ def test_f16x2_two_tile_pointnet_equals_one_tile_form_bit_for_bit(Kx, P, monkeyp
         assert torch.equal(u, v) and torch.equal(u, w_)
 
 
+@pytest.mark.parametrize("kx,P", [(128, 700), (32, 37), (256, 3)])
+def test_f16x2_decoder_four_tile_form_equals_two_tile_form_bit_for_bit(kx, P, monkeypatch):
+    """dec_main_h2_kernel<4> (four patch tiles per wave in the GEMM, inv_mlp in two batches from the tail's second copy in the stream;
+    the default) against <2> (PCCX_DEC_H2_NT=2): every accumulator sees the same products in the same order, so the outputs are
+    IDENTICAL; P = 700 leaves the last workgroup with clamped tiles, P = 3 all but one wave."""
+    ae = _seeded_ae(2 * kx, kx)
+    rng = np.random.default_rng(kx + P)
+    lq = torch.from_numpy(rng.integers(-3, 4, size=(P, d)).astype(np.float32) * np.exp2(rng.integers(-1, 3, size=(P, 1))).astype(np.float32)).cuda()
+    monkeypatch.delenv("PCCX_DEC_H2_NT", raising=False)
+    a = ae.decode(lq, matmul="f16x2")
+    monkeypatch.setenv("PCCX_DEC_H2_NT", "2")
+    b = ae.decode(lq, matmul="f16x2")
+    monkeypatch.delenv("PCCX_DEC_H2_NT", raising=False)
+    c = ae.decode(lq, matmul="f16x2")
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+    ref = ae.decode(lq, matmul="f32")
+    assert float((a - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 0.99999994, 2.0, 37.0, 3000.0, 1e6])
 def test_f16x2_per_patch_normalisation_over_input_magnitudes(scale):
     """fp16 has five exponent bits; the f16x2 kernels bring every operand into range with exact power-of-two scales, one of them

@@ -124,13 +124,15 @@ def run(clouds, tags):
     ref = None
     V = C.c_void_p
     for t in tags:
-        if t.endswith("@nt1"):                   # tag@nt1: the one-tile-per-wave PointNet form of the same build (PCCX_ENC_H2_NT=1, read per call)
-            os.environ["PCCX_ENC_H2_NT"] = "1"
-            t = t[:-4]
-            label = t + "@nt1"
-        else:
-            os.environ.pop("PCCX_ENC_H2_NT", None)
-            label = t
+        label = t
+        os.environ.pop("PCCX_ENC_H2_NT", None)
+        os.environ.pop("PCCX_DEC_H2_NT", None)
+        while "@" in t:                          # tag@nt1: one point tile per wave in PointNet; tag@d2: two patch tiles per wave in the decoder
+            t, opt = t.rsplit("@", 1)            # (forms of the same build, chosen per call by PCCX_ENC_H2_NT / PCCX_DEC_H2_NT)
+            if opt == "nt1":
+                os.environ["PCCX_ENC_H2_NT"] = "1"
+            elif opt == "d2":
+                os.environ["PCCX_DEC_H2_NT"] = "2"
         lib = C.CDLL(os.path.join(OUT, f"libh2_{t}.so"))
         lib.encv_last_error.restype = C.c_char_p
         fe = lib.pccx_ae_encode_h2_ws
