@@ -432,6 +432,39 @@ def test_f16x2_two_tile_pointnet_equals_one_tile_form_bit_for_bit(Kx, P, monkeyp
         assert torch.equal(u, v) and torch.equal(u, w_)
 
 
+def test_every_mode_against_the_float64_oracle(nets):
+    """How far each arithmetic is from the TRUE result: the oracle's modules evaluated in float64 on the same fp32 inputs and weights.
+    The exact-fp32 MFMA kernels are themselves ~1e-6 away (fp32 accumulation); the split-operand modes must not be further than
+    1.5 x that (measured: all three within 10 % of each other -- the accumulation, not the operand representation, dominates)."""
+    ae, _, oae, _ = nets
+    o64 = ref_model.AE(K, k, d, L).eval()
+    o64.load_state_dict(oae.state_dict())
+    o64 = o64.double()
+    patches = synth.patch_batch(K)
+    x = torch.from_numpy(patches).cuda()
+    with torch.no_grad():
+        lat64 = o64.encode(torch.from_numpy(patches).double()).numpy()
+    err = {}
+    for mode in ("f32", "bf16x3", "f16x2"):
+        _, lat, q = ae.encode(x, sa_matmul=mode, pn_matmul=mode)
+        err[mode] = np.abs(lat.cpu().numpy().astype(np.float64) - lat64)
+    print("latent error against float64, max / rms:", {m: (float(e.max()), float(np.sqrt((e ** 2).mean()))) for m, e in err.items()})
+    for mode in ("bf16x3", "f16x2"):
+        assert err[mode].max() <= 1.5 * err["f32"].max() + 1e-7, (mode, err[mode].max(), err["f32"].max())
+        assert np.sqrt((err[mode] ** 2).mean()) <= 1.5 * np.sqrt((err["f32"] ** 2).mean()) + 1e-8
+    lq = torch.from_numpy(synth.latent_case(2, d, L))
+    with torch.no_grad():
+        dec64 = o64.decode(lq.double()).numpy()
+    derr = {}
+    for mode in ("f32", "bf16x3", "f16x2"):
+        out = ae.decode(lq.cuda(), matmul=mode).cpu().numpy().astype(np.float64)
+        derr[mode] = np.abs(out - dec64.reshape(out.shape))
+    print("decoder error against float64, max / rms:", {m: (float(e.max()), float(np.sqrt((e ** 2).mean()))) for m, e in derr.items()})
+    for mode in ("bf16x3", "f16x2"):
+        assert derr[mode].max() <= 1.5 * derr["f32"].max() + 1e-8, (mode, derr[mode].max(), derr["f32"].max())
+        assert np.sqrt((derr[mode] ** 2).mean()) <= 1.5 * np.sqrt((derr["f32"] ** 2).mean()) + 1e-9
+
+
 @pytest.mark.parametrize("kx,P", [(128, 700), (32, 37), (256, 3)])
 def test_f16x2_decoder_four_tile_form_equals_two_tile_form_bit_for_bit(kx, P, monkeypatch):
     """dec_main_h2_kernel<4> (four patch tiles per wave in the GEMM, inv_mlp in two batches from the tail's second copy in the stream;
