@@ -77,6 +77,18 @@ def committed_traffic(stage, batch, matmul="bf16x3"):
     return None, None
 
 
+def committed_traffic_of(kernel, batch):
+    """the same lookup by kernel name"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * batch / j.get("batch", 256)), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def committed_pmc(stage, matmul="bf16x3"):
     """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over the cycles of all SIMDs) and the clock the chip held during the
     stage's kernel (GRBM_GUI_ACTIVE / 8 / duration), from the same committed PMC passes -- NOT measured in this run."""
@@ -361,7 +373,15 @@ def roofline_of(stages, steps, P, matmul, batch):
     else:
         peak, note = F32_MATRIX_PEAK_TFLOPS, "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) against the fp32 matrix peak"
     traffic, src = committed_traffic(dom, batch, matmul)
-    rf = {"kernel": dom, "kernel_name": stage_kernel(dom, matmul), "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+    stage_kernels = [stage_kernel(dom, matmul)]
+    if dom == "sa_pn_forward":
+        # the stage's HIP events bracket TWO kernels: the in-patch neighbour tables (patch_knn16_kernel, no matrix work) and the fused encoder;
+        # `achieved` divides the encoder's FLOPs by the time of both (rocprofv3 lists them separately: profiles/*_kernel_stats.csv)
+        stage_kernels = ["patch_knn16_kernel"] + stage_kernels
+        t2, _ = committed_traffic_of("patch_knn16_kernel", batch)
+        if traffic is not None and t2 is not None:
+            traffic += t2
+    rf = {"kernel": dom, "kernel_name": stage_kernel(dom, matmul), "stage_kernels": stage_kernels, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
           "traffic": traffic, "traffic_source": src, "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P,
           "arithmetic": matmul, "note": note, "window": "resident leg (single stream; HIP events per stage)",
           "pmc": committed_pmc(dom, matmul)}
