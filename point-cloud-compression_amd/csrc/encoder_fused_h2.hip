@@ -8,7 +8,8 @@
 // patch's largest |coordinate| times s is at most 1.  Coordinates and biases are multiplied by s when they are staged (the stack is
 // positively homogeneous in the two), the latent is divided by it at the end; since s is a power of two nothing rounds differently.
 //
-// The in-patch neighbour tables come from patch_knn.hip (pccx_patch_knn16), as in the default bf16x3 form.
+// The in-patch neighbour tables come from patch_knn.hip (pccx_patch_knn16), as in the bf16x3 form.  Two kernel forms (template NT2, below):
+// one or two 16-point tiles per wave in PointNet; the weight fragments reach the MFMAs through a register FIFO (mfma_chain.h: H2Reader).
 #include <math.h>
 #include <stdlib.h>
 
