@@ -357,8 +357,8 @@ class AE(nn.Module):
         sa_matmul / pn_matmul: "f32" (exact-fp32 MFMA), "bf16x3" (fp32 products of three bf16 pieces per operand on the
         bf16 matrix cores) or "f16x2" (two exactly scaled fp16 pieces per operand, three products on the fp16 matrix cores;
         both split modes: fp32-level error, a latent within ~1e-6 of a rounding boundary may round the other way);
-        None = pccx.DEFAULT_MATMUL.  "f16x2" exists as the fused kernel only: with fused=False, a K the fused kernel does not hold
-        (> 512) or different modes for the two modules, an "f16x2" request runs the bf16x3 kernels.  fused=False forces the
+        None = pccx.DEFAULT_MATMUL.  "f16x2" exists as the fused kernel only (it holds every K up to 1024): with fused=False or different modes
+        for the two modules, an "f16x2" request runs the bf16x3 kernels.  fused=False forces the
         two-kernel path (feature map through HBM)."""
         x = _f32c(patches, "AE.encode")
         P, K, _ = x.shape

@@ -432,6 +432,31 @@ def test_f16x2_two_tile_pointnet_equals_one_tile_form_bit_for_bit(Kx, P, monkeyp
         assert torch.equal(u, v) and torch.equal(u, w_)
 
 
+def test_f16x2_at_the_largest_patch_and_without_the_fused_kernel(monkeypatch):
+    """K = 1024: the f16x2 fused encoder still holds the patch (two fp16 weight planes leave the LDS the bf16x3 kernel lacks there):
+    same bars against the exact-fp32 kernels as at K = 256, and its two forms agree bit for bit.  fused=False (ae.sa / ae.pn have no f16x2
+    form of their own) runs the bf16x3 kernels: the same results as asking for them."""
+    from pccx import _lib
+    assert _lib.load().pccx_ae_encode_h2_fused_ok(1024) == 1 and _lib.load().pccx_ae_encode_b3_fused_ok(1024) == 0
+    ae = _seeded_ae(1024, 512)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((rng.random((2, 1024, 3)).astype(np.float32) - 0.5)).cuda()
+    raw0, lat0, q0 = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
+    a = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    assert np.abs(raw0.cpu().numpy() - a[0].cpu().numpy()).max() <= 2e-5 * max(1.0, float(raw0.abs().max()))
+    assert np.abs(lat0.cpu().numpy() - a[1].cpu().numpy()).max() <= 5e-6
+    _symbols_agree(a[2].cpu().numpy(), lat0.cpu().numpy(), q0.cpu().numpy())
+    monkeypatch.setenv("PCCX_ENC_H2_NT", "1")
+    b = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    monkeypatch.delenv("PCCX_ENC_H2_NT", raising=False)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    ae2 = _seeded_ae(K, k)
+    x2 = torch.from_numpy((rng.random((3, K, 3)).astype(np.float32) - 0.5)).cuda()
+    c = ae2.encode(x2, sa_matmul="f16x2", pn_matmul="f16x2", fused=False)
+    e = ae2.encode(x2, sa_matmul="bf16x3", pn_matmul="bf16x3", fused=False)
+    assert all(torch.equal(u, v) for u, v in zip(c, e))
+
+
 def test_every_mode_against_the_float64_oracle(nets):
     """How far each arithmetic is from the TRUE result: the oracle's modules evaluated in float64 on the same fp32 inputs and weights.
     The exact-fp32 MFMA kernels are themselves ~1e-6 away (fp32 accumulation); the split-operand modes must not be further than
