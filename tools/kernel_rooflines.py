@@ -25,6 +25,7 @@ from pccx import models, ops, synth  # noqa: E402
 HBM_PEAK = 8000.0          # GB/s
 MFMA_F32_PEAK = 157.3      # TFLOP/s
 MFMA_B3_PEAK = 16 * 157.3 / 6   # fp32-equivalent TFLOP/s of the bf16x3 arithmetic: bf16 dense peak / six products
+MFMA_H2_PEAK = 16 * 157.3 / 3   # ... of the f16x2 arithmetic: fp16 dense peak (= bf16's) / three products
 VALU_F32_PEAK = 78.6       # TFLOP/s of non-fused packed fp32 (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 
 
@@ -112,7 +113,7 @@ def main():
     ae.pack(dev)
     prob.pack(dev)
     pt = patches.reshape(B * S, K, 3)
-    for mode, peak in (("f32", MFMA_F32_PEAK), ("bf16x3", MFMA_B3_PEAK)):
+    for mode, peak in (("f32", MFMA_F32_PEAK), ("bf16x3", MFMA_B3_PEAK), ("f16x2", MFMA_H2_PEAK)):
         for _ in range(2):
             ae.encode(pt, sa_matmul=mode, pn_matmul=mode)
         t = ops.StageTimer()
