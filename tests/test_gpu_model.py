@@ -432,6 +432,41 @@ def test_f16x2_two_tile_pointnet_equals_one_tile_form_bit_for_bit(Kx, P, monkeyp
         assert torch.equal(u, v) and torch.equal(u, w_)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_f16x2_over_randomly_scaled_weights(seed):
+    """The operand scales come from interval bounds of whatever weights are packed.  Models whose layers are rescaled at random (each
+    weight tensor by 2^[-3, 3], each bias by 0 ... 8, one layer's weights made sparse) must stay finite and agree with the exact-fp32
+    kernels to the usual relative bars -- no layer may overflow fp16 or lose its low piece whatever the weights' magnitudes."""
+    rng = np.random.default_rng(100 + seed)
+    ae = models.AE(K, k, d, L)
+    sd = ref_model.seeded_state_dict(ae, synth.AE_SEED + seed, last_gain=synth.AE_LAST_GAIN)
+    for n in list(sd):
+        if n.endswith("weight"):
+            sd[n] = sd[n] * float(np.exp2(rng.uniform(-3, 3)))
+        elif n.endswith("bias"):
+            sd[n] = sd[n] * float(rng.uniform(0, 8))
+    sp = sd["pn.mlp_Modules.2.0.weight"]
+    sd["pn.mlp_Modules.2.0.weight"] = sp * torch.from_numpy((rng.random(tuple(sp.shape)) < 0.1).astype(np.float32))
+    ae.load_state_dict(sd)
+    ae.pack("cuda")
+    x = torch.from_numpy((rng.random((40, K, 3)).astype(np.float32) - 0.5) * np.exp2(rng.integers(-4, 5, size=(40, 1, 1))).astype(np.float32)).cuda()
+    raw0, _, _ = ae.encode(x, sa_matmul="f32", pn_matmul="f32")
+    raw1, _, _ = ae.encode(x, sa_matmul="f16x2", pn_matmul="f16x2")
+    raw3, _, _ = ae.encode(x, sa_matmul="bf16x3", pn_matmul="bf16x3")
+    assert torch.isfinite(raw0).all() and torch.isfinite(raw1).all()
+    scale = max(1e-30, float(raw0.abs().max()))
+    e1, e3 = float((raw0 - raw1).abs().max()) / scale, float((raw0 - raw3).abs().max()) / scale
+    assert e1 <= 2e-5 and e1 <= max(2e-6, 4.0 * e3), (e1, e3, scale)
+    lq = torch.from_numpy(rng.integers(-3, 4, size=(40, d)).astype(np.float32)).cuda()
+    a = ae.decode(lq, matmul="f32")
+    b = ae.decode(lq, matmul="f16x2")
+    c = ae.decode(lq, matmul="bf16x3")
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    dscale = max(1e-30, float(a.abs().max()))
+    d1, d3 = float((a - b).abs().max()) / dscale, float((a - c).abs().max()) / dscale
+    assert d1 <= 2e-6 * max(1.0, 1.0 / dscale) and d1 <= max(1e-6, 4.0 * d3), (d1, d3, dscale)
+
+
 def test_f16x2_at_the_largest_patch_and_without_the_fused_kernel(monkeypatch):
     """K = 1024: the f16x2 fused encoder still holds the patch (two fp16 weight planes leave the LDS the bf16x3 kernel lacks there):
     same bars against the exact-fp32 kernels as at K = 256, and its two forms agree bit for bit.  fused=False (ae.sa / ae.pn have no f16x2
