@@ -492,6 +492,40 @@ def test_f16x2_at_the_largest_patch_and_without_the_fused_kernel(monkeypatch):
     assert all(torch.equal(u, v) for u, v in zip(c, e))
 
 
+def test_integration_stub_of_the_f16x2_encoder(nets):
+    """INTEGRATION.md, Option B: the ctypes stub a maintainer adds on the reference side for the batched analysis transform -- raw
+    C ABI, weights packed on the host from state_dict tensors -- gives exactly what the host layer gives."""
+    import ctypes
+    from pccx import _lib
+    ae = nets[0]
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    _P = ctypes.c_void_p
+    lib.pccx_last_error.restype = ctypes.c_char_p
+
+    def _check(rc):
+        if rc:
+            raise RuntimeError(lib.pccx_last_error().decode())
+    sd = ae.state_dict()
+    w = lambda key: sd[key].reshape(sd[key].shape[0], -1).float().contiguous().cpu()
+    keys = ["sa.conv0", "sa.conv1", "sa.conv2", "pn.mlp_Modules.0.0", "pn.mlp_Modules.1.0", "pn.mlp_Modules.2.0", "pn.mlp_Modules.3.0"]
+    host = [t for key in keys for t in (w(key + ".weight"), sd[key + ".bias"].float().contiguous().cpu())]
+    lib.pccx_ae_encoder_blob_floats.restype = lib.pccx_ae_encoder_h2_blob_floats.restype = ctypes.c_size_t
+    enc = torch.zeros(lib.pccx_ae_encoder_blob_floats())
+    _check(lib.pccx_pack_ae_encoder(*[_P(t.data_ptr()) for t in host], d, _P(enc.data_ptr())))
+    h2 = torch.zeros(lib.pccx_ae_encoder_h2_blob_floats())
+    _check(lib.pccx_pack_ae_encoder_h2(*[_P(t.data_ptr()) for t in host], d, _P(h2.data_ptr())))
+    enc, h2 = enc.cuda(), h2.cuda()
+    patches = torch.from_numpy(synth.patch_batch(K)).cuda().contiguous()
+    P = patches.shape[0]
+    raw, lat, q = (torch.empty(P, d, device="cuda") for _ in range(3))
+    lib.pccx_ae_encode_h2_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.empty(lib.pccx_ae_encode_h2_workspace_bytes(P, K), dtype=torch.uint8, device="cuda")
+    _check(lib.pccx_ae_encode_h2_ws(_P(patches.data_ptr()), P, K, _P(enc.data_ptr()), _P(h2.data_ptr()), d, L, _P(raw.data_ptr()), _P(lat.data_ptr()),
+                                    _P(q.data_ptr()), _P(ws.data_ptr()), _P(torch.cuda.current_stream().cuda_stream)))
+    want = ae.encode(patches, sa_matmul="f16x2", pn_matmul="f16x2")
+    assert torch.equal(raw, want[0]) and torch.equal(lat, want[1]) and torch.equal(q, want[2])
+
+
 def test_every_mode_against_the_float64_oracle(nets):
     """How far each arithmetic is from the TRUE result: the oracle's modules evaluated in float64 on the same fp32 inputs and weights.
     The exact-fp32 MFMA kernels are themselves ~1e-6 away (fp32 accumulation); the split-operand modes must not be further than
