@@ -20,7 +20,9 @@ Prints ONE JSON line on rank 0.  Besides the driver's contract it carries
   roofline     -- the dominant kernel: algorithmic FLOPs per launch / its HIP-event duration against the
                   matrix-core peak of the arithmetic used (MI355X_MICROARCH.md: fp32 matrix 157.3 TFLOP/s;
                   bf16 dense 16x that, / 6 products for the three-way split = 419.5 fp32-equivalent);
-  f32          -- the same step with every product formed by the exact-fp32 MFMA (its own value + roofline);
+  f32, bf16x3  -- the same step in the other arithmetic modes, each with its own host-to-host value, resident value, window checks,
+                  stage table and roofline; ``precision_matched`` names the leg whose products are as wide as the reference's (f32);
+  full_mode    -- the same clouds with octree_mode="full" (the decode that reconstructs all 64 centres) in the default arithmetic;
   cpu_baseline -- the CPU restatement of the reference loop (oracle/ref_pipeline.py), timed on this node's host
                   cores on a bounded sample, with its bpp / D1-PSNR and a 1-thread figure, rank 0 at N=1 only.
 """
@@ -409,10 +411,15 @@ def bench_ipdae(args, rk):
     P = B * S_PATCH
     sync = torch.cuda.synchronize
     modes = [args.matmul] + [m for m in ("f32", "bf16x3", "f16x2") if m != args.matmul and not args.one_mode]
-    res_by_mode = {}
-    for mode in modes:
-        cd, _, _ = build_codec(rk, mode, args.octree_mode)
-        S = S_PATCH
+    from pccx import models as _models                                            # sizes of the packed stream buffer (codec.packed_layout)
+    S = S_PATCH
+    s_stride, p_cap = (ops.octree_bits_capacity(S) + 7) // 8, _models.range_cap(S * D_LAT)
+    row = codec.packed_layout(1, s_stride, p_cap)[-1]                             # bytes per cloud
+    nb_ = min(B, int(base.shape[0]))                # the unturned base shapes = the CPU leg's first clouds (cpu_baseline.same_clouds_as_gpu)
+
+    def measure(cd, with_files=False):
+        """Both legs of one (arithmetic mode, octree mode): resident (per-stage events) and host-to-host (the reference's window)."""
+        keep = {}
 
         # ---- resident leg: one stream, everything stays in HBM, per-stage events -------------------------------
         def step_resident(i):
@@ -423,106 +430,114 @@ def bench_ipdae(args, rk):
         sync()
         timer = ops.StageTimer()
         ops.set_timer(timer)
-        keep = {}
         dt_res = timed(rk, lambda i: keep.__setitem__("r", step_resident(i)), args.steps, sync)
         ops.set_timer(None)
         comp, out = keep["r"]
         stages = {k: (ms / n, n) for k, (ms, n) in timer.totals_ms().items()}
         r = {"dt_res": dt_res, "stages": stages, "bits": float(comp.bits().sum()), "psnr_sum": float(codec.d1_psnr(clouds, out).sum()),
              "chamfer_sum": float(codec.normalized_chamfer(clouds, out).sum())}
-        nb_ = min(B, int(base.shape[0]))            # the unturned base shapes = the CPU leg's first clouds (cpu_baseline.same_clouds_as_gpu)
         r["base_shapes"] = {"clouds": nb_, "bpp": float(comp.bits()[:nb_].sum()) / (nb_ * N_POINTS),
                             "d1_psnr_db": float(codec.d1_psnr(clouds[:nb_], out[:nb_]).sum()) / nb_}
 
         # ---- host-to-host leg (the reference's window): two streams, pinned double buffers ---------------------
-        if mode == args.matmul:
-            from pccx import models as _models                                    # sizes of the packed stream buffer (codec.packed_layout)
-            s_stride, p_cap = (ops.octree_bits_capacity(S) + 7) // 8, _models.range_cap(S * D_LAT)
-            row = codec.packed_layout(1, s_stride, p_cap)[-1]                     # bytes per cloud
-            copy_stream = torch.cuda.Stream(device=dev)
-            main_stream = torch.cuda.current_stream()
-            pin_comp = [torch.empty(row * B, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            pin_out = [torch.empty(B, N_POINTS, 3, dtype=torch.float32).pin_memory() for _ in range(2)]
-            pending = []
+        copy_stream = torch.cuda.Stream(device=dev)
+        main_stream = torch.cuda.current_stream()
+        pin_comp = [torch.empty(row * B, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        pin_out = [torch.empty(B, N_POINTS, 3, dtype=torch.float32).pin_memory() for _ in range(2)]
+        pending = []
 
-            def finish(up, ready, j):
-                """decompress(step) from the host bytes that came back on the copy stream; its XYZ goes to the host there too."""
-                main_stream.wait_event(ready)
-                o = cd.decompress(codec.Compressed.from_packed(up, B, s_stride, p_cap, N_POINTS), S=S)
-                done = torch.cuda.Event()
-                done.record(main_stream)
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(done)
-                    pin_out[j].copy_(o, non_blocking=True)                    # reconstructed XYZ on the host
-                o.record_stream(copy_stream)
+        def finish(up, ready, j):
+            """decompress(step) from the host bytes that came back on the copy stream; its XYZ goes to the host there too."""
+            main_stream.wait_event(ready)
+            o = cd.decompress(codec.Compressed.from_packed(up, B, s_stride, p_cap, N_POINTS), S=S)
+            done = torch.cuda.Event()
+            done.record(main_stream)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                pin_out[j].copy_(o, non_blocking=True)                    # reconstructed XYZ on the host
+            o.record_stream(copy_stream)
 
-            def step_host(i, last=None):
-                # ALL kernels stay on the one compute stream, in the order compress(i), decompress(i-1): their durations are what
-                # the resident leg measures.  Only the copies run beside them, on the copy stream, ordered by events:
-                #   compress(i) -> [D2H of the packed streams = the three files' bytes on the host, then the same bytes H2D]
-                #   -> decompress(i) one step later -> [D2H of the XYZ].
-                j = i % 2
-                c = cd.compress(clouds, starts)
-                ev = torch.cuda.Event()
-                ev.record(main_stream)
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(ev)
-                    pin_comp[j].copy_(c.packed, non_blocking=True)            # ONE D2H per batch
-                    up = pin_comp[j].to(dev, non_blocking=True)               # decompress starts from the host bytes
-                    ready = torch.cuda.Event()
-                    ready.record(copy_stream)
-                c.packed.record_stream(copy_stream)
-                up.record_stream(main_stream)
-                if pending:
-                    finish(*pending.pop())
-                pending.append((up, ready, j))
-                if i == (args.steps if last is None else last) - 1:           # the timed region ends with the last step's decompress
-                    finish(*pending.pop())
-            copy_stream.wait_stream(main_stream)
-            nw = max(args.warmup, 2)
-            for i in range(nw):
-                step_host(i, last=nw)
-            sync()
-            r["dt_host"] = timed(rk, step_host, args.steps, sync)
-            last = (args.steps - 1) % 2
-            r["host_equals_resident"] = bool(torch.equal(pin_out[last], out.cpu()))
-            hc = codec.Compressed.from_packed(pin_comp[last], B, s_stride, p_cap, N_POINTS)
-            r["host_bytes_equal_resident"] = bool(torch.equal(hc.s_nbytes, comp.s_nbytes.cpu()) and torch.equal(hc.p_nbytes, comp.p_nbytes.cpu()))
-            r["d2h_bytes_per_step"] = row * B + B * N_POINTS * 12
-            del copy_stream, pin_comp, pin_out
-            if args.with_files:
-                # ---- the window WITH the file system in it (compress.py:139-152 writes the three files inside its timer,
-                # decompress.py:80-91 reads them back inside its own): files on tmpfs, plain Python I/O as the reference does,
-                # synchronous (a secondary figure: 3 x B small files per step are the host's work, not the GPU's)
-                import shutil
-                import tempfile
-                tmp = tempfile.mkdtemp(prefix="pccx_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-                try:
-                    def step_files(i):
-                        c = cd.compress(clouds, starts)
-                        for b_ in range(B):
-                            for ext, blob in zip((".s.bin", ".p.bin", ".c.bin"), c.files(b_)):
-                                with open(os.path.join(tmp, f"{b_:05d}{ext}"), "wb") as f:
-                                    f.write(blob)
-                        rd = lambda b_, ext: open(os.path.join(tmp, f"{b_:05d}{ext}"), "rb").read()
-                        sb = np.zeros((B, s_stride), dtype=np.uint8)
-                        pb = np.zeros((B, p_cap), dtype=np.uint8)
-                        sn, pn, cc = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4), np.float32)
-                        for b_ in range(B):
-                            s_, p_, c_ = rd(b_, ".s.bin"), rd(b_, ".p.bin"), rd(b_, ".c.bin")
-                            sb[b_, :len(s_)] = np.frombuffer(s_, np.uint8); sn[b_] = len(s_)
-                            pb[b_, :len(p_)] = np.frombuffer(p_, np.uint8); pn[b_] = len(p_)
-                            cc[b_] = np.frombuffer(c_, np.float32)
-                        up = codec.Compressed(torch.from_numpy(sb).to(dev), torch.from_numpy(sn).to(dev), torch.from_numpy(pb).to(dev),
-                                              torch.from_numpy(pn).to(dev), torch.from_numpy(cc).to(dev), N_POINTS)
-                        keep["files_out"] = cd.decompress(up, S=S).cpu()
-                    step_files(0)
-                    nf = max(2, min(args.steps, 3))
-                    r["dt_files"], r["files_steps"] = timed(rk, step_files, nf, sync), nf
-                    r["files_equal_resident"] = bool(torch.equal(keep["files_out"], out.cpu()))
-                finally:
-                    shutil.rmtree(tmp, ignore_errors=True)
-        res_by_mode[mode] = r
+        def step_host(i, last=None):
+            # ALL kernels stay on the one compute stream, in the order compress(i), decompress(i-1): their durations are what
+            # the resident leg measures.  Only the copies run beside them, on the copy stream, ordered by events:
+            #   compress(i) -> [D2H of the packed streams = the three files' bytes on the host, then the same bytes H2D]
+            #   -> decompress(i) one step later -> [D2H of the XYZ].
+            j = i % 2
+            c = cd.compress(clouds, starts)
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev)
+                pin_comp[j].copy_(c.packed, non_blocking=True)            # ONE D2H per batch
+                up = pin_comp[j].to(dev, non_blocking=True)               # decompress starts from the host bytes
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            c.packed.record_stream(copy_stream)
+            up.record_stream(main_stream)
+            if pending:
+                finish(*pending.pop())
+            pending.append((up, ready, j))
+            if i == (args.steps if last is None else last) - 1:           # the timed region ends with the last step's decompress
+                finish(*pending.pop())
+        copy_stream.wait_stream(main_stream)
+        nw = max(args.warmup, 2)
+        for i in range(nw):
+            step_host(i, last=nw)
+        sync()
+        r["dt_host"] = timed(rk, step_host, args.steps, sync)
+        last = (args.steps - 1) % 2
+        r["host_equals_resident"] = bool(torch.equal(pin_out[last], out.cpu()))
+        hc = codec.Compressed.from_packed(pin_comp[last], B, s_stride, p_cap, N_POINTS)
+        r["host_bytes_equal_resident"] = bool(torch.equal(hc.s_nbytes, comp.s_nbytes.cpu()) and torch.equal(hc.p_nbytes, comp.p_nbytes.cpu()))
+        r["d2h_bytes_per_step"] = row * B + B * N_POINTS * 12
+        del copy_stream, pin_comp, pin_out
+        if with_files:
+            # ---- the window WITH the file system in it (compress.py:139-152 writes the three files inside its timer,
+            # decompress.py:80-91 reads them back inside its own): files on tmpfs, plain Python I/O as the reference does,
+            # synchronous (a secondary figure: 3 x B small files per step are the host's work, not the GPU's)
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="pccx_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                def step_files(i):
+                    c = cd.compress(clouds, starts)
+                    for b_ in range(B):
+                        for ext, blob in zip((".s.bin", ".p.bin", ".c.bin"), c.files(b_)):
+                            with open(os.path.join(tmp, f"{b_:05d}{ext}"), "wb") as f:
+                                f.write(blob)
+                    rd = lambda b_, ext: open(os.path.join(tmp, f"{b_:05d}{ext}"), "rb").read()
+                    sb = np.zeros((B, s_stride), dtype=np.uint8)
+                    pb = np.zeros((B, p_cap), dtype=np.uint8)
+                    sn, pn, cc = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4), np.float32)
+                    for b_ in range(B):
+                        s_, p_, c_ = rd(b_, ".s.bin"), rd(b_, ".p.bin"), rd(b_, ".c.bin")
+                        sb[b_, :len(s_)] = np.frombuffer(s_, np.uint8); sn[b_] = len(s_)
+                        pb[b_, :len(p_)] = np.frombuffer(p_, np.uint8); pn[b_] = len(p_)
+                        cc[b_] = np.frombuffer(c_, np.float32)
+                    up = codec.Compressed(torch.from_numpy(sb).to(dev), torch.from_numpy(sn).to(dev), torch.from_numpy(pb).to(dev),
+                                          torch.from_numpy(pn).to(dev), torch.from_numpy(cc).to(dev), N_POINTS)
+                    keep["files_out"] = cd.decompress(up, S=S).cpu()
+                step_files(0)
+                nf = max(2, min(args.steps, 3))
+                r["dt_files"], r["files_steps"] = timed(rk, step_files, nf, sync), nf
+                r["files_equal_resident"] = bool(torch.equal(keep["files_out"], out.cpu()))
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        return r
+
+    res_by_mode = {}
+    for mode in modes:
+        cd, _, _ = build_codec(rk, mode, args.octree_mode)
+        res_by_mode[mode] = measure(cd, with_files=args.with_files and mode == args.matmul)
+        del cd
+        torch.cuda.empty_cache()
+    # the same clouds in the OTHER octree mode, default arithmetic: "reference" reproduces octree_np.decode as written (<= 8 distinct
+    # centres per cloud, SURVEY Appendix B), "full" is the level-by-level decode under which the codec actually reconstructs the cloud
+    other_mode = None if args.one_mode else ("full" if args.octree_mode == "reference" else "reference")
+    other = None
+    if other_mode:
+        cd, _, _ = build_codec(rk, args.matmul, other_mode)
+        other = measure(cd)
         del cd
         torch.cuda.empty_cache()
 
@@ -551,14 +566,32 @@ def bench_ipdae(args, rk):
             "bpp": summ["bpp"], "d1_psnr_db": summ["d1_psnr_db"], "chamfer": summ["chamfer"], "summary_files": summ["files"],
             "base_shapes": main["base_shapes"],
         }
-        for mode, r in res_by_mode.items():
-            if mode == args.matmul:
-                continue
+        def leg_record(r, mode, octree_mode):
+            """a secondary leg in full: host-to-host value + resident value, its own window checks, stage table and roofline"""
             rf2, ps2, tfl2 = roofline_of(r["stages"], args.steps, P, mode, B)
-            res["f32" if mode == "f32" else mode] = {
-                "value_resident": rk.world * pts / r["dt_res"], "ms_per_step_resident": 1e3 * r["dt_res"] / args.steps,
-                "dtype": mode, "roofline": rf2, "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(ps2.items(), key=lambda kv: -kv[1])},
-                "bpp": r["bits"] / (B * N_POINTS), "d1_psnr_db": r["psnr_sum"] / B}
+            return {"value": rk.world * pts / r["dt_host"], "unit": "points/s", "ms_per_step": 1e3 * r["dt_host"] / args.steps,
+                    "window": "host-to-host (as the top-level value)",
+                    "value_resident": rk.world * pts / r["dt_res"], "ms_per_step_resident": 1e3 * r["dt_res"] / args.steps,
+                    "host_window_checks": {k: r[k] for k in ("host_equals_resident", "host_bytes_equal_resident", "d2h_bytes_per_step")},
+                    "dtype": MODE_DTYPE[mode], "matmul": mode, "octree_mode": octree_mode, "roofline": rf2,
+                    "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(ps2.items(), key=lambda kv: -kv[1])},
+                    "mfma_stage_tflops": tfl2,
+                    "bpp": r["bits"] / (B * N_POINTS), "d1_psnr_db": r["psnr_sum"] / B, "chamfer": r["chamfer_sum"] / B,
+                    "base_shapes": r["base_shapes"]}
+        for mode, r in res_by_mode.items():
+            if mode != args.matmul:
+                res[mode] = leg_record(r, mode, args.octree_mode)
+        # which leg forms every product at the reference's own width (torch fp32): the exact-fp32 MFMA.  The split modes carry 22-24 operand
+        # bits and are as close to the float64 oracle as it is (tests/test_gpu_model.py), but they are emulation on narrower matrix cores.
+        res["precision_matched"] = "f32" if ("f32" in res_by_mode) else None
+        if args.matmul == "f32":
+            res["precision_matched"] = "value (this line's top-level figures are the exact-fp32 leg)"
+        if other is not None:
+            rec = leg_record(other, args.matmul, other_mode)
+            rec["note"] = ("the same %d clouds, octree mode '%s'" % (B, other_mode)) + (
+                ": the level-by-level decode (every one of the 64 centres distinct), i.e. the mode in which the codec reconstructs the cloud; "
+                "the top-level line is the reference's decode as written (octree_np.py:47-112: <= 8 distinct centres per cloud)" if other_mode == "full" else "")
+            res[other_mode + "_mode"] = rec
         if "dt_files" in main:
             res["with_files"] = {"value": rk.world * B * N_POINTS * main["files_steps"] / main["dt_files"], "unit": "points/s",
                                  "ms_per_step": 1e3 * main["dt_files"] / main["files_steps"], "steps": main["files_steps"],
