@@ -55,6 +55,9 @@ static __global__ void pccx_zero_kernel(unsigned *__restrict__ p, size_t n4)
 }
 static inline hipError_t pccx_zero_async(void *p, size_t bytes, hipStream_t st)
 {
+#ifdef PCCX_ZERO_WITH_MEMSET       // experiment builds only (tools/experiments/r4/graph_memset_probe.py): the round-2 form, memset NODES in the captured step
+    return hipMemsetAsync(p, 0, bytes, st);
+#endif
     const size_t n4 = bytes / 4;
     if (n4 == 0) return hipSuccess;
     size_t blocks = (n4 + 255) / 256;

@@ -90,8 +90,6 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const WStreamT<CH, NB> ws{hb + DEC_H2_G_W(k) + (size_t)p * DEC_H2_STREAM_CHUNKS * DEC_H2_CHUNK * 256, swt, DEC_H2_STREAM_CHUNKS, lane, wu, false};
     ws.prologue();
-    const float rho0 = hb[DEC_H2_META + H2D_RHO0], sig_q = hb[DEC_H2_META + H2D_SIG_Q], rho1 = hb[DEC_H2_META + H2D_RHO1];
-    const float rho2 = hb[DEC_H2_META + H2D_RHO2], rho3 = hb[DEC_H2_META + H2D_RHO3], inv_out = hb[DEC_H2_META + H2D_INV_OUT];
 
     int tq[NT];
     float sn[NT];
@@ -185,6 +183,28 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
     }
     // ---- inv_mlp as an f16x2 chain on registers, two tiles at a time: channels 0..127 = relu(inv_pool.4) of point p, 128..143 = latent.
     // Pair pr reads the tail's fragments from their pr-th copy in the stream, which simply continues.
+    // Everything the tail needs per lane (tile and patch indices, bias / latent / output addresses, the patch scales) is derived HERE from a
+    // laundered thread id and re-read from L2, not carried through the GEMM loop: the loop holds 224 registers of accumulators and operand
+    // planes, and values computed in the prologue for the tail were spilled around it (41 VGPRs, 152 B of scratch per lane, round 3).
+    int lane_t = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_t));
+    const int g_t = lane_t >> 4, n_t = lane_t & 15;
+    const int tile0_t = blk * 4 * NT + NT * wu;
+    const float *meta = hb + DEC_H2_META;                      // the six layer multipliers: wave-uniform, read after the loop, kept in SGPRs
+    asm volatile("" : "+s"(meta));
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+    const float rho0 = uni(meta[H2D_RHO0]), sig_q = uni(meta[H2D_SIG_Q]), rho1 = uni(meta[H2D_RHO1]);
+    const float rho2 = uni(meta[H2D_RHO2]), rho3 = uni(meta[H2D_RHO3]), inv_out = uni(meta[H2D_INV_OUT]);
+    float sn_t[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int tt = tile0_t + nt < ntiles ? tile0_t + nt : ntiles - 1;
+        sn_t[nt] = pscale[tt * 16 + n_t];
+    }
+    const WStreamT<CH, NB> ws_t{ws.g, swt, DEC_H2_STREAM_CHUNKS, lane_t, wu, false};       // the same ring, addressed from the tail's lane id
+    // bias rows: wave-uniform base + an UNSIGNED 32-bit lane offset, so the loads take the scalar-base form and no 64-bit address is held per lane
+    const unsigned goff = 16u * (unsigned)g_t;
+    auto bias4 = [&](int at) { return *(const f32x4 *)((const char *)(hb + at) + goff); };
     int f = DEC_H2_GEMM_FRAGS;
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
@@ -196,18 +216,18 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
             for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) h2_split8(relu4(acc[pr][nt][2 * t]), relu4(acc[pr][nt][2 * t + 1]), rho0, i0[nt][t]);
-                const int patch = (tile0 + 2 * pr + nt) * 16 + n;
+                const int patch = (tile0_t + 2 * pr + nt) * 16 + n_t;
                 f32x4 lat;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lat[r] = (patch < P && 4 * g + r < d) ? latent_q[(size_t)patch * d + 4 * g + r] : 0.f;
-                h2_split8(lat, zero, sn[2 * pr + nt] * sig_q, i0[nt][4]);
+                for (int r = 0; r < 4; ++r) lat[r] = (patch < P && 4 * g_t + r < d) ? latent_q[(size_t)patch * d + 4 * g_t + r] : 0.f;
+                h2_split8(lat, zero, sn_t[2 * pr + nt] * sig_q, i0[nt][4]);
             }
             f32x4 m0[2][8];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B0 + 16 * mt + 4 * g) * sn[2 * pr + nt];
-            dense_h2_stream<5, 8, 2>(ws, f, i0, m0);
+                for (int mt = 0; mt < 8; ++mt) m0[nt][mt] = bias4(DEC_H2_M_B0 + 16 * mt) * sn_t[2 * pr + nt];
+            dense_h2_stream<5, 8, 2>(ws_t, f, i0, m0);
             f16x8 i1[2][4][2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -217,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B1 + 16 * mt + 4 * g) * sn[2 * pr + nt];
-            dense_h2_stream<4, 4, 2>(ws, f, i1, m1);
+                for (int mt = 0; mt < 4; ++mt) m1[nt][mt] = bias4(DEC_H2_M_B1 + 16 * mt) * sn_t[2 * pr + nt];
+            dense_h2_stream<4, 4, 2>(ws_t, f, i1, m1);
             f16x8 i2[2][2][2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -228,22 +248,22 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = *(const f32x4 *)(hb + DEC_H2_M_B2 + 16 * mt + 4 * g) * sn[2 * pr + nt];
-            dense_h2_stream<2, 2, 2>(ws, f, i2, m2);
+                for (int mt = 0; mt < 2; ++mt) m2[nt][mt] = bias4(DEC_H2_M_B2 + 16 * mt) * sn_t[2 * pr + nt];
+            dense_h2_stream<2, 2, 2>(ws_t, f, i2, m2);
             f16x8 i3[2][1][2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) h2_split8(relu4(m2[nt][0]), relu4(m2[nt][1]), rho3, i3[nt][0]);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) m3[nt][0] = *(const f32x4 *)(hb + DEC_H2_M_B3 + 4 * g) * sn[2 * pr + nt];
-            dense_h2_stream<1, 1, 2>(ws, f, i3, m3);          // last layer: no ReLU (AE.py:27)
+            for (int nt = 0; nt < 2; ++nt) m3[nt][0] = bias4(DEC_H2_M_B3) * sn_t[2 * pr + nt];
+            dense_h2_stream<1, 1, 2>(ws_t, f, i3, m3);          // last layer: no ReLU (AE.py:27)
         }
-        // ---- epilogue of the pair: rows 0..2 of the last tile (g == 0, r = 0..2) are x,y,z of (patch, point p)
-        if (g == 0) {
+        // ---- epilogue of the pair: rows 0..2 of the last tile (g_t == 0, r = 0..2) are x,y,z of (patch, point p)
+        if (g_t == 0) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int tile = tile0 + 2 * pr + nt, patch = tile * 16 + n;
+                const int tile = tile0_t + 2 * pr + nt, patch = tile * 16 + n_t;
                 if (tile < ntiles && patch < P) {
-                    const float un = __fmul_rn(inv_out, __fdiv_rn(1.0f, sn[2 * pr + nt]));       // undo the operand scales (exact)
+                    const float un = __fmul_rn(inv_out, __fdiv_rn(1.0f, sn_t[2 * pr + nt]));       // undo the operand scales (exact)
                     float v[3] = {__fmul_rn(m3[nt][0][0], un), __fmul_rn(m3[nt][0][1], un), __fmul_rn(m3[nt][0][2], un)};
                     if (patches_out) {
                         float *o = patches_out + ((size_t)patch * k + p) * 3;       // new_xyz.transpose(2,1)

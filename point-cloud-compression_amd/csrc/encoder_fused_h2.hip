@@ -82,20 +82,26 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
     int *sa_next = (int *)(region + fh_region_bytes() + 8 * 16 * 4);
     unsigned *srmax = (unsigned *)(sa_next + 8);                        // bits of the patch's largest |coordinate|
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ntiles = K >> 4;
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    const float rho0 = h2[ENC_H2_META + H2E_RHO0], rho1 = h2[ENC_H2_META + H2E_RHO1], inv2 = h2[ENC_H2_META + H2E_INV2];
-    const float rho_in = h2[ENC_H2_META + H2E_RHO_IN], rho_p1 = h2[ENC_H2_META + H2E_RHO_P1], rho_p2 = h2[ENC_H2_META + H2E_RHO_P2];
-    const float rho_p3 = h2[ENC_H2_META + H2E_RHO_P3], inv_out = h2[ENC_H2_META + H2E_INV_OUT];
-
+    const int wu = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // Nothing per-lane or per-layer is carried from here through the patch loop: the hardware thread id dies after this block -- every phase
+    // below takes its lane id from mbcnt, laundered, and the wave id from `wu` -- and the eight layer multipliers are read (scalar loads
+    // through an opaque pointer) at the head of the phase that uses them.  Round 3 held all of that across the loop: 21 SGPRs and 5 VGPRs spilled.
+    auto fresh_lane = []() {
+        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    auto meta = [&](int i) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(opaque_uniform(h2)[ENC_H2_META + i]))); };
     {   // the SetAbstraction weight planes, once per workgroup
+        const int tid0 = threadIdx.x;
         const f32x4 *gw = (const f32x4 *)(h2 + ENC_H2_SA_W);
-        for (int i = tid; i < (ENC_H2_SA_W1_FRAGS + ENC_H2_SA_W2_FRAGS) * 64; i += 512) sw1[i] = gw[i];
+        for (int i = tid0; i < (ENC_H2_SA_W1_FRAGS + ENC_H2_SA_W2_FRAGS) * 64; i += 512) sw1[i] = gw[i];
+        if (tid0 == 0) *srmax = 0u;
     }
-    if (tid == 0) *srmax = 0u;
     __syncthreads();
   for (size_t P = blockIdx.x; P < (size_t)npatches; P += gridDim.x) {
+    const int lane = fresh_lane(), tid = wu * 64 + lane;
     const float *xp = x + P * (size_t)K * 3;
     {   // the patch's power-of-two normalisation
         unsigned m = 0u;
@@ -138,7 +144,6 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (lane < 16) smax[wu][lane] = -INFINITY;            // running channel maximum of this wave, kept in LDS between passes
-    const int lane0 = lane;
 
     // ---- SetAbstraction of pass `it` (128 points) + hand-over of this wave's tile as PointNet's B operand planes
     auto sa_and_handover = [&](int it, f16x8 (&i0p)[1][5][2], bool &valid) {
@@ -147,9 +152,9 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
         const int p0 = (valid ? tile : 0) * 16;           // an idle wave recomputes tile 0 and discards it
         // each phase derives its lane indices from a freshly laundered lane id (encoder_fused.hip: keeps the phases' address
         // registers from being carried through each other)
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
+        int lane = fresh_lane();
         int g = lane >> 4, n = lane & 15;
+        const float rho0 = meta(H2E_RHO0), rho1 = meta(H2E_RHO1), inv2 = meta(H2E_INV2);
         const float w0a = blob[ENC_SA_W0B0 + 4 * n + g], w0b = blob[ENC_SA_W0B0 + 4 * (16 + n) + g];
 
         // SetAbstraction for the pass's points, two per unit, units taken from the LDS counter
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
         const int units = ((K - pass_base < 128 ? K - pass_base : 128) + 1) >> 1;
         for (;;) {
             int unit = 0;
-            if (lane0 == 0) unit = atomicAdd(&sa_next[it & 7], 1);
+            if (lane == 0) unit = atomicAdd(&sa_next[it & 7], 1);
             unit = __builtin_amdgcn_readfirstlane(unit);
             if (unit >= units) break;
             const int i0 = pass_base + 2 * unit;
@@ -200,10 +205,10 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
 
         __syncthreads();                                  // every row of the pass is staged
         // hand-over: the rows of this wave's tile, read back as PointNet's B operand and split into planes
-        lane = lane0;
-        asm volatile("" : "+v"(lane));
+        lane = fresh_lane();
         g = lane >> 4; n = lane & 15;
         {
+            const float rho_in = meta(H2E_RHO_IN);
             f32x4 in[9];
             const float *stage_t = stage_all + (valid ? p0 - pass_base : 0) * FH_STAGE_STRIDE;   // an idle wave: block 0, discarded
 #pragma unroll
@@ -227,9 +232,9 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
         bool valid;
         sa_and_handover(it, i0p, valid);
         // ---- PointNet pass, ring started cold
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
+        const int lane = fresh_lane();
         const int g = lane >> 4, n = lane & 15;
+        const float rho_p1 = meta(H2E_RHO_P1), rho_p2 = meta(H2E_RHO_P2), rho_p3 = meta(H2E_RHO_P3);
         WStreamT<FH_CHUNK, FH_NB, 8> ws{opaque_uniform(h2) + ENC_H2_PN_STREAM, swt, (PN_H2_STREAM_FRAGS + FH_CHUNK - 1) / FH_CHUNK, lane, wu, false};
         ws.prologue();
         int f = 0;                                        // fragment cursor of this pass (constant-folds)
@@ -294,9 +299,9 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
             bool valid;
             sa_and_handover(2 * rnd + hf, i0p, valid);
             // PointNet layer 0 for this half's tile: the first three chunks of the second stream (80 fragments + padding), ring started cold
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));
+            const int lane = fresh_lane();
             const int g = lane >> 4;
+            const float rho_p1 = meta(H2E_RHO_P1);
             WStreamT<FH_CHUNK, FH_NB, 8> ws0{opaque_uniform(h2) + ENC_H2_PN_STREAM2, swt, PN_H2_S2_L0_FRAGS / FH_CHUNK, lane, wu, false};
             ws0.prologue();
             int f = 0;
@@ -312,9 +317,9 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
             __syncthreads();                              // the region is staging (second half) or the ring of layers 1-3 again
         }
         // ---- PointNet layers 1-3 over both tiles, ring started cold
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
+        const int lane = fresh_lane();
         const int g = lane >> 4, n = lane & 15;
+        const float rho_p2 = meta(H2E_RHO_P2), rho_p3 = meta(H2E_RHO_P3);
         WStreamT<FH_CHUNK, FH_NB, 8> ws{opaque_uniform(h2) + ENC_H2_PN_STREAM2 + (size_t)PN_H2_S2_L0_FRAGS * 256, swt, PN_H2_S2_MAIN_FRAGS / FH_CHUNK, lane, wu, false};
         ws.prologue();
         int f = 0;
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(512, 1) void sa_pn_forward_h2_kernel(const float *_
     }
     __syncthreads();
     if (tid < 16 && tid < d) {
+        const float inv_out = meta(H2E_INV_OUT);
         float m = smax[0][tid];
 #pragma unroll
         for (int k8 = 1; k8 < 8; ++k8) m = fmaxf(m, smax[k8][tid]);                                    // torch.max(points, 2)

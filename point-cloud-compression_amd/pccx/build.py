@@ -13,9 +13,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-OBJ = os.path.join(CSRC, "_obj")
+# PCCX_BUILD_TAG=<tag> (with PCCX_EXTRA_FLAGS) builds an EXPERIMENT variant beside the product: objects in csrc/_obj_<tag>/, library
+# pccx/lib/libpccx_<tag>.so -- never loaded by the package (tools/experiments/ab_lib.sh swaps it in on the GPU box for an A/B run)
+TAG = os.environ.get("PCCX_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + TAG if TAG else ""))
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libpccx.so")
+LIB = os.path.join(LIBDIR, "libpccx" + ("_" + TAG if TAG else "") + ".so")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

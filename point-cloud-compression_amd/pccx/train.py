@@ -423,7 +423,7 @@ class GraphedTrainStep:
     (dist.allreduce_mean_, on the gradients' fixed graph-pool addresses) runs between the two replays on the same stream."""
 
     def __init__(self, model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, loss_type="chamfer", autocast=False, warmup=2,
-                 data_parallel=False):
+                 data_parallel=False, debug_dot=None):
         if loss_type != "chamfer":
             raise _lib.PccxError("GraphedTrainStep: loss_type='chamfer' (what train_pppe_pcd_ae.py:48 builds) is the captured loss; "
                                  "the smooth-L1 backward still reads its upstream gradient on the host")
@@ -444,6 +444,8 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        if debug_dot:                       # hipGraphDebugDotPrint of the captured step (nodes and edges), for diagnostics
+            self.graph.enable_debug_mode()
         if self.data_parallel:
             with torch.cuda.graph(self.graph):
                 self.out = self._fwd_bwd()
@@ -454,6 +456,8 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(self.graph):
                 self.out = self._body()
+        if debug_dot:
+            self.graph.debug_dump(debug_dot)
         self._grads = opt._keep            # the captured gradients: graph-pool tensors at the addresses the table holds
         opt.flush_table()
         # Leave no python handle on the captured iteration: the parameters' .grad are graph-pool tensors the replays own.  Eager
