@@ -66,6 +66,20 @@ PCCX_API int pccx_morton_keys(const float *xyz, int64_t n, const float *lo_host,
  * host round trip, so the block partition of a large cloud can be queued without a synchronisation. */
 PCCX_API int pccx_morton_keys_auto(const float *xyz, int64_t n, int64_t *keys, int32_t *bbox_workspace, void *stream);
 
+/* The block partition of a room-scale cloud (BASELINE configs[3]; the reference has no such path: octree_np.decode hard-codes S = 64,
+ * octree_np.py:100, so a cloud of N points is cut into blocks of 8192).  pccx_sort_keys_u64: STABLE ascending radix sort of the keys IN
+ * PLACE; order (n) int64 = the input position of the key at each sorted position (torch.sort(keys, stable=True).indices).  key_bits:
+ * significant low bits (63 for the Morton keys).  workspace: pccx_sort_keys_workspace_bytes(n) bytes, 16-byte aligned; n < 2^32. */
+PCCX_API size_t pccx_sort_keys_workspace_bytes(int64_t n);
+PCCX_API int pccx_sort_keys_u64(int64_t *keys, int64_t n, int key_bits, int64_t *order, void *workspace, void *stream);
+/* blocks_out (count, block, 3): block b = rows order[(first + b * stride) * block + i], i < block, of pc (n,3); positions >= n repeat
+ * row order[n - 1] (the last block is completed with copies of its final point).  first / stride select a rank's blocks. */
+PCCX_API int pccx_gather_blocks(const float *pc, const int64_t *order, int64_t n, int block, int64_t first, int64_t stride,
+                                int64_t count, float *blocks_out, void *stream);
+/* The inverse: pc_out[order[(first + b * stride) * block + i]] = rows_in[b][i] for every position < n (padding rows are dropped). */
+PCCX_API int pccx_scatter_blocks(const float *rows_in, const int64_t *order, int64_t n, int block, int64_t first, int64_t stride,
+                                 int64_t count, float *pc_out, void *stream);
+
 /* pn_kit.index_points (pn_kit.py:332-360) / pytorch3d knn_gather (pointnet_sa_module.py:28):
  * out[b,m,:] = points[b, idx[b,m], :].  points: (B,N,C); idx: (B,M) int64 (negative -> row 0,
  * the clamp of pointnet_sa_module.py:27); out: (B,M,C). */

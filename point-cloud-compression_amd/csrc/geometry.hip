@@ -5,24 +5,8 @@
 // LDS (160 KiB/CU) and in registers for the whole of FPS; throughput comes from running one
 // cloud per CU across the 256 CUs, not from splitting a cloud.
 #include <math.h>
-#include <stdarg.h>
 
 #include "common.h"
-
-// ------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-void pccx_set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-}
-extern "C" const char *pccx_last_error(void) { return g_err; }
-extern "C" int pccx_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------------------
 // normalize (pn_kit.py:47-60) / denormalize (pn_kit.py:62-66)

@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpccx.so")
+# PCCX_LIB: another build of the same ABI (a sanitizer or experiment build).  PCCX_LIB_PARTIAL=1 accepts a library that exports only
+# part of the ABI -- the host-only sanitizer build of the packers (oracle/Makefile `asan`); calling an entry point it lacks raises.
+LIB_PATH = os.environ.get("PCCX_LIB") or os.path.join(_HERE, "lib", "libpccx.so")
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _P = C.c_void_p
@@ -19,6 +21,10 @@ _SIGNATURES = {
     "pccx_fps": [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],
     "pccx_morton_keys": [_P, C.c_int64, _P, C.c_float, _P, _P],
     "pccx_morton_keys_auto": [_P, C.c_int64, _P, _P, _P],
+    "pccx_sort_keys_workspace_bytes": [C.c_int64],
+    "pccx_sort_keys_u64": [_P, C.c_int64, C.c_int, _P, _P, _P],
+    "pccx_gather_blocks": [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, _P],
+    "pccx_scatter_blocks": [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, _P],
     "pccx_gather": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_knn": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P],
     "pccx_ball_query": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P],
@@ -123,7 +129,7 @@ _SIGNATURES = {
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
-_RESTYPES = {"pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
+_RESTYPES = {"pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
              "pccx_ae_encode_h2_workspace_bytes": C.c_size_t, "pccx_ae_decode_h2_workspace_floats": C.c_size_t,
              "pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,
@@ -152,7 +158,10 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.pccx_last_error.restype = C.c_char_p
         lib.pccx_last_error.argtypes = []
+        partial = os.environ.get("PCCX_LIB_PARTIAL") == "1"
         for name, args in _SIGNATURES.items():
+            if partial and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)   # AttributeError if the ABI and the header disagree
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)

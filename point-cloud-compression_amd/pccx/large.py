@@ -5,7 +5,9 @@ octree_np.decode hard-codes S = 64 (compress.py:102 asserts).  The build keeps S
 large cloud into spatially compact blocks of ``block`` = 8192 points (Morton order over the bounding
 box) and running the unchanged codec per block; blocks are independent, so they shard across ranks
 exactly like files (dist.shard_indices).  The last block is completed by repeating its final point.
-Ordering the keys uses torch.sort: data preparation outside the codec's timed window.
+The partition is HIP end to end (csrc/geometry.hip, csrc/sort.hip): bounding box + Morton keys, a stable radix sort of the
+(key, index) pairs (the permutation torch.sort(keys, stable=True) gives; round 3 used that call), and block gather / scatter
+kernels that read and write through the permutation -- no library sort and no torch indexing in the timed step.
 """
 import ctypes
 
@@ -37,29 +39,66 @@ def morton_keys_host_bbox(pc):
     return keys
 
 
+def morton_order(pc):
+    """pc (N,3) -> (N,) int64: the rows of pc in Morton order, ties in input order (= torch.sort(morton_keys(pc), stable=True).indices),
+    by the library's radix sort."""
+    keys = morton_keys(pc)
+    n = keys.shape[0]
+    order = torch.empty(n, device=pc.device, dtype=torch.int64)
+    ws = torch.empty(_lib.load().pccx_sort_keys_workspace_bytes(n), device=pc.device, dtype=torch.uint8)
+    _lib.call("pccx_sort_keys_u64", keys.data_ptr(), n, 63, order.data_ptr(), ws.data_ptr(), _stream())
+    return order
+
+
+def gather_blocks(pc, order, block=8192, first=0, stride=1, count=None, out=None):
+    """Blocks first, first + stride, ... (count of them; default: every block) of pc in the order `order`, as (count, block, 3); the
+    last block of the cloud is completed with copies of its final point.  ``out``: a (count, block, 3) slice to write into."""
+    pc = _f32c(pc, "gather_blocks")
+    N = pc.shape[0]
+    nb = (N + block - 1) // block
+    if count is None:
+        count = max((nb - first + stride - 1) // stride, 0)
+    if out is None:
+        out = torch.empty(count, block, 3, device=pc.device, dtype=torch.float32)
+    if count:
+        _lib.call("pccx_gather_blocks", pc.data_ptr(), order.data_ptr(), N, block, first, stride, count, out.data_ptr(), _stream())
+    return out
+
+
 def split_blocks(pc, block=8192):
     """pc (N,3) -> (blocks (nb,block,3), order (N,) permutation, n_valid_last).  Block j holds points
     order[j*block : (j+1)*block]; the last block is padded with copies of its final point."""
     N = pc.shape[0]
-    order = torch.sort(morton_keys(pc), stable=True).indices
+    order = morton_order(pc)
     nb = (N + block - 1) // block
-    pad = nb * block - N
-    idx = torch.cat([order, order[-1:].expand(pad)]) if pad else order
-    return pc[idx].view(nb, block, 3).contiguous(), order, block - pad
+    return gather_blocks(pc, order, block), order, N - (nb - 1) * block
 
 
 def compress_large(codec, pc, seed=11, rank=0, world=1, block=8192, batch=256):
     """Compress this rank's share of the blocks of one large cloud.  Returns (list of (block indices,
     Compressed batch), number of blocks, order, n_valid_last): everything decompress_large needs."""
     from . import dist
-    blocks, order, n_last = split_blocks(pc, block)
-    mine = dist.shard_indices(blocks.shape[0], rank, world)
+    N = pc.shape[0]
+    order = morton_order(pc)
+    nb = (N + block - 1) // block
+    mine = dist.shard_indices(nb, rank, world)                     # rank, rank + world, ...
     out = []
     for i in range(0, len(mine), batch):
         ids = mine[i:i + batch]
         starts = [dist.fps_start_index(seed, j, block) for j in ids]
-        out.append((ids, codec.compress(blocks[ids], starts)))
-    return out, blocks.shape[0], order, n_last
+        out.append((ids, codec.compress(gather_blocks(pc, order, block, first=ids[0], stride=world, count=len(ids)), starts)))
+    return out, nb, order, N - (nb - 1) * block
+
+
+def _progression(ids):
+    """(first, stride) when ids is first, first + stride, ... (what dist.shard_indices hands a rank), else None"""
+    ids = list(ids)
+    if len(ids) == 1:
+        return int(ids[0]), 1
+    st = int(ids[1]) - int(ids[0])
+    if st >= 1 and all(int(ids[i + 1]) - int(ids[i]) == st for i in range(len(ids) - 1)):
+        return int(ids[0]), st
+    return None
 
 
 def unsplit_blocks(rows, ids, order, n_points, block=8192, out=None):
@@ -70,10 +109,17 @@ def unsplit_blocks(rows, ids, order, n_points, block=8192, out=None):
     block-to-region placement and, for rows == the input blocks, the cloud itself bit for bit."""
     if out is None:
         out = torch.empty(n_points, 3, device=rows.device, dtype=rows.dtype)
-    ids_t = torch.as_tensor(list(ids), device=rows.device, dtype=torch.int64)
-    pos = ids_t[:, None] * block + torch.arange(block, device=rows.device)[None]          # position in Morton order
-    keep = pos < n_points                                                                  # drops the padding
-    out[order[pos[keep]]] = rows.reshape(-1, block, 3)[keep]
+    ids = list(ids)
+    if not ids:
+        return out
+    rows = _f32c(rows.reshape(len(ids), block, 3), "unsplit_blocks")
+    runs, prog = [], _progression(ids)
+    if prog is not None:
+        runs = [(0, len(ids), prog[0], prog[1])]
+    else:                                                 # arbitrary ids: one launch per block
+        runs = [(s_, 1, int(j), 1) for s_, j in enumerate(ids)]
+    for s0, cnt, first, stride in runs:
+        _lib.call("pccx_scatter_blocks", rows[s0:s0 + cnt].data_ptr(), order.data_ptr(), n_points, block, first, stride, cnt, out.data_ptr(), _stream())
     return out
 
 
@@ -93,43 +139,67 @@ def decompress_large(codec, parts, n_blocks, order, n_points, block=8192, out=No
     return out
 
 
+def _segments(ids, metas):
+    """Cut a batch's ascending global block ids into runs that belong to one cloud: (slot of the run's first block, count, cloud,
+    block-in-cloud of the first)"""
+    segs, slot = [], 0
+    while slot < len(ids):
+        g = ids[slot]
+        ci = next(c for c, (first, nb, _, _) in enumerate(metas) if first <= g < first + nb)
+        first, nb = metas[ci][0], metas[ci][1]
+        cnt = 1
+        while slot + cnt < len(ids) and ids[slot + cnt] < first + nb:
+            cnt += 1
+        segs.append((slot, cnt, ci, g - first))
+        slot += cnt
+    return segs
+
+
 def compress_large_many(codec, clouds, seed=11, rank=0, world=1, block=8192, batch=256):
     """Several large clouds at once: every cloud is cut as compress_large cuts it, but the blocks of ALL clouds form one
     sequence (global block g = blocks of cloud 0, then cloud 1, ...) that is sharded g mod world and compressed in batches of
     ``batch`` blocks regardless of cloud boundaries -- full launches instead of one short launch per room.  A block's FPS start
     index is dist.fps_start_index(seed + cloud, block-in-cloud, block), i.e. what compress_large(seed=seed + cloud) would draw, so a
     block's files do not depend on how the clouds were batched.  Returns (parts, metas): parts = list of (global block ids,
-    Compressed batch), metas = per cloud (first global block, number of blocks, order, n_points)."""
+    Compressed batch), metas = per cloud (first global block, number of blocks, order, n_points).  The clouds must stay alive and
+    unchanged until the call returns; each batch's blocks are gathered straight from them through the permutation."""
     from . import dist
-    metas, all_blocks, first = [], [], 0
+    metas, first = [], 0
+    clouds = [_f32c(pc, "compress_large_many") for pc in clouds]
     for pc in clouds:
-        blocks, order, _ = split_blocks(pc, block)
-        metas.append((first, int(blocks.shape[0]), order, int(pc.shape[0])))
-        all_blocks.append(blocks)
-        first += int(blocks.shape[0])
-    flat = torch.cat(all_blocks) if all_blocks else torch.empty(0, block, 3)
-    where = [(ci, j) for ci, (_, nb, _, _) in enumerate(metas) for j in range(nb)]
+        nb = (int(pc.shape[0]) + block - 1) // block
+        metas.append((first, nb, morton_order(pc), int(pc.shape[0])))
+        first += nb
     mine = dist.shard_indices(first, rank, world)
     parts = []
     for i in range(0, len(mine), batch):
         ids = mine[i:i + batch]
-        starts = [dist.fps_start_index(seed + where[g][0], where[g][1], block) for g in ids]
-        parts.append((ids, codec.compress(flat[ids], starts)))
+        buf = torch.empty(len(ids), block, 3, device=clouds[0].device, dtype=torch.float32)
+        starts = []
+        for slot, cnt, ci, j0 in _segments(ids, metas):
+            gather_blocks(clouds[ci], metas[ci][2], block, first=j0, stride=world, count=cnt, out=buf[slot:slot + cnt])
+            starts += [dist.fps_start_index(seed + ci, j0 + q * world, block) for q in range(cnt)]
+        parts.append((ids, codec.compress(buf, starts)))
     return parts, metas
 
 
 def decompress_large_many(codec, parts, metas, block=8192, outs=None, S=64):
     """Decode compress_large_many's batches and put every block back into its cloud (unsplit_blocks).  Returns the list of clouds;
-    with world > 1 a rank fills the rows of its own blocks only."""
+    with world > 1 a rank fills the rows of its own blocks only (the other rows are zero)."""
     if outs is None:
         dev = parts[0][1].s_bytes.device if parts else "cuda"
-        outs = [torch.zeros(n, 3, device=dev, dtype=torch.float32) for (_, _, _, n) in metas]
+        have = [0] * len(metas)
+        for ids, _ in parts:
+            for _, cnt, ci, _ in _segments(ids, metas):
+                have[ci] += cnt
+        # a cloud all of whose blocks are decoded here is written row by row: no clear needed
+        outs = [(torch.empty if have[ci] == nb else torch.zeros)(n, 3, device=dev, dtype=torch.float32) for ci, (_, nb, _, n) in enumerate(metas)]
     for ids, comp in parts:
         rec = codec.decompress(comp, S=S)
         if rec.shape[1] != block:
             raise ValueError(f"decoded blocks have {rec.shape[1]} points, expected {block} (S*k must equal the block size)")
-        for ci, (first, nb, order, n) in enumerate(metas):
-            sel = [slot for slot, g in enumerate(ids) if first <= g < first + nb]
-            if sel:
-                unsplit_blocks(rec[sel], [ids[slot] - first for slot in sel], order, n, block, outs[ci])
+        stride = ids[1] - ids[0] if len(ids) > 1 else 1
+        for slot, cnt, ci, j0 in _segments(ids, metas):
+            _, _, order, n = metas[ci]
+            unsplit_blocks(rec[slot:slot + cnt], [j0 + q * stride for q in range(cnt)], order, n, block, outs[ci])
     return outs

@@ -260,3 +260,40 @@ def test_chamfer_backward_matches_autograd_of_the_definition(P, Q):
     assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * float(ref.detach())
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(yg.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_radix_sort_is_the_stable_sort_and_block_gather_scatter_are_its_inverse_pair():
+    """csrc/sort.hip (configs[3]'s block partition): pccx_sort_keys_u64 = torch.sort(keys, stable=True) -- keys sorted in place and
+    the permutation identical, ties in input order -- on sizes around the 4096-key tile, with heavy duplication, with keys that use
+    all 63 bits and with keys confined to a few low bits; gather_blocks / unsplit_blocks against torch indexing incl. the padded last
+    block and a strided (rank-style) subset."""
+    from pccx import _lib, large
+    from pccx.ops import _stream
+    rng = np.random.default_rng(3)
+    for n, hi in ((1, 2 ** 62), (255, 2 ** 62), (4096, 7), (4097, 2 ** 63 - 1), (100_003, 1000), (1_000_001, 2 ** 63 - 1)):
+        keys = torch.from_numpy(rng.integers(0, hi, n, dtype=np.int64)).cuda()
+        if n > 1000:
+            keys[::7] = keys[3]                              # a large tie class
+        want = torch.sort(keys, stable=True)
+        order = torch.empty(n, device="cuda", dtype=torch.int64)
+        ws = torch.empty(_lib.load().pccx_sort_keys_workspace_bytes(n), device="cuda", dtype=torch.uint8)
+        k2 = keys.clone()
+        _lib.call("pccx_sort_keys_u64", k2.data_ptr(), n, 63, order.data_ptr(), ws.data_ptr(), _stream())
+        assert torch.equal(k2, want.values), n
+        assert torch.equal(order, want.indices), n
+    pc = torch.from_numpy(rng.random((20_001, 3)).astype(np.float32)).cuda()
+    order = large.morton_order(pc)
+    assert torch.equal(order, torch.sort(large.morton_keys(pc), stable=True).indices)
+    block, nb = 4096, 5
+    idx = torch.cat([order, order[-1:].expand(nb * block - pc.shape[0])])
+    want = pc[idx].view(nb, block, 3)
+    assert torch.equal(large.gather_blocks(pc, order, block), want)
+    assert torch.equal(large.gather_blocks(pc, order, block, first=1, stride=2), want[1::2])
+    back = large.unsplit_blocks(want, list(range(nb)), order, pc.shape[0], block)
+    assert torch.equal(back, pc)
+    part = torch.full_like(pc, float("nan"))
+    large.unsplit_blocks(want[[0, 2, 4]].contiguous(), [0, 2, 4], order, pc.shape[0], block, out=part)
+    large.unsplit_blocks(want[[3, 1]].contiguous(), [3, 1], order, pc.shape[0], block, out=part)     # not a progression: per-block launches
+    assert torch.equal(part, pc)
+    with pytest.raises(_lib.PccxError):
+        large.gather_blocks(pc, order, block, first=5, stride=1, count=1)                         # beyond the cloud
