@@ -713,11 +713,13 @@ def bench_pppf(args, rk):
             except Exception as e:
                 cpu = {"error": repr(e)}
         rf = None
+        # the arithmetic that RUNS: there is no f16x2 form of the PointNet++ / FoldingNet layers, the default mode takes their bf16x3 kernels
+        eff_matmul = "bf16x3" if args.matmul == "f16x2" else args.matmul
         if flop:
             ach = flop * B * S * args.steps / dt / 1e12
-            peak = F32_MATRIX_PEAK_TFLOPS if args.matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS   # f16x2: the PointNet++ layers run bf16x3
+            peak = F32_MATRIX_PEAK_TFLOPS if eff_matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS
             rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                  "frac": ach / peak, "traffic": None, "flop_per_patch": flop, "arithmetic": args.matmul,
+                  "frac": ach / peak, "traffic": None, "flop_per_patch": flop, "arithmetic": eff_matmul,
                   "reference_flop_per_patch": flop_ref, "reference_counted_tflops": flop_ref * B * S * args.steps / dt / 1e12,
                   "note": "whole-forward wall time over the FLOPs this implementation EXECUTES: PointnetSAModule gathers un-centred rows "
                           "(pointnet_sa_module.py:73-85), so its Conv-BN-ReLU stacks run on the N source rows once and the groups take their maxima "
@@ -728,8 +730,9 @@ def bench_pppf(args, rk):
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": MODE_DTYPE["bf16x3" if args.matmul == "f16x2" else args.matmul], "data": "synthetic",      # no f16x2 form of these layers
-            "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": args.matmul,
+            "dtype": MODE_DTYPE[eff_matmul], "data": "synthetic",
+            "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": eff_matmul,
+                       "matmul_requested": args.matmul,
                        "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
             "roofline": rf, "cpu_baseline": cpu,
             "gpu_over_cpu": (rk.world * B * S * Kp * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None}), flush=True)
@@ -737,35 +740,54 @@ def bench_pppf(args, rk):
 
 def bench_pppe_train(args, rk):
     """configs[4]: one optimisation step of the pppe fast path per "step" (forward in train mode, Chamfer rate-distortion
-    loss as the script builds it, backward, clip, Adam; data-parallel gradient all-reduce over RCCL when N > 1)."""
+    loss as the script builds it, backward, clip, Adam; data-parallel gradient all-reduce over RCCL when N > 1).  The line is
+    quoted at --train-batch clouds per GPU (4 = train_pppe_pcd_ae.py's batch_size); `batch_sweep` repeats the measurement at
+    batches 4 / 16 / 64 (clouds/s and patches/s: a cloud is 512 first-level patches per set-abstraction branch)."""
     import numpy as np
     import torch
     from pccx import families, synth, train
-    Bt = 4                                                   # train_pppe_pcd_ae.py: batch_size 4
-    model = families.PointCloudAE(64, 16, N_POINTS)
-    model.load_state_dict(seeded_state_dict(model, 32))
-    for k, v in model.state_dict().items():                  # sane BatchNorm statistics
-        if k.endswith("running_var"):
-            v.fill_(1.0)
-    sd0 = {k_: v.detach().clone() for k_, v in model.state_dict().items()}          # the CPU leg starts from the same weights
-    model = model.to(rk.dev)
-    opt = train.Adam(model.parameters(), lr=1e-3)
-    x = torch.from_numpy(np.stack([synth.cad_cloud(900 + rk.rank * Bt + i, N_POINTS) for i in range(Bt)])).to(rk.dev)
-    rng = np.random.default_rng(rk.rank)
-    starts = [[rng.integers(0, N_POINTS, Bt), rng.integers(0, N_POINTS, Bt)], rng.integers(0, 512, Bt), rng.integers(0, 128, Bt)]
-    keep = {}
-    kw = dict(lam=1e-3, data_parallel=rk.world > 1)
-    if args.autocast:
-        kw["autocast"] = True
-    if args.graph:
-        gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=args.autocast, warmup=max(args.warmup, 1),
-                                       data_parallel=rk.world > 1)     # N > 1: two graphs cut at the gradient all-reduce
-        dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), args.steps, torch.cuda.synchronize)
-        keep["o"] = tuple(float(t) for t in keep["o"])
-    else:
-        for _ in range(args.warmup):
-            train.train_step(model, opt, x, starts, **kw)
-        dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), args.steps, torch.cuda.synchronize)
+
+    def run(Bt, steps, warmup):
+        model = families.PointCloudAE(64, 16, N_POINTS)
+        model.load_state_dict(seeded_state_dict(model, 32))
+        for k, v in model.state_dict().items():                  # sane BatchNorm statistics
+            if k.endswith("running_var"):
+                v.fill_(1.0)
+        sd0 = {k_: v.detach().clone() for k_, v in model.state_dict().items()}          # the CPU leg starts from the same weights
+        model = model.to(rk.dev)
+        opt = train.Adam(model.parameters(), lr=1e-3)
+        x = torch.from_numpy(np.stack([synth.cad_cloud(900 + rk.rank * Bt + i, N_POINTS) for i in range(Bt)])).to(rk.dev)
+        rng = np.random.default_rng(rk.rank)
+        starts = [[rng.integers(0, N_POINTS, Bt), rng.integers(0, N_POINTS, Bt)], rng.integers(0, 512, Bt), rng.integers(0, 128, Bt)]
+        keep = {}
+        kw = dict(lam=1e-3, data_parallel=rk.world > 1)
+        if args.autocast:
+            kw["autocast"] = True
+        if args.graph:
+            gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=args.autocast, warmup=max(warmup, 1),
+                                           data_parallel=rk.world > 1)     # N > 1: two graphs cut at the gradient all-reduce
+            dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), steps, torch.cuda.synchronize)
+            keep["o"] = tuple(float(t) for t in keep["o"])
+        else:
+            for _ in range(warmup):
+                train.train_step(model, opt, x, starts, **kw)
+            dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), steps, torch.cuda.synchronize)
+        return dt, keep["o"][0], model, sd0, x, starts
+
+    Bt = args.train_batch
+    dt, loss, model, sd0, x, starts = run(Bt, args.steps, args.warmup)
+    sweep = {}
+    if not args.one_mode:
+        for b_ in (4, 16, 64):
+            if b_ == Bt:
+                sweep[str(b_)] = {"clouds_per_s": rk.world * Bt * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps}
+                continue
+            torch.cuda.empty_cache()
+            st_ = max(3, args.steps // 2)
+            dtb, _, _, _, _, _ = run(b_, st_, max(args.warmup, 1))
+            sweep[str(b_)] = {"clouds_per_s": rk.world * b_ * st_ / dtb, "ms_per_step": 1e3 * dtb / st_}
+        for v in sweep.values():
+            v["patches_per_s"] = v["clouds_per_s"] * 512
     if rk.rank == 0:
         cpu = None
         if rk.world == 1 and args.cpu_clouds > 0:
@@ -782,14 +804,18 @@ def bench_pppe_train(args, rk):
                   "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): small, launch-bound layers"}
         print(json.dumps({
             "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": rk.world * Bt * args.steps / dt,
-            "unit": "clouds/s", "points_per_s": rk.world * Bt * N_POINTS * args.steps / dt, "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if args.autocast else "f32", "data": "synthetic",
-            "config": {"workload": "pppe PointCloudAE training step (configs[4]), batch 4 x 8192 points per GPU",
+            "unit": "clouds/s", "points_per_s": rk.world * Bt * N_POINTS * args.steps / dt, "patches_per_s": rk.world * Bt * 512 * args.steps / dt,
+            "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 autocast (the reference's CUDA branch is fp16 autocast + GradScaler, train_pppe_pcd_ae.py:193,280; BASELINE configs[4] names bf16)"
+                     if args.autocast else "f32", "data": "synthetic",
+            "config": {"workload": f"pppe PointCloudAE training step (configs[4]), batch {Bt} x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
                        "launch": ("one hipGraph replay per step" if rk.world == 1 else "two hipGraph replays per step around the RCCL gradient all-reduce")
-                                 if args.graph else "eager (about 400 launches per step" + (", gradient all-reduce overlapped with backward)" if rk.world > 1 else ")")},
+                                 if args.graph else "eager" + (" (gradient all-reduce overlapped with backward)" if rk.world > 1 else "")},
+            "batch_sweep": sweep or None,
             "roofline": rf, "cpu_baseline": cpu,
-            "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": keep["o"][0]}), flush=True)
+            "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": loss}), flush=True)
 
 
 def main():
@@ -810,6 +836,8 @@ def main():
                          "blocks; pppf = configs[2] PPPF_AE forward; pppe-train = the training step of configs[4]; "
                          "launch-check = no GPU work, exercises the N-rank launch and the summary all-gather")
     ap.add_argument("--rooms", type=int, default=8, help="s3dis: number of rooms")
+    ap.add_argument("--train-batch", type=int, default=4, help="pppe-train: clouds per GPU per step (train_pppe_pcd_ae.py: batch_size 4); "
+                                                                 "batches 4 / 16 / 64 are swept beside it unless --one-mode")
     ap.add_argument("--autocast", action="store_true", default=None,
                     help="pppe-train: the bf16 autocast branch of train_pppe_pcd_ae.py:193-217 (the default for this workload: BASELINE "
                          "configs[4] names bf16)")

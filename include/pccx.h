@@ -109,7 +109,16 @@ PCCX_API int pccx_ball_query_grid(const float *q, int B, int M, const float *ref
  * eval.py:204) and of eval.py's D1 loop (eval.py:73-81). */
 PCCX_API int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q, float *d2, int32_t *nn,
                           void *stream);
+/* pccx_nn_dist for batches too small to fill the chip (configs[4]: 4 clouds): the reference cloud is scanned in `split` chunks by
+ * different workgroups (partials in scratch_d / scratch_nn: split * B * P entries each; scratch_nn may be NULL when nn is) and merged
+ * by a second kernel; identical results.  pccx_nn_dist_split_count: the split this shape should use (1 = call pccx_nn_dist). */
+PCCX_API int pccx_nn_dist_split_count(int B, int P, int Q);
+PCCX_API int pccx_nn_dist_split(const float *X, int B, int P, const float *Y, int Q, int split, float *scratch_d, int32_t *scratch_nn,
+                                float *d2, int32_t *nn, void *stream);
 
+/* chamfer_distance's value from the two pccx_nn_dist passes dxy (B,P), dyx (B,Q) (pytorch3d defaults: point and batch mean, both
+ * directions summed; AE.py:67): out[0] = batch mean of (mean_p dxy + mean_q dyx), accumulated in double */
+PCCX_API int pccx_chamfer_mean(const float *dxy, const float *dyx, int B, int P, int Q, float *out, void *stream);
 /* Backward of chamfer_distance (batch mean of both directions' point means; AE.py:57-70,
  * pppe_pcd_ae.py:817-838) for fixed argmins nn_xy (B,P), nn_yx (B,Q) from pccx_nn_dist:
  * gX (B,P,3), gY (B,Q,3) receive grad_out * dL/dX, dL/dY (buffers are zeroed here). */
@@ -118,6 +127,10 @@ PCCX_API int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, int
 /* pccx_chamfer_grad with the upstream gradient scalar read from device memory (no host sync: usable under hipGraph capture). */
 PCCX_API int pccx_chamfer_grad_dev(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
                                    const int32_t *nn_yx, const float *grad_out_dev, float *gX, float *gY, void *stream);
+/* ... into gX / gY the caller cleared (flags & 4) */
+PCCX_API int pccx_chamfer_grad_dev_acc(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
+                                       const int32_t *nn_yx, const float *grad_out_dev, float *gX, float *gY, int flags,
+                                       void *stream);
 
 /* D2 (point-to-plane) PSNR support (eval.py:58-60,73-81).  pccx_estimate_normals: PCA normal of
  * every point over its K neighbours nbr (B,N,K) int64 (e.g. pccx_knn with K=30, as open3d's
@@ -379,7 +392,8 @@ PCCX_API int pccx_planes_chain_wide(const float *src, int ldp, const int64_t *id
  * staying in registers: out (M / group, ldo) from the planes of the gathered input.  wstream = the four layers'
  * pccx_pack_planes_gemm streams back to back; b0..b3 the (folded) biases.  Supported width patterns: (<=32, 33..64, 33..64, 65..128)
  * and (97..128, 97..128, 97..128, 129..256) -- sa1 and sa2 of PPPF_AE.py:29-34; anything else returns PCCX_ERR_ARG and the caller
- * runs pccx_planes_gemm layer by layer. */
+ * runs pccx_planes_gemm layer by layer.  group in {32, 64, 128}, or 1 = no reduction: out (M, ldo) holds the stack's output rows
+ * (the stacks evaluated once per SOURCE row, the groups taking their maxima with pccx_gather_max). */
 PCCX_API int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
                                 const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
                                 int ldo, void *stream);
@@ -447,6 +461,22 @@ PCCX_API int pccx_linear_skinny(const float *x, int M, int K, int ldx, const flo
 PCCX_API int pccx_linear_skinny_dx(const float *dZ, int M, int N, int ldz, const float *W, int K, int flags, float *dX, int ldd,
                                    void *stream);
 PCCX_API int pccx_col_sum(const float *dY, int64_t M, int C, double *sums, float *g_bias, void *stream);
+/* The training step's forms of the four entry points above (train_pppe_pcd_ae.py:184-226; round 4): the same arithmetic in fewer launches.
+ * flags bit 2 (value 4): the accumulation target (`sums`, dF, gX / gY) was CLEARED BY THE CALLER -- pccx/train.py clears one arena per
+ * step with pccx_zero_bytes instead of one launch per reduction.  pccx_bn_relu_train_forward = pccx_bn_train_stats + pccx_bn_relu_forward
+ * (moments, then one kernel that finalises them and applies the layer; mean / rstd / running stats / Y bit-identical);
+ * pccx_bn_relu_train_backward = pccx_bn_relu_backward with g_gamma / g_beta WRITTEN (not accumulated); pccx_col_sum_w writes g_bias. */
+PCCX_API int pccx_bn_relu_train_forward(const float *Z, int64_t M, int C, float eps, float momentum, double *sums, const float *gamma,
+                                        const float *beta, int relu, float *mean, float *rstd, float *running_mean,
+                                        float *running_var, float *Y, int flags, void *stream);
+PCCX_API int pccx_bn_relu_train_backward(const float *dY, const float *Y, const float *Z, int64_t M, int C, const float *mean,
+                                         const float *rstd, const float *gamma, double *sums, float *dZ, float *g_gamma,
+                                         float *g_beta, int flags, void *stream);
+PCCX_API int pccx_col_sum_w(const float *dY, int64_t M, int C, double *sums, float *g_bias, int flags, void *stream);
+/* clear `bytes` (a multiple of 4) with a kernel (as a hipGraph node it is ordered like every other kernel: DESIGN.md section 7) */
+PCCX_API int pccx_zero_bytes(void *p, size_t bytes, void *stream);
+/* *table[i] += delta for n int64 counters whose device addresses sit in table_dev (BatchNorm's num_batches_tracked of a whole model) */
+PCCX_API int pccx_add_i64_table(const int64_t *table_dev, int n, int64_t delta, void *stream);
 PCCX_API int pccx_relu_backward(const float *dY, const float *Y, int64_t n, float *dZ, void *stream);
 PCCX_API int pccx_group_max_arg(const float *x, int64_t G, int Kn, int C, float *out, int32_t *arg,
                                 void *stream);
@@ -455,6 +485,9 @@ PCCX_API int pccx_group_max_backward(const float *dOut, const int32_t *arg, int6
 /* backward of pccx_gather: dF (B,N,C) = scatter-add of dG (B,Mrows, row stride ldg >= C) through idx */
 PCCX_API int pccx_gather_backward(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N,
                                   int C, float *dF, void *stream);
+/* the same, ACCUMULATING into a dF the caller cleared (flags & 4; without the flag dF is cleared here) */
+PCCX_API int pccx_gather_backward_acc(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N, int C, float *dF,
+                                      int flags, void *stream);
 /* F.smooth_l1_loss(a, b, reduction="mean") * n summed into value[0] (double); grad = grad_scale * dl/da */
 PCCX_API int pccx_smooth_l1(const float *a, const float *b, int64_t n, float grad_scale, double *value,
                             float *grad, void *stream);

@@ -617,8 +617,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // XPT queries per thread: 4 (1024 per workgroup) for the evaluation batches; 1 when the batch is too small to fill the chip that way
 // (the training step's 4 clouds: 32 workgroups become 128).  A query's scan over Y is the same sequence either way.
 template <bool WANT_NN, int XPT>
+// gridDim.z > 1 (pccx_nn_dist_split): workgroup z scans only the references [z qchunk, (z + 1) qchunk) and writes its partial
+// (distance, index) to slice z of d2 / nn (B P entries each); nn_merge_kernel then takes the first minimum over the slices.
 __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ X, int P, const float *__restrict__ Y, int Q,
-                                                      float *__restrict__ d2, int32_t *__restrict__ nn)
+                                                      float *__restrict__ d2, int32_t *__restrict__ nn, int qchunk)
 {
     __shared__ __attribute__((aligned(8))) float tyx[NND_TILE], tyy[NND_TILE], tyz[NND_TILE];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -633,8 +635,10 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
         x[j][0] = xp[3 * ii]; x[j][1] = xp[3 * ii + 1]; x[j][2] = xp[3 * ii + 2];
         best[j] = INFINITY; bi[j] = -1;
     }
-    for (int base = 0; base < Q; base += NND_TILE) {
-        const int cnt = Q - base < NND_TILE ? Q - base : NND_TILE;
+    const int q_begin = blockIdx.z * qchunk, q_end = q_begin + qchunk < Q ? q_begin + qchunk : Q;
+    const size_t slice = (size_t)blockIdx.z * gridDim.y * P;
+    for (int base = q_begin; base < q_end; base += NND_TILE) {
+        const int cnt = q_end - base < NND_TILE ? q_end - base : NND_TILE;
         const int cnt2 = (cnt + 1) & ~1;                  // an odd tail repeats its last point: no effect on min / first argmin
         __syncthreads();
         for (int t = tid; t < cnt2; t += 256) {
@@ -662,8 +666,8 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const float *__restrict__ 
     for (int j = 0; j < XPT; ++j) {
         int i = blockIdx.x * (256 * XPT) + j * 256 + tid;
         if (i < P) {
-            d2[(size_t)b * P + i] = best[j];
-            if (WANT_NN) nn[(size_t)b * P + i] = bi[j];
+            d2[slice + (size_t)b * P + i] = best[j];
+            if (WANT_NN) nn[slice + (size_t)b * P + i] = bi[j];
         }
     }
 }
@@ -679,12 +683,66 @@ extern "C" int pccx_nn_dist(const float *X, int B, int P, const float *Y, int Q,
     const int gx = (P + 256 * xpt - 1) / (256 * xpt);
     hipStream_t st = (hipStream_t)stream;
     if (nn) {
-        if (small) hipLaunchKernelGGL((nn_dist_kernel<true, 1>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
-        else hipLaunchKernelGGL((nn_dist_kernel<true, 4>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
+        if (small) hipLaunchKernelGGL((nn_dist_kernel<true, 1>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn, Q);
+        else hipLaunchKernelGGL((nn_dist_kernel<true, 4>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn, Q);
     } else {
-        if (small) hipLaunchKernelGGL((nn_dist_kernel<false, 1>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
-        else hipLaunchKernelGGL((nn_dist_kernel<false, 4>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn);
+        if (small) hipLaunchKernelGGL((nn_dist_kernel<false, 1>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn, Q);
+        else hipLaunchKernelGGL((nn_dist_kernel<false, 4>), dim3(gx, B), dim3(256), 0, st, X, P, Y, Q, d2, nn, Q);
     }
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// first minimum over the `split` partial results of pccx_nn_dist_split: slice z holds the references of chunk z in ascending order, so
+// taking a later slice only on a strictly smaller distance keeps the lowest index among equal distances, as the unsplit scan does
+__global__ void nn_merge_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pn, long n, int split, float *__restrict__ d2,
+                                int32_t *__restrict__ nn)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float best = pd[i];
+        int bi = pn ? pn[i] : -1;
+        for (int z = 1; z < split; ++z) {
+            const float v = pd[(size_t)z * n + i];
+            if (v < best) { best = v; bi = pn ? pn[(size_t)z * n + i] : -1; }
+        }
+        d2[i] = best;
+        if (nn) nn[i] = bi;
+    }
+}
+
+// How many reference chunks pccx_nn_dist_split should use for this shape: 1 when the plain launch already fills the chip (one
+// 256-query workgroup per CU), else enough chunks for about two workgroups per CU, each chunk a multiple of the LDS tile
+extern "C" int pccx_nn_dist_split_count(int B, int P, int Q)
+{
+    const long long wgs = (long long)B * ((P + 255) / 256);
+    if (wgs <= 0 || wgs >= 256 || Q < 2 * NND_TILE) return 1;
+    int split = (int)((512 + wgs - 1) / wgs);
+    const int max_split = Q / NND_TILE;
+    if (split > max_split) split = max_split;
+    if (split > 16) split = 16;
+    return split < 1 ? 1 : split;
+}
+
+// pccx_nn_dist for batches too small to fill the chip (the training step's 4 clouds of 8192 points: 128 workgroups): the reference
+// cloud is cut into `split` chunks scanned by different workgroups, the partial results (split x B x P distances and, when nn is
+// asked for, indices: `scratch_d` / `scratch_nn` from the caller) are merged by a second small kernel.  Same results as pccx_nn_dist.
+extern "C" int pccx_nn_dist_split(const float *X, int B, int P, const float *Y, int Q, int split, float *scratch_d, int32_t *scratch_nn,
+                                  float *d2, int32_t *nn, void *stream)
+{
+    if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(X && Y && d2 && scratch_d && (!nn || scratch_nn), "pccx_nn_dist_split: null pointer");
+    PCCX_CHECK_ARG(B >= 0 && B <= 65535 && P >= 1 && Q >= 1 && split >= 1 && split <= 64, "pccx_nn_dist_split: bad shape (split=%d)", split);
+    int qchunk = (Q + split - 1) / split;
+    qchunk = (qchunk + NND_TILE - 1) / NND_TILE * NND_TILE;
+    split = (Q + qchunk - 1) / qchunk;
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = (P + 255) / 256;
+    if (nn) hipLaunchKernelGGL((nn_dist_kernel<true, 1>), dim3(gx, B, split), dim3(256), 0, st, X, P, Y, Q, scratch_d, scratch_nn, qchunk);
+    else hipLaunchKernelGGL((nn_dist_kernel<false, 1>), dim3(gx, B, split), dim3(256), 0, st, X, P, Y, Q, scratch_d, (int32_t *)nullptr, qchunk);
+    const long n = (long)B * P;
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(nn_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)scratch_d, (const int32_t *)(nn ? scratch_nn : nullptr), n, split, d2, nn);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
@@ -825,8 +883,40 @@ __global__ void chamfer_grad_kernel(const float *__restrict__ X, int P, const fl
     }
 }
 
+// chamfer_distance's value from the two nearest-neighbour passes (pytorch3d defaults: point_reduction = batch_reduction = "mean"):
+//   out = (1/B) sum_b [ (1/P) sum_p dxy[b,p] + (1/Q) sum_q dyx[b,q] ]   accumulated in double, stored as float.
+// One workgroup, one launch (round 3 formed it with six torch kernels: two casts, two means, an add, a mean).
+__global__ __launch_bounds__(1024) void chamfer_mean_kernel(const float *__restrict__ dxy, const float *__restrict__ dyx, int B, int P, int Q,
+                                                            float *__restrict__ out)
+{
+    __shared__ double red[16];
+    double tot = 0;
+    for (int b = 0; b < B; ++b) {
+        double sx = 0, sy = 0;
+        for (int i = threadIdx.x; i < P; i += 1024) sx += (double)dxy[(size_t)b * P + i];
+        for (int i = threadIdx.x; i < Q; i += 1024) sy += (double)dyx[(size_t)b * Q + i];
+        tot += sx / (double)P + sy / (double)Q;
+    }
+    for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = (float)(t / (double)B);
+    }
+}
+
+extern "C" int pccx_chamfer_mean(const float *dxy, const float *dyx, int B, int P, int Q, float *out, void *stream)
+{
+    PCCX_CHECK_ARG(dxy && dyx && out && B >= 1 && P >= 1 && Q >= 1, "pccx_chamfer_mean: bad arguments");
+    hipLaunchKernelGGL(chamfer_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dxy, dyx, B, P, Q, out);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 static int chamfer_grad_launch(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy, const int32_t *nn_yx,
-                               float grad_out, const float *g_dev, float *gX, float *gY, void *stream);
+                               float grad_out, const float *g_dev, float *gX, float *gY, void *stream, bool prezeroed = false);
 
 extern "C" int pccx_chamfer_grad(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
                                  const int32_t *nn_yx, float grad_out, float *gX, float *gY, void *stream)
@@ -842,14 +932,24 @@ extern "C" int pccx_chamfer_grad_dev(const float *X, int B, int P, const float *
     return chamfer_grad_launch(X, B, P, Y, Q, nn_xy, nn_yx, 1.0f, grad_out_dev, gX, gY, stream);
 }
 
+// the same into gX / gY the caller has cleared (flags & 4): no clearing launches
+extern "C" int pccx_chamfer_grad_dev_acc(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy,
+                                         const int32_t *nn_yx, const float *grad_out_dev, float *gX, float *gY, int flags, void *stream)
+{
+    PCCX_CHECK_ARG(grad_out_dev, "pccx_chamfer_grad_dev_acc: null pointer");
+    return chamfer_grad_launch(X, B, P, Y, Q, nn_xy, nn_yx, 1.0f, grad_out_dev, gX, gY, stream, (flags & 4) != 0);
+}
+
 static int chamfer_grad_launch(const float *X, int B, int P, const float *Y, int Q, const int32_t *nn_xy, const int32_t *nn_yx,
-                               float grad_out, const float *g_dev, float *gX, float *gY, void *stream)
+                               float grad_out, const float *g_dev, float *gX, float *gY, void *stream, bool prezeroed)
 {
     if (B == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(X && Y && nn_xy && nn_yx && gX && gY, "pccx_chamfer_grad: null pointer");
     PCCX_CHECK_ARG(P >= 1 && Q >= 1 && B <= 65535, "pccx_chamfer_grad: bad shape");
-    PCCX_CHECK_HIP(pccx_zero_async(gX, sizeof(float) * (size_t)B * P * 3, (hipStream_t)stream));
-    PCCX_CHECK_HIP(pccx_zero_async(gY, sizeof(float) * (size_t)B * Q * 3, (hipStream_t)stream));
+    if (!prezeroed) {
+        PCCX_CHECK_HIP(pccx_zero_async(gX, sizeof(float) * (size_t)B * P * 3, (hipStream_t)stream));
+        PCCX_CHECK_HIP(pccx_zero_async(gY, sizeof(float) * (size_t)B * Q * 3, (hipStream_t)stream));
+    }
     const int n = P > Q ? P : Q;
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, X, P, Y, Q, nn_xy, nn_yx,
                        grad_out / ((float)B * P), grad_out / ((float)B * Q), g_dev, gX, gY);

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
     pg_chain_layer<KT2, MQ2>(ws, c, nch, i2, acc2);
     bf16x8 i3[2][KT3][3];
     pg_to_planes<4 * MQ2, KT3>(acc2, i3);
-    // ---- last layer in passes of 8 m-tiles, each reduced over the row groups
+    // ---- last layer in passes of 8 m-tiles, each reduced over the row groups (group == 1: no reduction, the rows themselves)
     const int gpb = 128 / group, wpg = group / 32;
     const long long G = M / group;
 #pragma unroll 1
@@ -608,6 +608,28 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
         f32x4 acc3[2][8];
         pg_bias_init<8>(acc3, b3, N3, 8 * ps, g);
         pg_chain_layer<KT3, 2>(ws, c, nch, i3, acc3);
+        if (group == 1) {
+            // relu(L3(...)) as fp32 rows (M, ldo): lane (g, n) holds channels 128 ps + 16 mt + 4 g .. + 3 of row 16 (tile0 + nt) + n
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const long long row = (tile0 + nt) * 16 + n;
+                if (tile0 + nt < ntiles && row < M) {
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt) {
+                        const int co = 128 * ps + 16 * mt + 4 * g;
+                        const f32x4 v = relu4(acc3[nt][mt]);
+                        if (co + 3 < N3 && (ldo & 3) == 0) {
+                            *(f32x4 *)(out + (size_t)row * ldo + co) = v;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < N3) out[(size_t)row * ldo + co + r] = v[r];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
@@ -646,8 +668,8 @@ static int planes_chain4_launch(const float *x, const int64_t *idx, int64_t rows
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
     PCCX_CHECK_ARG(M > 0 && K0 >= 1 && N0 >= 1 && N1 >= 1 && N2 >= 1 && N3 >= 1 && ldo >= N3, "%s: bad shape", who);
-    PCCX_CHECK_ARG((group == 32 || group == 64 || group == 128) && M % group == 0, "%s: group in {32,64,128} dividing M (group=%d M=%lld)",
-                   who, group, (long long)M);
+    PCCX_CHECK_ARG((group == 1 || group == 32 || group == 64 || group == 128) && M % group == 0 && (group != 1 || (uintptr_t)out % 16 == 0),
+                   "%s: group in {1,32,64,128} dividing M (group=%d M=%lld; group 1 = rows, out 16-byte aligned)", who, group, (long long)M);
     const long long ntiles = (M + 15) / 16, nblk = (ntiles + 7) / 8;
     PCCX_CHECK_ARG(nblk <= 0x7fffffffLL, "%s: M too large", who);
     const int KT0 = pg_kt32(K0);

@@ -304,17 +304,14 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(const float *__restric
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     float4 mu = make_float4(0, 0, 0, 0), rs = mu;
     if (MODE == 1) { mu = ((const float4 *)mean)[cq]; rs = ((const float4 *)rstd)[cq]; }
-    for (long m = m0 + rl; m < m1; m += rstep) {
-        const size_t e = (size_t)m * cv + cq;
-        const float4 a = ((const float4 *)A)[e];
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+    auto add_row = [&](const float4 &a, const float4 &y, const float4 &z) {
         const float av[4] = {a.x, a.y, a.z, a.w};
         if (MODE == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double z = av[u]; s0[u] += z; s1[u] += z * z; }
+            for (int u = 0; u < 4; ++u) { const double zz = av[u]; s0[u] += zz; s1[u] += zz * zz; }
         } else if (MODE == 1) {
-            const float4 y = ((const float4 *)Y)[e], z = ((const float4 *)Z)[e];
             const float yv[4] = {y.x, y.y, y.z, y.w}, zv[4] = {z.x, z.y, z.z, z.w};
-            const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float d = yv[u] > 0.f ? av[u] : 0.f;
@@ -325,6 +322,26 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(const float *__restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) s0[u] += av[u];
         }
+    };
+    // FOUR row steps' loads in flight per thread (a thread's rows are still added in ascending order: the sums are bit-identical to the
+    // one-row-at-a-time loop, which exposed one HBM latency per 16 bytes: 31-34 us per call, 0.84 ms of the round-3 training step)
+    long m = m0 + rl;
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    for (; m + 3 * rstep < m1; m += 4 * rstep) {
+        float4 a[4], y[4], z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t e = (size_t)(m + q * rstep) * cv + cq;
+            a[q] = ((const float4 *)A)[e];
+            y[q] = MODE == 1 ? ((const float4 *)Y)[e] : zero4;
+            z[q] = MODE == 1 ? ((const float4 *)Z)[e] : zero4;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) add_row(a[q], y[q], z[q]);
+    }
+    for (; m < m1; m += rstep) {
+        const size_t e = (size_t)m * cv + cq;
+        add_row(((const float4 *)A)[e], MODE == 1 ? ((const float4 *)Y)[e] : zero4, MODE == 1 ? ((const float4 *)Z)[e] : zero4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { red[0][u][tid] = s0[u]; red[1][u][tid] = s1[u]; }
@@ -340,18 +357,23 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(const float *__restric
     }
 }
 
+// prezeroed: the caller cleared o0 / o1 already (train.py's step arena: ONE clear per training step instead of one per reduction)
 static int launch_col_reduce(int mode, const float *A, const float *Y, const float *Z, const float *mean, const float *rstd,
-                             int64_t M, int C, double *o0, double *o1, hipStream_t st)
+                             int64_t M, int C, double *o0, double *o1, hipStream_t st, bool prezeroed = false)
 {
     const int cv = C >> 2;
     if (C % 4 == 0 && cv >= 1 && cv <= 256 && (cv & (cv - 1)) == 0 && ((uintptr_t)A & 15) == 0 && (!Y || ((uintptr_t)Y & 15) == 0) &&
         (!Z || ((uintptr_t)Z & 15) == 0)) {
-        long rpb = (M + 1023) / 1024;                                  // about four workgroups per CU
+        // One workgroup per CU: every workgroup ends with one double atomic per column on the SAME 2 C addresses, and same-address atomics
+        // serialise at L2 -- with ~1024 workgroups that tail was most of the kernel (31-35 us per call for 17-34 MB of input, round 4
+        // profile); 256 workgroups with four 16-byte loads in flight per thread still cover the HBM latency.
+        long rpb = (M + 255) / 256;
         const long rstep = 256 / cv;
         if (rpb < 8 * rstep) rpb = 8 * rstep;
         rpb = (rpb + rstep - 1) / rstep * rstep;
         const unsigned blocks = (unsigned)((M + rpb - 1) / rpb);
-        if (o1 == o0 + C) {
+        if (prezeroed) {
+        } else if (o1 == o0 + C) {
             PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * 2 * C, st));          // both sums in one launch
         } else {
             PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
@@ -365,8 +387,10 @@ static int launch_col_reduce(int mode, const float *A, const float *Y, const flo
     }
     dim3 grid((C + 63) / 64, (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
     PCCX_CHECK_ARG(grid.y <= 65535u, "column reduction: M=%ld rows too many", (long)M);
-    PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
-    if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
+    if (!prezeroed) {
+        PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
+        if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
+    }
     hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, st, mode, A, Y, Z, mean, rstd, (long)M, C, o0, o1);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
@@ -477,6 +501,136 @@ extern "C" int pccx_bn_relu_backward(const float *dY, const float *Y, const floa
     return PCCX_OK;
 }
 
+// ---- the training step's BatchNorm-ReLU in two launches each way (round 4) -----------------------------------------------------------
+// forward: column moments (col_reduce4<0>) -> ONE kernel that turns the double sums into mean / rstd itself (every workgroup for the C
+// columns, in LDS; workgroup 0 also stores them for the backward and updates the running statistics) and applies the layer: the same
+// fp32 expressions as bn_finalize_kernel + bn_relu_fwd_kernel, so Y, mean, rstd and the running buffers are bit-identical to
+// pccx_bn_train_stats + pccx_bn_relu_forward.  flags & 4: `sums` was cleared by the caller.
+__global__ __launch_bounds__(256) void bn_relu_fwd_fused_kernel(const float *__restrict__ Z, long n, int C, long M, const double *__restrict__ s0,
+                                                                const double *__restrict__ s1, float eps, float momentum,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                                                float *__restrict__ Y, float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                                float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    extern __shared__ float bnsm[];                                    // mean[C] | rstd[C]
+    float *smean = bnsm, *srstd = bnsm + C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mu = s0[c] / (double)M;
+        double var = s1[c] / (double)M - mu * mu;
+        if (var < 0) var = 0;
+        const float mf = (float)mu, rf = (float)(1.0 / sqrt(var + (double)eps));
+        smean[c] = mf;
+        srstd[c] = rf;
+        if (blockIdx.x == 0) {
+            mean_out[c] = mf;
+            rstd_out[c] = rf;
+            if (running_mean) {
+                const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+        }
+    }
+    __syncthreads();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float v = (Z[i] - smean[c]) * srstd[c] * gamma[c] + beta[c];
+        Y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+extern "C" int pccx_bn_relu_train_forward(const float *Z, int64_t M, int C, float eps, float momentum, double *sums, const float *gamma,
+                                          const float *beta, int relu, float *mean, float *rstd, float *running_mean, float *running_var,
+                                          float *Y, int flags, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(Z && sums && gamma && beta && mean && rstd && Y && C >= 1 && C <= 4096, "pccx_bn_relu_train_forward: bad arguments (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_col_reduce(0, Z, nullptr, nullptr, nullptr, nullptr, M, C, sums, sums + C, st, (flags & 4) != 0);
+    if (rc) return rc;
+    long blocks = ((long)M * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_relu_fwd_fused_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 2 * C, st, Z, (long)M * C, C, (long)M, sums,
+                       sums + C, eps, momentum, gamma, beta, relu, Y, mean, rstd, running_mean, running_var);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// backward: dgamma / dbeta sums (col_reduce4<1>) -> the apply kernel, whose workgroup 0 also WRITES the two parameter gradients as float
+// (pccx_bn_relu_backward adds them onto its zeroed outputs in a third launch: the same values).  flags & 4: `sums` cleared by the caller.
+__global__ void bn_relu_bwd_apply_w_kernel(const float *__restrict__ dY, const float *__restrict__ Y, const float *__restrict__ Z,
+                                           long n, int C, long M, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                           const float *__restrict__ gamma, const double *__restrict__ dgamma,
+                                           const double *__restrict__ dbeta, float *__restrict__ dZ, float *__restrict__ g_gamma,
+                                           float *__restrict__ g_beta)
+{
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            g_gamma[c] = (float)dgamma[c];
+            g_beta[c] = (float)dbeta[c];
+        }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const double d = Y[i] > 0.f ? dY[i] : 0.f;
+        const double xh = (double)((Z[i] - mean[c]) * rstd[c]);
+        dZ[i] = (float)((double)gamma[c] * rstd[c] / (double)M * ((double)M * d - dbeta[c] - xh * dgamma[c]));
+    }
+}
+
+extern "C" int pccx_bn_relu_train_backward(const float *dY, const float *Y, const float *Z, int64_t M, int C, const float *mean,
+                                           const float *rstd, const float *gamma, double *sums, float *dZ, float *g_gamma,
+                                           float *g_beta, int flags, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dY && Y && Z && mean && rstd && gamma && sums && dZ && g_gamma && g_beta, "pccx_bn_relu_train_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_col_reduce(1, dY, Y, Z, mean, rstd, M, C, sums, sums + C, st, (flags & 4) != 0);
+    if (rc) return rc;
+    long blocks = ((long)M * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dY, Y, Z, (long)M * C, C, (long)M, mean, rstd,
+                       gamma, sums, sums + C, dZ, g_gamma, g_beta);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// bias gradient, written: g_bias[c] = sum_m dY[m][c]  (flags & 4: `sums` cleared by the caller)
+extern "C" int pccx_col_sum_w(const float *dY, int64_t M, int C, double *sums, float *g_bias, int flags, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(dY && sums && g_bias, "pccx_col_sum_w: null pointer");
+    int rc = launch_col_reduce(2, dY, nullptr, nullptr, nullptr, nullptr, M, C, sums, nullptr, (hipStream_t)stream, (flags & 4) != 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, g_bias, 0);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// clear `bytes` (a multiple of 4) on the stream with a kernel node (common.h: pccx_zero_async) -- train.py's step arena
+extern "C" int pccx_zero_bytes(void *p, size_t bytes, void *stream)
+{
+    if (bytes == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(p && bytes % 4 == 0 && ((uintptr_t)p & 3) == 0, "pccx_zero_bytes: needs a 4-byte aligned buffer of a multiple of 4 bytes");
+    PCCX_CHECK_HIP(pccx_zero_async(p, bytes, (hipStream_t)stream));
+    return PCCX_OK;
+}
+
+// *table[i] += delta for n int64 counters whose addresses sit in a device table (BatchNorm's num_batches_tracked: one launch per step
+// instead of one torch add per layer)
+__global__ void add_i64_table_kernel(const int64_t *__restrict__ table, int n, long long delta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) *(long long *)(uintptr_t)table[i] += delta;
+}
+extern "C" int pccx_add_i64_table(const int64_t *table_dev, int n, int64_t delta, void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(table_dev && n > 0, "pccx_add_i64_table: bad arguments");
+    hipLaunchKernelGGL(add_i64_table_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, table_dev, n, (long long)delta);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // bias gradient: g_bias[c] += sum_m dY[m][c]
 extern "C" int pccx_col_sum(const float *dY, int64_t M, int C, double *sums, float *g_bias, void *stream)
 {
@@ -577,12 +731,23 @@ __global__ void scatter_add_rows_kernel(const float *__restrict__ dG, int ldg, c
     }
 }
 
+static int gather_backward_launch(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N, int C, float *dF, bool prezeroed, void *stream);
 extern "C" int pccx_gather_backward(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N, int C, float *dF,
                                     void *stream)
 {
+    return gather_backward_launch(dG, ldg, idx, B, Mrows, N, C, dF, false, stream);
+}
+// the same into a dF the caller has cleared (flags & 4), i.e. without the clearing launch
+extern "C" int pccx_gather_backward_acc(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N, int C, float *dF, int flags,
+                                        void *stream)
+{
+    return gather_backward_launch(dG, ldg, idx, B, Mrows, N, C, dF, (flags & 4) != 0, stream);
+}
+static int gather_backward_launch(const float *dG, int ldg, const int64_t *idx, int B, int Mrows, int N, int C, float *dF, bool prezeroed, void *stream)
+{
     if (B == 0 || Mrows == 0) return PCCX_OK;
     PCCX_CHECK_ARG(dG && idx && dF && ldg >= C && B <= 65535, "pccx_gather_backward: bad arguments");
-    PCCX_CHECK_HIP(pccx_zero_async(dF, sizeof(float) * (size_t)B * N * C, (hipStream_t)stream));
+    if (!prezeroed) PCCX_CHECK_HIP(pccx_zero_async(dF, sizeof(float) * (size_t)B * N * C, (hipStream_t)stream));
     long blocks = ((long)Mrows * C + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, dG, ldg, idx, Mrows, N,

@@ -31,7 +31,10 @@ _SIGNATURES = {
     "pccx_ball_query_grid_workspace_ints": [C.c_int, C.c_int],
     "pccx_ball_query_grid": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P],
     "pccx_nn_dist": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P],
+    "pccx_nn_dist_split_count": [C.c_int, C.c_int, C.c_int],
+    "pccx_nn_dist_split": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_chamfer_grad": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P],
+    "pccx_chamfer_mean": [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "pccx_chamfer_grad_dev": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P],
     "pccx_estimate_normals": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_point_plane_err": [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P],
@@ -114,6 +117,13 @@ _SIGNATURES = {
     "pccx_bn_relu_forward": [_P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P],
     "pccx_bn_relu_backward": [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P],
     "pccx_col_sum": [_P, C.c_int64, C.c_int, _P, _P, _P],
+    "pccx_bn_relu_train_forward": [_P, C.c_int64, C.c_int, C.c_float, C.c_float, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P],
+    "pccx_bn_relu_train_backward": [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
+    "pccx_col_sum_w": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P],
+    "pccx_zero_bytes": [_P, C.c_size_t, _P],
+    "pccx_add_i64_table": [_P, C.c_int, C.c_int64, _P],
+    "pccx_gather_backward_acc": [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
+    "pccx_chamfer_grad_dev_acc": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P],
     "pccx_relu_backward": [_P, _P, C.c_int64, _P, _P],
     "pccx_group_max_arg": [_P, C.c_int64, C.c_int, C.c_int, _P, _P, _P],
     "pccx_group_max_backward": [_P, _P, C.c_int64, C.c_int, C.c_int, _P, _P],

@@ -353,8 +353,28 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
         new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)                   # :66-68 (start index 0)
         idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
         if self.dedup and B > 0 and stack[-1].N % 4 == 0:
-            rows = cat_rows([feats, xyz] if feats is not None else [xyz])           # :83 features first, xyz last, one row per SOURCE point
-            y = run_stack(stack, rows)                                              # :90 Conv-BN-ReLU, (B * N, C) rows
+            if stack[0].mode() == "bf16x3":
+                # :83 features first, xyz last, one row per SOURCE point -- split straight into the first layer's operand planes from the
+                # two tables (pccx_group_planes without indices): the concatenated rows (two torch copies per level in round 3) never exist
+                f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
+                x2 = xyz.reshape(-1, 3).contiguous()
+                rows_n = x2.shape[0]
+                C0 = int(f2.shape[1]) if f2 is not None else 0
+                pl = torch.empty(_lib.load().pccx_planes_floats(rows_n, C0 + 3), device=xyz.device, dtype=torch.float32)
+                _lib.call("pccx_group_planes", f2.data_ptr() if f2 is not None else None, C0, C0, x2.data_ptr(), 3, 3, None, rows_n, 1, 1,
+                          pl.data_ptr(), _stream())
+                if chain4_fits(stack):
+                    # :90 Conv-BN-ReLU x 4 on the source rows in ONE kernel (the chain of planes.hip with its row epilogue, group = 1)
+                    if getattr(self, "_chain_of", None) is not stack:               # new pack -> new stream
+                        self._chain_of, self._chain_cache = stack, {}
+                    ws, a = _chain_args(stack, self._chain_cache)
+                    y = torch.empty(rows_n, stack[3].N, device=xyz.device, dtype=torch.float32)
+                    _lib.call("pccx_planes_chain4", pl.data_ptr(), rows_n, stack[0].K, ws.data_ptr(), *a, 1, y.data_ptr(), stack[3].N, _stream())
+                else:
+                    y = run_stack_planes(stack, pl, rows_n)                         # :90 Conv-BN-ReLU, (B * N, C) rows
+            else:
+                rows = cat_rows([feats, xyz] if feats is not None else [xyz])
+                y = run_stack(stack, rows)
             return new_xyz, gather_max(y.view(B, xyz.shape[1], -1), idx)            # :91 max over the group's members
         if stack[0].mode() == "bf16x3" and self.nsample in (32, 64, 128) and B > 0:
             # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue

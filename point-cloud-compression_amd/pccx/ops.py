@@ -176,6 +176,14 @@ def nn_dist(x, y, return_idx=False):
     B, P, _ = x.shape
     d2 = torch.empty(B, P, device=x.device, dtype=torch.float32)
     nn = torch.empty(B, P, device=x.device, dtype=torch.int32) if return_idx else None
+    split = _lib.load().pccx_nn_dist_split_count(B, P, int(y.shape[1])) if B > 0 else 1
+    if split > 1:
+        # a batch too small to fill the chip (the training step's 4 clouds): the reference cloud in `split` chunks over more workgroups
+        sd = torch.empty(split, B, P, device=x.device, dtype=torch.float32)
+        sn = torch.empty(split, B, P, device=x.device, dtype=torch.int32) if return_idx else None
+        _lib.call("pccx_nn_dist_split", x.data_ptr(), B, P, y.data_ptr(), y.shape[1], split, sd.data_ptr(),
+                  sn.data_ptr() if sn is not None else None, d2.data_ptr(), nn.data_ptr() if nn is not None else None, _stream())
+        return (d2, nn) if return_idx else d2
     _lib.call("pccx_nn_dist", x.data_ptr(), B, P, y.data_ptr(), y.shape[1], d2.data_ptr(),
               nn.data_ptr() if nn is not None else None, _stream())
     return (d2, nn) if return_idx else d2
@@ -202,6 +210,9 @@ def point_plane_err(x, y, normals_y):
     return err
 
 
+zeros_hook = None       # pccx.train installs its arena's allocator here: (shape, dtype, device) -> (zero tensor, from-arena?)
+
+
 class _ChamferFn(torch.autograd.Function):
     """Differentiable chamfer_distance (batch mean): forward = two nn_dist launches, backward =
     pccx_chamfer_grad with the argmins saved from the forward."""
@@ -211,13 +222,20 @@ class _ChamferFn(torch.autograd.Function):
         dxy, nxy = nn_dist(x, y, return_idx=True)
         dyx, nyx = nn_dist(y, x, return_idx=True)
         ctx.save_for_backward(x, y, nxy, nyx)
-        return (dxy.double().mean(dim=1) + dyx.double().mean(dim=1)).mean().float()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        _lib.call("pccx_chamfer_mean", dxy.data_ptr(), dyx.data_ptr(), x.shape[0], x.shape[1], y.shape[1], out.data_ptr(), _stream())
+        return out
 
     @staticmethod
     def backward(ctx, g):
         x, y, nxy, nyx = ctx.saved_tensors
-        gx, gy = torch.empty_like(x), torch.empty_like(y)
         gd = g.detach().to(torch.float32).reshape(1).contiguous()        # stays on the device: no sync inside backward
+        if zeros_hook is not None:          # inside a training step: the two gradients come cleared from the step's arena (train.StepArena)
+            gx, gy = zeros_hook(tuple(x.shape), torch.float32, x.device)[0], zeros_hook(tuple(y.shape), torch.float32, y.device)[0]
+            _lib.call("pccx_chamfer_grad_dev_acc", x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), y.shape[1], nxy.data_ptr(),
+                      nyx.data_ptr(), gd.data_ptr(), gx.data_ptr(), gy.data_ptr(), 4, _stream())
+            return gx, gy
+        gx, gy = torch.empty_like(x), torch.empty_like(y)
         _lib.call("pccx_chamfer_grad_dev", x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), y.shape[1], nxy.data_ptr(),
                   nyx.data_ptr(), gd.data_ptr(), gx.data_ptr(), gy.data_ptr(), _stream())
         return gx, gy

@@ -25,11 +25,69 @@ _SCRATCH = {}
 _AUTOCAST = False          # set by train_step(autocast=True) around forward + backward
 
 
+class StepArena:
+    """Everything a training step ACCUMULATES into -- the weight / bias gradients (atomics over row slices), split-K dX of the skinny
+    Linears, scatter-added feature gradients, the Chamfer gradients, the column-sum scratch of every BatchNorm, Adam's norm
+    accumulator -- carved from ONE buffer that is cleared by ONE launch at the start of the step (pccx_zero_bytes).  Round 3 cleared
+    each of them separately: 75 torch fill kernels + 35 pccx_zero_kernel launches per step, ~0.5 ms of a 5 ms step.
+    The first step through an arena only measures (every request falls back to torch.zeros); the buffer is allocated when that step
+    ends and used from the next one on.  Slices are valid until the next begin() on the same arena: gradients are consumed by the
+    optimiser inside the step.  A captured step owns its arena (GraphedTrainStep), so eager steps never clear a graph's gradients."""
+
+    def __init__(self):
+        self.buf, self.off, self.need, self.active = None, 0, 0, False
+
+    def begin(self, device):
+        self.off, self.need, self.active = 0, 0, True
+        if self.buf is not None and self.buf.device != torch.device(device):
+            self.buf = None
+        if self.buf is not None:
+            _lib.call("pccx_zero_bytes", self.buf.data_ptr(), self.buf.numel(), _stream())
+
+    def zeros(self, shape, dtype, device):
+        """a zero tensor: an arena slice when the arena is live and large enough (second value True), else torch.zeros"""
+        numel = 1
+        for d_ in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+            numel *= int(d_)
+        nbytes = (numel * torch.empty(0, dtype=dtype).element_size() + 15) // 16 * 16
+        if self.active:
+            self.need += nbytes
+            if self.buf is not None and self.off + nbytes <= self.buf.numel():
+                v = self.buf[self.off:self.off + nbytes].view(dtype)[:numel].view(shape)
+                self.off += nbytes
+                return v, True
+        return torch.zeros(shape, dtype=dtype, device=device), False
+
+    def end(self, device):
+        self.active = False
+        if (self.buf is None or self.need > self.buf.numel()) and self.need > 0 and not torch.cuda.is_current_stream_capturing():
+            self.buf = torch.empty(self.need, dtype=torch.uint8, device=device)      # the next step's arena
+
+
+_EAGER_ARENA = StepArena()
+_ARENA = None              # the arena of the step in progress (train_step / GraphedTrainStep set it), or None outside a step
+
+
+def _zeros(shape, dtype, device):
+    """(tensor, cleared-by-the-arena?) -- see StepArena.zeros"""
+    if _ARENA is not None:
+        return _ARENA.zeros(shape, dtype, device)
+    return torch.zeros(shape, dtype=dtype, device=device), False
+
+
+ops.zeros_hook = _zeros       # the Chamfer backward's two gradient buffers come from the step's arena too
+
+
 def _sums(C, device):
+    """2*C doubles of column-sum scratch and the flag the reduction takes: 4 when the step's arena has cleared them already"""
+    if _ARENA is not None:
+        t, pre = _ARENA.zeros(2 * C, torch.float64, device)
+        if pre:
+            return t, 4
     t = _SCRATCH.get((C, str(device)))
     if t is None:
         t = _SCRATCH[(C, str(device))] = torch.empty(2 * C, device=device, dtype=torch.float64)
-    return t
+    return t, 0
 
 
 def _packed(W, transpose):
@@ -59,10 +117,14 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias, ctx.wshape = b is not None, W.shape
         ctx.flags = 2 if _AUTOCAST else 0
         N, K = W2.shape
-        ctx.skinny = x.shape[0] <= 8 and K % 4 == 0          # a few rows: a weight stream, not matrix work (csrc/train.hip)
+        # a few rows: a weight stream, not matrix work (csrc/train.hip).  The kernels take 16-byte loads of x rows and W rows: row stride and
+        # base addresses are checked HERE (a (1, K) view keeps an arbitrary stride(0), a tensor with a storage offset can be misaligned) and
+        # anything else takes the generic layer, as before round 3.
+        ldx = K if x.shape[0] == 1 else x.stride(0)
+        ctx.skinny = (x.shape[0] <= 8 and K % 4 == 0 and ldx % 4 == 0 and ldx >= K and x.data_ptr() % 16 == 0 and W2.data_ptr() % 16 == 0)
         if ctx.skinny:
             out = torch.empty(x.shape[0], N, device=x.device, dtype=torch.float32)
-            _lib.call("pccx_linear_skinny", x.data_ptr(), x.shape[0], K, x.stride(0), W2.data_ptr(), b.data_ptr() if b is not None else None,
+            _lib.call("pccx_linear_skinny", x.data_ptr(), x.shape[0], K, ldx, W2.data_ptr(), b.data_ptr() if b is not None else None,
                       N, ctx.flags, out.data_ptr(), N, _stream())
             return out
         return _linear_raw(x, _packed(W2, False), b, N, K, ctx.flags)
@@ -75,16 +137,19 @@ class LinearFn(torch.autograd.Function):
         M = x.shape[0]
         dx = None
         if ctx.needs_input_grad[0] and ctx.skinny:
-            dx = torch.zeros(M, K, device=dz.device, dtype=torch.float32)
+            # split-K with fp32 atomics: under autocast the operands are rounded to bf16 as in the generic dX, the SUM is left in fp32 (the
+            # generic path rounds its result to bf16 as well; the per-layer pin of tests/test_train_step.py holds either to one bf16 ulp)
+            dx, _ = _zeros((M, K), torch.float32, dz.device)
             _lib.call("pccx_linear_skinny_dx", dz.data_ptr(), M, N, dz.stride(0), W2.data_ptr(), K, ctx.flags, dx.data_ptr(), K, _stream())
         elif ctx.needs_input_grad[0]:
             dx = _linear_raw(dz, _packed(W2, True), None, K, N, ctx.flags)                                       # dX = dZ . W
-        dW = torch.zeros_like(W2)
+        dW, _ = _zeros(tuple(W2.shape), torch.float32, dz.device)
         _lib.call("pccx_linear_dw", dz.data_ptr(), x.data_ptr(), M, N, K, N, x.stride(0), dW.data_ptr(), ctx.flags, _stream())
         db = None
         if ctx.has_bias:
-            db = torch.zeros(N, device=dz.device, dtype=torch.float32)
-            _lib.call("pccx_col_sum", dz.data_ptr(), M, N, _sums(N, dz.device).data_ptr(), db.data_ptr(), _stream())
+            db = torch.empty(N, device=dz.device, dtype=torch.float32)                                             # written, not accumulated
+            sums, pre = _sums(N, dz.device)
+            _lib.call("pccx_col_sum_w", dz.data_ptr(), M, N, sums.data_ptr(), db.data_ptr(), pre, _stream())
         return dx, dW.view(ctx.wshape), db
 
 
@@ -97,12 +162,14 @@ class BnReluFn(torch.autograd.Function):
         M, Cc = z.shape
         mean = torch.empty(Cc, device=z.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        _lib.call("pccx_bn_train_stats", z.data_ptr(), M, Cc, float(bn.eps), float(bn.momentum), _sums(Cc, z.device).data_ptr(),
-                  mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), _stream())
         y = torch.empty_like(z)
-        _lib.call("pccx_bn_relu_forward", z.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                  1, y.data_ptr(), _stream())
-        bn.num_batches_tracked += 1
+        sums, pre = _sums(Cc, z.device)
+        # moments, then ONE kernel that finalises them (mean, rstd, running statistics) and applies the layer (csrc/train.hip)
+        _lib.call("pccx_bn_relu_train_forward", z.data_ptr(), M, Cc, float(bn.eps), float(bn.momentum), sums.data_ptr(), gamma.data_ptr(),
+                  beta.data_ptr(), 1, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), y.data_ptr(),
+                  pre, _stream())
+        if _BN_COUNTED is None:
+            bn.num_batches_tracked += 1             # outside forward_train (which advances every counter of the model in one launch)
         ctx.save_for_backward(z, y, mean, rstd, gamma)
         return y
 
@@ -112,9 +179,10 @@ class BnReluFn(torch.autograd.Function):
         dy = dy.contiguous()
         M, Cc = z.shape
         dz = torch.empty_like(z)
-        gg, gb = torch.zeros_like(gamma), torch.zeros_like(gamma)
-        _lib.call("pccx_bn_relu_backward", dy.data_ptr(), y.data_ptr(), z.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
-                  gamma.data_ptr(), _sums(Cc, z.device).data_ptr(), dz.data_ptr(), gg.data_ptr(), gb.data_ptr(), _stream())
+        gg, gb = torch.empty_like(gamma), torch.empty_like(gamma)                    # written by the apply kernel's first workgroup
+        sums, pre = _sums(Cc, z.device)
+        _lib.call("pccx_bn_relu_train_backward", dy.data_ptr(), y.data_ptr(), z.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
+                  gamma.data_ptr(), sums.data_ptr(), dz.data_ptr(), gg.data_ptr(), gb.data_ptr(), pre, _stream())
         return dz, gg, gb, None
 
 
@@ -173,8 +241,8 @@ class GatherFn(torch.autograd.Function):
         B, N, Cc = ctx.shape
         dg = dg.contiguous()
         M = idx[0].numel()
-        df = torch.empty(B, N, Cc, device=dg.device, dtype=torch.float32)
-        _lib.call("pccx_gather_backward", dg.data_ptr(), Cc, idx.contiguous().data_ptr(), B, M, N, Cc, df.data_ptr(), _stream())
+        df, pre = _zeros((B, N, Cc), torch.float32, dg.device)
+        _lib.call("pccx_gather_backward_acc", dg.data_ptr(), Cc, idx.contiguous().data_ptr(), B, M, N, Cc, df.data_ptr(), 4, _stream())
         return df, None
 
 
@@ -244,10 +312,39 @@ def _sa_train(mod, xyz, feats, start, fps_idx=None):
 def forward_train(model, x, starts):
     """PointCloudAE.forward (pppe_pcd_ae.py:858-877) with BatchNorm in train mode.
     -> (coarse (B,512,3), fine (B,N,3), cond (B,512), y_q (B,d))."""
+    global _BN_COUNTED
     enc, dec = model.encoder, model.decoder
     B = x.shape[0]
     sa = enc.sa_modules
     outs, new_xyz = [], None
+    _BN_COUNTED = _advance_bn_counters(model, x.device)    # every BatchNorm's num_batches_tracked += 1, one launch
+    try:
+        return _forward_train_body(model, x, starts, enc, dec, B, sa, outs, new_xyz)
+    finally:
+        _BN_COUNTED = None
+
+
+_BN_COUNTED = None
+
+
+def _advance_bn_counters(model, device):
+    """num_batches_tracked += 1 for every BatchNorm of the model (what nn.BatchNorm does per forward in train mode, pppe_pcd_ae.py:556-568)
+    by ONE kernel over a device table of the counters' addresses, cached on the model and rebuilt when a buffer has moved."""
+    ctrs = [b for n, b in model.named_buffers() if n.endswith("num_batches_tracked") and b.device.type == "cuda"]
+    if not ctrs:
+        return None
+    ptrs = [int(b.data_ptr()) for b in ctrs]
+    cache = getattr(model, "_pccx_bn_table", None)
+    if cache is None or cache[0] != ptrs:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                      # no host-to-device copy inside a capture: the layers advance their own counters
+        cache = (ptrs, torch.tensor(ptrs, dtype=torch.int64, device=device))
+        model._pccx_bn_table = cache
+    _lib.call("pccx_add_i64_table", cache[1].data_ptr(), len(ptrs), 1, _stream())
+    return True
+
+
+def _forward_train_body(model, x, starts, enc, dec, B, sa, outs, new_xyz):
     brs = list(sa[0].branches)
     fps_of = [None] * len(brs)
     if len(brs) > 1 and all(b_.npoint == brs[0].npoint != x.shape[1] for b_ in brs):
@@ -378,7 +475,7 @@ class Adam:
             table[:len(live)].copy_(torch.from_numpy(rows))          # pageable source: the copy has completed when this returns
         acc = None
         if max_norm is not None:
-            acc = torch.zeros(1, device=dev, dtype=torch.float64)
+            acc, _ = _zeros(1, torch.float64, dev)
             _lib.call("pccx_sumsq_multi", table.data_ptr(), len(live), first, acc.data_ptr(), _stream())
         _lib.call("pccx_adam_multi", table.data_ptr(), len(live), first, acc.data_ptr() if acc is not None else None,
                   float(max_norm or 0.0), self.hyper.data_ptr() if capturable else None, float(self.lr), int(max(self.t, 1)),
@@ -430,6 +527,7 @@ class GraphedTrainStep:
         dev = batch_x.device
         self.model, self.opt, self.grad_clip, self.loss_type, self.autocast = model, opt, grad_clip, loss_type, autocast
         self.data_parallel, self.graph_opt = bool(data_parallel), None
+        self.arena = StepArena()            # this step's accumulation buffers: sized by the warm-up iterations, cleared by the graph's first node
         opt.make_capturable(dev)
         as_dev = lambda s_: torch.as_tensor(s_).to(device=dev, dtype=torch.int32).contiguous().clone()
         self.x = batch_x.detach().clone().contiguous()
@@ -452,7 +550,7 @@ class GraphedTrainStep:
             self._dp_grads = [p.grad for p in opt.params if p.grad is not None]      # fixed addresses: what the all-reduce averages
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
-                self.opt.step(max_norm=self.grad_clip)
+                self._opt_step()
         else:
             with torch.cuda.graph(self.graph):
                 self.out = self._body()
@@ -467,25 +565,38 @@ class GraphedTrainStep:
             p.grad = None
 
     def _fwd_bwd(self):
-        global _AUTOCAST
+        global _AUTOCAST, _ARENA
         for p in self.opt.params:
             p.grad = None
         _AUTOCAST = bool(self.autocast)
+        _ARENA = self.arena
+        self.arena.begin(self.x.device)
         try:
             coarse, fine, cond, y_q = forward_train(self.model, self.x, self.starts)
             fbpp = estimate_bits_per_point(self.model, y_q, cond.detach())
             loss, dist, rate = rd_loss(fine, self.x, fbpp, self.lam, self.loss_type)
+            _AUTOCAST = False
+            loss.backward()
         finally:
             _AUTOCAST = False
-        loss.backward()
+            _ARENA = None
         return loss.detach(), dist, rate
+
+    def _opt_step(self):
+        global _ARENA
+        _ARENA = self.arena                                          # Adam's norm accumulator comes from the same cleared buffer
+        try:
+            self.opt.step(max_norm=self.grad_clip)
+        finally:
+            _ARENA = None
+            self.arena.end(self.x.device)
 
     def _body(self):
         out = self._fwd_bwd()
         if self.data_parallel:                                       # warm-up iterations of a replica: average, then step
             from . import dist as pdist
             pdist.allreduce_mean_([p.grad for p in self.opt.params])
-        self.opt.step(max_norm=self.grad_clip)
+        self._opt_step()
         return out
 
     def __call__(self, batch_x=None, starts=None, lam=None, sync=True):
@@ -513,26 +624,33 @@ def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, data_paralle
     parameters as the reference's optimizer does; returns (loss, dist, rate) as python floats.
     data_parallel=True averages the gradients over the ranks of the default process group (bucketed
     all-reduce, dist.allreduce_mean_) between backward and the clipped Adam step."""
-    global _AUTOCAST
+    global _AUTOCAST, _ARENA
     for p in opt.params:
         p.grad = None
     _AUTOCAST = bool(autocast)              # the Linear layers of forward (and, through ctx.flags, of backward) take the bf16 form
+    _ARENA = _EAGER_ARENA if batch_x.is_cuda else None
+    if _ARENA is not None:
+        _ARENA.begin(batch_x.device)        # ONE clear for everything this step accumulates into (StepArena)
     try:
         coarse, fine, cond, y_q = forward_train(model, batch_x, starts)
         fbpp = estimate_bits_per_point(model, y_q, cond.detach())
         loss, dist, rate = rd_loss(fine.float(), batch_x.float(), fbpp, lam, loss_type)      # :205 casts back to fp32 for the loss
+        _AUTOCAST = False
+        if data_parallel:
+            # gradient averaging overlapped with backward: each bucket is all-reduced on a side stream as soon as its last gradient is
+            # written (dist.GradBuckets); the clipped Adam step waits for the last bucket
+            from . import dist as pdist
+            if getattr(opt, "_dp", None) is None:
+                opt._dp = pdist.GradBuckets(opt.params)
+            opt._dp.begin()
+            loss.backward()
+            opt._dp.finish()
+        else:
+            loss.backward()
+        opt.step(max_norm=grad_clip)
     finally:
         _AUTOCAST = False
-    if data_parallel:
-        # gradient averaging overlapped with backward: each bucket is all-reduced on a side stream as soon as its last gradient is
-        # written (dist.GradBuckets); the clipped Adam step waits for the last bucket
-        from . import dist as pdist
-        if getattr(opt, "_dp", None) is None:
-            opt._dp = pdist.GradBuckets(opt.params)
-        opt._dp.begin()
-        loss.backward()
-        opt._dp.finish()
-    else:
-        loss.backward()
-    opt.step(max_norm=grad_clip)
+        if _ARENA is not None:
+            _ARENA.end(batch_x.device)
+        _ARENA = None
     return float(loss.detach()), float(dist), float(rate)

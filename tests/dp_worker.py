@@ -1,0 +1,95 @@
+"""Worker of tests/test_gpu_dp.py: one of two ranks that SHARE cuda:0, process group over gloo with CUDA tensors (RCCL refuses two ranks
+on one device; the gloo collectives take the same code path through pccx.dist: event, side stream, all_reduce + in-place divide on
+p.grad, record_stream, finish()).  Prints one JSON line with the checks; exit code 0 only if it ran to the end."""
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "point-cloud-compression_amd"))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from pccx import families, train
+from tests import synth
+
+
+def local_grads(model, x, starts):
+    """gradients of ONE rank's loss on its own batch (no averaging, no optimiser step), from a copy of the model"""
+    m = copy.deepcopy(model)
+    for p in m.parameters():
+        p.grad = None
+    coarse, fine, cond, y_q = train.forward_train(m, x, starts)
+    fbpp = train.estimate_bits_per_point(m, y_q, cond.detach())
+    loss, _, _ = train.rd_loss(fine, x, fbpp, 1e-3, "chamfer")
+    loss.backward()
+    return [p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p) for p in m.parameters()]
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    N, B = 2048, 4
+    torch.manual_seed(5)
+    base = families.PointCloudAE(64, 16, N)
+    for k, v in base.state_dict().items():
+        if k.endswith("running_var"):
+            v.fill_(1.0)
+    base = base.cuda()
+    x = torch.from_numpy(synth.train_input(B * world, N)[rank * B:(rank + 1) * B].copy()).cuda()       # every rank its own clouds
+    rng = np.random.default_rng(7 + rank)
+    starts = [[rng.integers(0, N, B), rng.integers(0, N, B)], rng.integers(0, 512, B), rng.integers(0, 128, B)]
+    # reference: the mean over ranks of the local gradients (exchanged as CPU tensors), and the run-to-run noise of a local gradient
+    g_a, g_b = local_grads(base, x, starts), local_grads(base, x, starts)
+    noise = max(rel(a, b) for a, b in zip(g_a, g_b))
+    mean_ref = []
+    for g in g_a:
+        t = g.cpu()
+        dist.all_reduce(t)
+        mean_ref.append((t / world).cuda())
+    distinct = max(rel(a, m) for a, m in zip(g_a, mean_ref))            # the ranks' gradients really differ
+    res = {"rank": rank, "noise": noise, "local_vs_mean": distinct}
+    tol = max(2e-3, 30 * noise)
+
+    # 1. eager step with the overlapped buckets (GradBuckets' CUDA branch: side stream, in-place all_reduce on p.grad)
+    m1 = copy.deepcopy(base)
+    opt1 = train.Adam(m1.parameters(), lr=1e-4)
+    train.train_step(m1, opt1, x, starts, lam=1e-3, data_parallel=True)
+    res["buckets_launched"] = int(opt1._dp.launched)
+    res["side_stream"] = opt1._dp.side is not None
+    res["eager_grad_err"] = max(rel(p.grad, m) for p, m in zip(m1.parameters(), mean_ref))
+    flat = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    res["eager_params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
+
+    # 2. the captured step: two graphs around the all-reduce (warmup=0: the first replay starts from the same state)
+    m2 = copy.deepcopy(base)
+    opt2 = train.Adam(m2.parameters(), lr=1e-4)
+    gs = train.GraphedTrainStep(m2, opt2, x, starts, lam=1e-3, warmup=0, data_parallel=True)
+    gs(sync=False)
+    torch.cuda.synchronize()
+    res["graph_grad_err"] = max(rel(g, m) for g, m in zip(gs._dp_grads, mean_ref))
+    flat2 = torch.cat([p.detach().reshape(-1) for p in m2.parameters()]).cpu()
+    both2 = [torch.zeros_like(flat2) for _ in range(world)]
+    dist.all_gather(both2, flat2)
+    res["graph_params_equal_across_ranks"] = bool(torch.equal(both2[0], both2[1]))
+    res["graph_vs_eager_params"] = float((flat2 - flat).abs().max())
+    res["tol"] = tol
+    res["ok"] = bool(res["eager_grad_err"] <= tol and res["graph_grad_err"] <= tol and res["eager_params_equal_across_ranks"]
+                     and res["graph_params_equal_across_ranks"] and res["side_stream"] and res["buckets_launched"] >= 2 and distinct > 10 * tol)
+    print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""GPU: the data-parallel training step with world size 2 on CUDA tensors (advisor finding, round 3: GradBuckets' CUDA branch and the
+two-graph step had only ever run with the all-reduce as a no-op).  Two fresh child processes share cuda:0 over a gloo process group
+(RCCL refuses two ranks on one device; multi-GPU RCCL runs are the driver's): tests/dp_worker.py drives train_step(data_parallel=True)
+and GraphedTrainStep(data_parallel=True) and compares each rank's averaged gradients with the mean of the two ranks' local gradients."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_gpu_average_their_gradients_in_both_step_forms():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=420)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:                       # by the exact PIDs started here
+            if p.poll() is None:
+                p.kill()
+    for rc, o, e in outs:
+        assert rc == 0, (o[-1500:], e[-3000:])
+    res = [json.loads([l for l in o.splitlines() if l.startswith("{")][-1]) for _, o, _ in outs]
+    for r in res:
+        assert r["ok"], r
+        assert r["local_vs_mean"] > 10 * r["tol"]          # the test would pass trivially if both ranks had the same gradients
+    assert {r["rank"] for r in res} == {0, 1}

@@ -1,5 +1,5 @@
 // Minimal reproducer for the round-3 hipGraph hazard, independent of torch and of libpccx (round 4).
-//   chain captured from ONE stream, 48 links:   hipMemsetAsync(sums) -> accumulate(sums += x_l) -> finalize(out_l = sums)
+//   chain captured from ONE stream, LINKS links (-DLINKS=256 -DROWS=512 -DBIG for a graph of the training step's size, with a 4 MB memset per link too):   hipMemsetAsync(sums) -> accumulate(sums += x_l) -> finalize(out_l = sums)
 // `sums` is one buffer reused by every link, as the training step's column-sum scratch is.  The program prints the graph's nodes and
 // edges (hipGraphGetNodes / hipGraphGetEdges: is every memset node ordered after the previous finalize and before its accumulate?),
 // then replays the graph back to back and after idle gaps (a host sleep + a small unrelated kernel on the stream) and checks every
@@ -11,7 +11,13 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-constexpr int C = 256, ROWS = 4096, LINKS = 48;
+#ifndef LINKS
+#define LINKS 48
+#endif
+#ifndef ROWS
+#define ROWS 4096
+#endif
+constexpr int C = 256;
 
 __global__ void accumulate(float *sums, const float *x, int rows)
 {
@@ -33,6 +39,8 @@ int main()
     CHECK(hipMalloc(&sums, C * 4));
     CHECK(hipMalloc(&out, (size_t)LINKS * C * 4));
     CHECK(hipMalloc(&other, C * 4));
+    float *big;
+    CHECK(hipMalloc(&big, (size_t)4 << 20));
     std::vector<float> hx((size_t)LINKS * ROWS * C);
     unsigned s = 12345u;
     for (auto &v : hx) { s = s * 1664525u + 1013904223u; v = (float)((s >> 20) & 7); }          // small integers: every partial sum is exact
@@ -49,6 +57,10 @@ int main()
         hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(C), 0, st, sums);
 #else
         CHECK(hipMemsetAsync(sums, 0, C * 4, st));
+#endif
+#ifdef BIG
+        CHECK(hipMemsetAsync(big, 0, (size_t)4 << 20, st));          // a large clear, as the scatter-add outputs of the step have
+        hipLaunchKernelGGL(touch, dim3(1), dim3(C), 0, st, big + (l % 1000) * C);
 #endif
         hipLaunchKernelGGL(accumulate, dim3(64), dim3(C), 0, st, sums, x + (size_t)l * ROWS * C, ROWS);
         hipLaunchKernelGGL(finalize, dim3(1), dim3(C), 0, st, sums, out + (size_t)l * C);
