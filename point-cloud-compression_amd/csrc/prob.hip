@@ -81,6 +81,12 @@ __global__ __launch_bounds__(256, 2) void prob_forward_kernel(const float *__res
             // clamped tile and discards the result: the ring's barriers need every wave), streamed L2 -> LDS three chunks ahead.
             const float *bl = opaque_uniform(blob);
             ws.g = bl + PRB_STREAM;
+            // this pass's lane indices from a laundered lane id: nothing computed for pass 1 or for the softmax below is carried through
+            // the 160 accumulator registers of the two wide layers (round 3: ten values spilled to scratch around them)
+            int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane2));
+            const int g = lane2 >> 4, n = lane2 & 15;
+            ws.lane = lane2;
             const int c = (tile < ntiles ? tile : ntiles - 1) * 16 + n;
             int f = 0;
             f32x4 a0[1][32];

@@ -57,72 +57,106 @@ template <bool BF16, int TN, int TK>
 __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict__ dZ, const float *__restrict__ X, long M, int N,
                                                         int K, int ldz, int ldx, int rows_per_slice, float *__restrict__ dW)
 {
+    // One workgroup = one (16 TN) x (16 TK) tile of dW and one row slice; its four waves take a quarter of the slice's rows each and
+    // add their partial tiles through LDS, so the slice ends with ONE fp32 atomic per element (round 3: every wave owned a tile and a
+    // slice of its own and 1024 slices x N x K same-address atomics were most of the kernel -- 4 M for a 64 x 64 layer).
+    extern __shared__ float dw_red[];                                  // [4 waves][TN * TK tiles][256]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int nt0 = blockIdx.x * TN, kt0 = (blockIdx.y * 4 + w) * TK;
-    if (kt0 * 16 >= K) return;
-    const long m0 = (long)blockIdx.z * rows_per_slice;
-    const long m1 = m0 + rows_per_slice < M ? m0 + rows_per_slice : M;
+    const int nt0 = blockIdx.x * TN, kt0 = blockIdx.y * TK;
+    const long s0 = (long)blockIdx.z * rows_per_slice;
+    const long s1 = s0 + rows_per_slice < M ? s0 + rows_per_slice : M;
+    const long per = ((s1 - s0 + 3) / 4 + 3) / 4 * 4;                  // rows per wave, a multiple of the MFMA's four
+    const long m0 = s0 + w * per;
+    const long m1 = m0 + per < s1 ? m0 + per : s1;
     f32x4 acc[TN][TK];
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long m = m0; m < m1; m += 4) {
-        const long mm = m + g;                                       // MFMA k index = row within the 4-row step
-        const bool row_ok = mm < m1;
-        float av[TN], bv[TK];
+    // U steps of four rows per trip: the U (TN + TK) operand loads of a trip are issued before its first MFMA (one step per trip exposed
+    // an HBM latency per 16 MFMAs).  The MFMAs of a tile still see the wave's rows in ascending order.
+    constexpr int U = (TN + TK <= 4) ? 8 : 4;
+    for (long m = m0; m < m1; m += 4 * U) {
+        float av[U][TN], bv[U][TK];
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int n = (nt0 + a) * 16 + c;
-            av[a] = (row_ok && n < N) ? dZ[(size_t)mm * ldz + n] : 0.f;          // A[i = n][k = g]
-            if (BF16) av[a] = round_bf16(av[a]);
+        for (int u = 0; u < U; ++u) {
+            const long mm = m + 4 * u + g;                           // MFMA k index = row within the 4-row step
+            const bool row_ok = mm < m1;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = (nt0 + a) * 16 + c;
+                av[u][a] = (row_ok && n < N) ? dZ[(size_t)mm * ldz + n] : 0.f;      // A[i = n][k = g]
+            }
+#pragma unroll
+            for (int b = 0; b < TK; ++b) {
+                const int k = (kt0 + b) * 16 + c;
+                bv[u][b] = (row_ok && k < K) ? X[(size_t)mm * ldx + k] : 0.f;       // B[k = g][j = k]
+            }
         }
 #pragma unroll
-        for (int b = 0; b < TK; ++b) {
-            const int k = (kt0 + b) * 16 + c;
-            bv[b] = (row_ok && k < K) ? X[(size_t)mm * ldx + k] : 0.f;           // B[k = g][j = k]
-            if (BF16) bv[b] = round_bf16(bv[b]);
+        for (int u = 0; u < U; ++u) {
+            if (BF16) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) av[u][a] = round_bf16(av[u][a]);
+#pragma unroll
+                for (int b = 0; b < TK; ++b) bv[u][b] = round_bf16(bv[u][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(av[u][a], bv[u][b], acc[a][b]);
         }
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(av[a], bv[b], acc[a][b]);
     }
-    // D[i = n-row 4g+r][j = k-col c]
+    // partial tiles to LDS; wave w then owns tiles w, w + 4, ...: the four partials in wave order, one atomic per element
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TK; ++b) {
-            const int k = (kt0 + b) * 16 + c;
+        for (int b = 0; b < TK; ++b) *(f32x4 *)(dw_red + ((size_t)(w * TN * TK + a * TK + b) * 64 + lane) * 4) = acc[a][b];
+    __syncthreads();
+    for (int t = w; t < TN * TK; t += 4) {
+        const int a = t / TK, b = t % TK;
+        f32x4 v = *(const f32x4 *)(dw_red + ((size_t)t * 64 + lane) * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nn = (nt0 + a) * 16 + 4 * g + r;
-                if (nn < N && k < K) atomicAdd(&dW[(size_t)nn * K + k], acc[a][b][r]);
-            }
+        for (int q = 1; q < 4; ++q) {
+            const f32x4 o = *(const f32x4 *)(dw_red + ((size_t)(q * TN * TK + t) * 64 + lane) * 4);
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
         }
+        // D[i = n-row 4g+r][j = k-col c]
+        const int k = (kt0 + b) * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = (nt0 + a) * 16 + 4 * g + r;
+            if (nn < N && k < K) atomicAdd(&dW[(size_t)nn * K + k], v[r]);
+        }
+    }
 }
 
 template <int TN, int TK>
 static int launch_dw(const float *dZ, const float *X, int64_t M, int N, int K, int ldz, int ldx, float *dW, int flags, hipStream_t st)
 {
     const int nt = (N + 15) / 16, kt = (K + 15) / 16;
-    // enough row slices to fill the chip: tiles x slices >= ~2048 waves, each slice at least 64 rows
+    // tiles x slices ~ 512 workgroups (two per CU), each slice at least 256 rows (64 per wave): the atomics are slices x N x K
     const int tiles = ((nt + TN - 1) / TN) * ((kt + TK - 1) / TK);
-    int slices = (2048 + tiles - 1) / tiles;
-    const int max_slices = (int)((M + 63) / 64);
+    int slices = (512 + tiles - 1) / tiles;
+    const int max_slices = (int)((M + 255) / 256);
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     if (slices > 1024) slices = 1024;
     int rps = (int)((M + slices - 1) / slices);
-    rps = (rps + 3) / 4 * 4;
+    rps = (rps + 15) / 16 * 16;
     slices = (int)((M + rps - 1) / rps);
-    dim3 grid((nt + TN - 1) / TN, ((kt + TK - 1) / TK + 3) / 4, slices);
+    dim3 grid((nt + TN - 1) / TN, (kt + TK - 1) / TK, slices);
     PCCX_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "pccx_linear_dw: shape too large");
+    const size_t lds = (size_t)4 * TN * TK * 256 * sizeof(float);
+    if (lds > 48 * 1024) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_dw_kernel<true, TN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_dw_kernel<false, TN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (flags & 2)
-        hipLaunchKernelGGL((linear_dw_kernel<true, TN, TK>), grid, dim3(256), 0, st, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
+        hipLaunchKernelGGL((linear_dw_kernel<true, TN, TK>), grid, dim3(256), lds, st, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
     else
-        hipLaunchKernelGGL((linear_dw_kernel<false, TN, TK>), grid, dim3(256), 0, st, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
+        hipLaunchKernelGGL((linear_dw_kernel<false, TN, TK>), grid, dim3(256), lds, st, dZ, X, (long)M, N, K, ldz, ldx, rps, dW);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

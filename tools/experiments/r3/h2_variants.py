@@ -56,11 +56,29 @@ extern "C" __attribute__((visibility("default"))) const char *encv_last_error(vo
 FILES = ["encoder_fused_h2.hip", "decoder_h2.hip", "decoder.hip", "patch_knn.hip"]
 
 
+# A diagnostic patch may not remove a PRODUCER and keep its consumers: the builds of round 3 that deleted the LDS-DMA (the weight ring was
+# then never written, its reads undefined to the compiler) ended in a GPU memory fault on the box (gpurun_out/r3l/variants4.log).  Such a
+# variant is refused here unless it also patches every reader of what it no longer writes.
+PRODUCERS = {"__builtin_amdgcn_global_load_lds": ("ds_read_b128", "ws.chunk(", "ws.get(", "buf[")}
+
+
+def check_variant(tag, patches):
+    for pf, old, new in [x for x in patches if x[0] != "@git"]:
+        for prod, consumers in PRODUCERS.items():
+            if prod in old and prod not in new:
+                touched = [c for c in consumers if any(c in o and (c not in n_ or o != n_) for _, o, n_ in [x for x in patches if x[0] != "@git"] if o is not old)]
+                if len(touched) < len(consumers):
+                    raise SystemExit(f"variant {tag!r} removes {prod} (the producer of the LDS weight ring) but leaves readers of the ring in place "
+                                     f"({sorted(set(consumers) - set(touched))}): the ring would be read uninitialised -- refused (a round-3 build of "
+                                     f"this kind faulted on the GPU box).  Separate the phases instead (onlysa / onlypn) or patch the readers too.")
+
+
 def build(tags):
     os.makedirs(OUT, exist_ok=True)
     procs = []
     for t in tags:
         flags, patches = VARIANTS[t]
+        check_variant(t, patches)
         d = os.path.join(OUT, "h2_" + t)
         os.makedirs(d, exist_ok=True)
         open(os.path.join(d, "stub.hip"), "w").write(STUB)
