@@ -1,6 +1,16 @@
 """Worker of tests/test_gpu_dp.py: one of two ranks that SHARE cuda:0, process group over gloo with CUDA tensors (RCCL refuses two ranks
 on one device; the gloo collectives take the same code path through pccx.dist: event, side stream, all_reduce + in-place divide on
-p.grad, record_stream, finish()).  Prints one JSON line with the checks; exit code 0 only if it ran to the end."""
+p.grad, record_stream, finish()).  Prints one JSON line with the checks; exit code 0 only if it ran to the end.
+
+What is checked is the MECHANICS of the data-parallel step, not a gradient value (on this small model the gradient of one batch
+moves by tens of percent from run to run -- a latent that sits on a rounding boundary of the quantiser flips --, so "equals the mean of
+two separately computed local gradients" cannot be asserted tightly): every all_reduce the step issues is recorded (a clone of its input
+before, its tensor after the in-place average), the inputs are exchanged between the ranks, and
+  * each averaged tensor equals the mean over ranks of what the ranks put in (to fp32 rounding),
+  * the ranks' inputs really differ (the check is not vacuous),
+  * after the step every parameter's .grad and every parameter is BIT-IDENTICAL on the two ranks (a gradient that missed its
+    bucket, or a bucket averaged before its last gradient was written, would differ),
+  * the eager step used the side stream and several buckets; the captured step is two graphs around the exchange."""
 import copy
 import json
 import os
@@ -16,21 +26,40 @@ import torch.distributed as dist
 from pccx import families, train
 from tests import synth
 
-
-def local_grads(model, x, starts):
-    """gradients of ONE rank's loss on its own batch (no averaging, no optimiser step), from a copy of the model"""
-    m = copy.deepcopy(model)
-    for p in m.parameters():
-        p.grad = None
-    coarse, fine, cond, y_q = train.forward_train(m, x, starts)
-    fbpp = train.estimate_bits_per_point(m, y_q, cond.detach())
-    loss, _, _ = train.rd_loss(fine, x, fbpp, 1e-3, "chamfer")
-    loss.backward()
-    return [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]      # the live gradients, in parameter order (as Adam.step keeps them)
+RECORD = []
+_real_all_reduce = dist.all_reduce
 
 
-def rel(a, b):
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+def _recording_all_reduce(t, *a, **k):
+    pre = t.detach().clone()
+    r = _real_all_reduce(t, *a, **k)
+    RECORD.append((pre, t))
+    return r
+
+
+def same_on_all_ranks(tensors, world):
+    flat = torch.cat([t.detach().reshape(-1).float() for t in tensors]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    _real_all_reduce_gather(both, flat)
+    return bool(all(torch.equal(both[0], b) for b in both[1:]))
+
+
+def _real_all_reduce_gather(out, t):
+    dist.all_gather(out, t)
+
+
+def check_records(world):
+    """(worst relative error of averaged-vs-mean-of-inputs over the recorded calls, largest relative spread of the inputs, calls)"""
+    worst, spread = 0.0, 0.0
+    for pre, post in RECORD:
+        mine = pre.reshape(-1).cpu()
+        all_pre = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(all_pre, mine)
+        mean = torch.stack(all_pre).double().mean(0).float()
+        scale = float(mean.abs().max()) + 1e-30
+        worst = max(worst, float((post.detach().reshape(-1).cpu() - mean).abs().max()) / scale)
+        spread = max(spread, float((all_pre[0] - all_pre[1]).abs().max()) / scale)
+    return worst, spread, len(RECORD)
 
 
 def main():
@@ -47,48 +76,39 @@ def main():
     x = torch.from_numpy(synth.train_input(B * world, N)[rank * B:(rank + 1) * B].copy()).cuda()       # every rank its own clouds
     rng = np.random.default_rng(7 + rank)
     starts = [[rng.integers(0, N, B), rng.integers(0, N, B)], rng.integers(0, 512, B), rng.integers(0, 128, B)]
-    # reference: the mean over ranks of the local gradients (exchanged as CPU tensors), and the run-to-run noise of a local gradient
-    g_a, g_b = local_grads(base, x, starts), local_grads(base, x, starts)
-    noise = max(rel(a, b) for a, b in zip(g_a, g_b))
-    mean_ref = []
-    for g in g_a:
-        t = g.cpu()
-        dist.all_reduce(t)
-        mean_ref.append((t / world).cuda())
-    distinct = max(rel(a, m) for a, m in zip(g_a, mean_ref))            # the ranks' gradients really differ
-    res = {"rank": rank, "noise": noise, "local_vs_mean": distinct}
-    tol = max(2e-3, 30 * noise)
+    res = {"rank": rank}
+    dist.all_reduce = _recording_all_reduce                  # pccx.dist calls torch.distributed.all_reduce by attribute
 
     # 1. eager step with the overlapped buckets (GradBuckets' CUDA branch: side stream, in-place all_reduce on p.grad)
     m1 = copy.deepcopy(base)
     opt1 = train.Adam(m1.parameters(), lr=1e-4)
+    RECORD.clear()
     train.train_step(m1, opt1, x, starts, lam=1e-3, data_parallel=True)
+    torch.cuda.synchronize()
     res["buckets_launched"] = int(opt1._dp.launched)
     res["side_stream"] = opt1._dp.side is not None
-    live1 = [p.grad for p in m1.parameters() if p.grad is not None]
-    assert len(live1) == len(mean_ref), (len(live1), len(mean_ref))
-    res["eager_grad_err"] = max(rel(g, m) for g, m in zip(live1, mean_ref))
-    flat = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu()
-    both = [torch.zeros_like(flat) for _ in range(world)]
-    dist.all_gather(both, flat)
-    res["eager_params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
+    res["eager_avg_err"], res["eager_input_spread"], res["eager_calls"] = check_records(world)
+    n_grad = sum(p.grad.numel() for p in m1.parameters() if p.grad is not None)
+    res["eager_covered"] = sum(pre.numel() for pre, _ in RECORD) == n_grad          # every gradient element went through exactly one all_reduce
+    res["eager_grads_equal_across_ranks"] = same_on_all_ranks([p.grad for p in m1.parameters() if p.grad is not None], world)
+    res["eager_params_equal_across_ranks"] = same_on_all_ranks(list(m1.parameters()), world)
 
     # 2. the captured step: two graphs around the all-reduce (warmup=0: the first replay starts from the same state)
     m2 = copy.deepcopy(base)
     opt2 = train.Adam(m2.parameters(), lr=1e-4)
     gs = train.GraphedTrainStep(m2, opt2, x, starts, lam=1e-3, warmup=0, data_parallel=True)
+    RECORD.clear()
     gs(sync=False)
     torch.cuda.synchronize()
-    assert len(gs._dp_grads) == len(mean_ref), (len(gs._dp_grads), len(mean_ref))
-    res["graph_grad_err"] = max(rel(g, m) for g, m in zip(gs._dp_grads, mean_ref))
-    flat2 = torch.cat([p.detach().reshape(-1) for p in m2.parameters()]).cpu()
-    both2 = [torch.zeros_like(flat2) for _ in range(world)]
-    dist.all_gather(both2, flat2)
-    res["graph_params_equal_across_ranks"] = bool(torch.equal(both2[0], both2[1]))
-    res["graph_vs_eager_params"] = float((flat2 - flat).abs().max())
-    res["tol"] = tol
-    res["ok"] = bool(res["eager_grad_err"] <= tol and res["graph_grad_err"] <= tol and res["eager_params_equal_across_ranks"]
-                     and res["graph_params_equal_across_ranks"] and res["side_stream"] and res["buckets_launched"] >= 2 and distinct > 10 * tol)
+    res["graph_avg_err"], res["graph_input_spread"], res["graph_calls"] = check_records(world)
+    res["graph_covered"] = sum(pre.numel() for pre, _ in RECORD) == sum(g.numel() for g in gs._dp_grads)
+    res["graph_grads_equal_across_ranks"] = same_on_all_ranks(gs._dp_grads, world)
+    res["graph_params_equal_across_ranks"] = same_on_all_ranks(list(m2.parameters()), world)
+    res["two_graphs"] = gs.graph_opt is not None
+    res["ok"] = bool(res["eager_avg_err"] <= 1e-5 and res["graph_avg_err"] <= 1e-5 and res["eager_input_spread"] > 1e-2 and res["graph_input_spread"] > 1e-2
+                     and res["eager_covered"] and res["graph_covered"] and res["eager_grads_equal_across_ranks"]
+                     and res["graph_grads_equal_across_ranks"] and res["eager_params_equal_across_ranks"]
+                     and res["graph_params_equal_across_ranks"] and res["side_stream"] and res["buckets_launched"] >= 2 and res["two_graphs"])
     print(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()

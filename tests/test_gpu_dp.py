@@ -1,7 +1,9 @@
 """GPU: the data-parallel training step with world size 2 on CUDA tensors (advisor finding, round 3: GradBuckets' CUDA branch and the
 two-graph step had only ever run with the all-reduce as a no-op).  Two fresh child processes share cuda:0 over a gloo process group
 (RCCL refuses two ranks on one device; multi-GPU RCCL runs are the driver's): tests/dp_worker.py drives train_step(data_parallel=True)
-and GraphedTrainStep(data_parallel=True) and compares each rank's averaged gradients with the mean of the two ranks' local gradients."""
+and GraphedTrainStep(data_parallel=True), records every all_reduce the steps issue and checks that each averaged tensor is the mean of what
+the two ranks put in, that every gradient element went through exactly one all_reduce, and that gradients and parameters end up
+bit-identical on both ranks."""
 import json
 import os
 import socket
@@ -38,6 +40,6 @@ def test_two_ranks_on_one_gpu_average_their_gradients_in_both_step_forms():
         assert rc == 0, (o[-1500:], e[-3000:])
     res = [json.loads([l for l in o.splitlines() if l.startswith("{")][-1]) for _, o, _ in outs]
     for r in res:
-        assert r["ok"], r
-        assert r["local_vs_mean"] > 10 * r["tol"]          # the test would pass trivially if both ranks had the same gradients
+        assert r["ok"], json.dumps(r)
+        assert r["eager_input_spread"] > 1e-2              # the ranks' gradients differ: the averaging check is not vacuous
     assert {r["rank"] for r in res} == {0, 1}
