@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
     // Everything the tail needs per lane (tile and patch indices, bias / latent / output addresses, the patch scales) is derived HERE from a
     // laundered thread id and re-read from L2, not carried through the GEMM loop: the loop holds 224 registers of accumulators and operand
     // planes, and values computed in the prologue for the tail were spilled around it (41 VGPRs, 152 B of scratch per lane, round 3).
+#ifdef DEC_TAIL_PRIO                 // experiment knob (round 4): issue priority of the VALU-heavy tail over the other workgroup's GEMM waves
+    __builtin_amdgcn_s_setprio(DEC_TAIL_PRIO);
+#endif
     int lane_t = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane_t));
     const int g_t = lane_t >> 4, n_t = lane_t & 15;
