@@ -64,6 +64,20 @@ def stage_kernel(stage, matmul):
     return STAGE_KERNEL_H2.get(stage, STAGE_KERNEL[stage]) if matmul == "f16x2" else STAGE_KERNEL[stage]
 
 
+# the instantiation each mode launches at the bench shape (K = 256): the key of a kernel in profiles/round4*_traffic.json, whose PMC passes
+# run all modes at once (older files are keyed by the bare name)
+STAGE_KERNEL_FULL = {"f32": {"sa_forward": "sa_forward_kernel<false>", "pn_forward": "pn_forward_kernel<2>", "ae_decode": "dec_main_kernel<false, 2>"},
+                     "bf16x3": {"sa_pn_forward": "sa_pn_forward_b3_kernel<true>", "ae_decode": "dec_main_kernel<true, 2>"},
+                     "f16x2": {"sa_pn_forward": "sa_pn_forward_h2_kernel<true>", "ae_decode": "dec_main_h2_kernel<4>"}}
+
+
+def _traffic_entry(kernels, stage, matmul):
+    full = STAGE_KERNEL_FULL.get(matmul, {}).get(stage)
+    if full in kernels:
+        return kernels[full]
+    return kernels[stage_kernel(stage, matmul)]          # KeyError -> the caller tries the next (older) file
+
+
 def committed_traffic(stage, batch, matmul="bf16x3"):
     """HBM bytes per launch of the stage's kernel, NOT measured in this run: read from the newest committed rocprofv3
     --pmc pass (profiles/round*_traffic.json, separate passes, gfx950 corrections applied) and scaled linearly from the
@@ -72,7 +86,7 @@ def committed_traffic(stage, batch, matmul="bf16x3"):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
         try:
             j = json.load(open(path))
-            t = j["kernels"][stage_kernel(stage, matmul)]
+            t = _traffic_entry(j["kernels"], stage, matmul)
             return int(t["hbm_bytes_per_launch"] * batch / j.get("batch", 256)), "scaled from committed PMC pass " + os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
@@ -85,8 +99,10 @@ def committed_traffic_of(kernel, batch):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
         try:
             j = json.load(open(path))
-            return int(j["kernels"][kernel]["hbm_bytes_per_launch"] * batch / j.get("batch", 256)), os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
+            ks = j["kernels"]
+            t = ks[kernel] if kernel in ks else next(v for k_, v in ks.items() if k_.split("<")[0] == kernel)
+            return int(t["hbm_bytes_per_launch"] * batch / j.get("batch", 256)), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, StopIteration):
             continue
     return None, None
 
@@ -97,7 +113,7 @@ def committed_pmc(stage, matmul="bf16x3"):
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), reverse=True):
         try:
-            t = json.load(open(path))["kernels"][stage_kernel(stage, matmul)]
+            t = _traffic_entry(json.load(open(path))["kernels"], stage, matmul)
             if "mfma_pipe_busy" in t:
                 return {"mfma_pipe_busy": round(t["mfma_pipe_busy"], 4), "clock_ghz_under_load": round(t.get("clock_ghz_under_load", 0.0), 3) or None,
                         "peak_quoted_at_ghz": 2.4, "source": "committed PMC pass " + os.path.relpath(path, ROOT)}

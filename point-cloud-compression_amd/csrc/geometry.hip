@@ -150,7 +150,11 @@ extern "C" int pccx_gather(const float *points, int B, int N, int C, const int64
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
 {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    // selects, not a branch: as an `if` this compiled to an exec-mask region with a scalar branch per merge -- 12 s_and_saveexec and six
+    // s_cbranch in every round of FPS, on the round's serial path
+    const bool take = (ov > v) | ((ov == v) & (oi < i));
+    v = take ? ov : v;
+    i = take ? oi : i;
 }
 
 // Wave-wide argmax of (value, index) pairs with torch.max's tie rule (largest value, then smallest index), without LDS traffic:
@@ -172,6 +176,48 @@ __device__ __forceinline__ void row16_argmax(float &v, int &i)
 #undef PCCX_DPP_STEP
 }
 
+// The same reductions on ONE 64-bit key per candidate: (distance bits << 32) | (0x7fffffff - index).  Distances are non-negative floats
+// (their bit patterns order like the values; a padding lane's -inf becomes 0), so the larger key is the larger distance and, among equal
+// distances, the SMALLER index: torch.max's rule with one 64-bit compare and two selects per merge instead of three compares, two
+// scalar mask operations and two selects -- these merges are the serial path of an FPS round.
+__device__ __forceinline__ unsigned long long argmax_key(float v, int i)
+{
+    const unsigned hi = v < 0.f ? 0u : __float_as_uint(v);
+    return ((unsigned long long)hi << 32) | (unsigned)(0x7fffffff - i);
+}
+__device__ __forceinline__ int argmax_key_index(unsigned long long k) { return 0x7fffffff - (int)(unsigned)(k & 0xffffffffu); }
+
+__device__ __forceinline__ unsigned long long row16_argmax_key(unsigned long long k)
+{
+#define PCCX_DPP_STEP64(CTRL)                                                                                          \
+    {                                                                                                                  \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xf, 0xf, true);         \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xf, 0xf, true); \
+        const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;                                           \
+        k = ok > k ? ok : k;                                                                                           \
+    }
+    PCCX_DPP_STEP64(0x140)   // row_mirror
+    PCCX_DPP_STEP64(0x141)   // row_half_mirror
+    PCCX_DPP_STEP64(0x1B)    // quad_perm [3,2,1,0]
+    PCCX_DPP_STEP64(0xB1)    // quad_perm [1,0,3,2]
+#undef PCCX_DPP_STEP64
+    return k;
+}
+
+__device__ __forceinline__ unsigned long long wave_argmax_key(unsigned long long k)
+{
+    k = row16_argmax_key(k);
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 16 * r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 16 * r);
+        const unsigned long long rk = ((unsigned long long)hi << 32) | lo;
+        best = rk > best ? rk : best;
+    }
+    return best;
+}
+
 __device__ __forceinline__ void wave_argmax(float &v, int &i)
 {
     row16_argmax(v, i);
@@ -187,14 +233,15 @@ __device__ __forceinline__ void wave_argmax(float &v, int &i)
     for (int r = 1; r < 4; ++r) argmax_merge(v, i, rv[r], ri[r]);
 }
 
-template <int PPT>
+// USE_LDS (the cloud's copy fits the LDS) is a template parameter: as a run-time flag the round's one load of the winner's coordinates
+// -- `use_lds ? sx + 3 far : p + 3 far` -- became a FLAT load (one pointer that may be LDS or global), whose round trip waits on both
+// memory counters; it sits on the serial path of every round.
+template <int PPT, bool USE_LDS>
 __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
-                                                   const int32_t *__restrict__ start, int64_t *__restrict__ out,
-                                                   int use_lds)
+                                                   const int32_t *__restrict__ start, int64_t *__restrict__ out)
 {
     extern __shared__ float smem[];
-    float *part_v = smem;                 // [2][16]
-    int *part_i = (int *)(smem + 32);     // [2][16]
+    unsigned long long *part_k = (unsigned long long *)smem;   // [2][16] wave winners as 64-bit keys (argmax_key)
     float *sx = smem + 64;                // [3N] when use_lds
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *p = xyz + (size_t)b * N * 3;
@@ -218,7 +265,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
                 md[j][e] = -INFINITY;          // never selected
             }
         }
-    if (use_lds)
+    if (USE_LDS)
         for (int i = tid; i < 3 * N; i += 1024) sx[i] = p[i];
     __syncthreads();
 
@@ -227,8 +274,9 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
     int par = 0;
     for (int s = 0; s < npoint; ++s) {
         if (tid == 0) out[(size_t)b * npoint + s] = far;             // centroids[:, i] = farthest (:324)
-        const float *cp = use_lds ? sx + 3 * far : p + 3 * far;
-        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        float cx, cy, cz;
+        if (USE_LDS) { cx = sx[3 * far]; cy = sx[3 * far + 1]; cz = sx[3 * far + 2]; }
+        else { cx = p[3 * far]; cy = p[3 * far + 1]; cz = p[3 * far + 2]; }
         float best = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
@@ -239,17 +287,17 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
             d = d + dz * dz;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                if (d[e] < md[j][e]) md[j][e] = d[e];                         // (:327-328)
-                if (md[j][e] > best) { best = md[j][e]; bi = tid + (2 * j + e) * 1024; }   // ascending index, strict '>'
+                md[j][e] = fminf(md[j][e], d[e]);                             // (:327-328) distance[mask] = dist[mask]: one v_min_f32
+                const bool up = md[j][e] > best;                              // ascending index, strict '>'
+                best = up ? md[j][e] : best;
+                bi = up ? tid + (2 * j + e) * 1024 : bi;
             }
         }
-        wave_argmax(best, bi);
-        if (lane == 0) { part_v[par * 16 + w] = best; part_i[par * 16 + w] = bi; }
+        const unsigned long long wk = wave_argmax_key(argmax_key(best, bi));
+        if (lane == 0) part_k[par * 16 + w] = wk;
         __syncthreads();
-        float v = part_v[par * 16 + (lane & 15)];                     // the 16 wave winners, one per lane of every row
-        int vi = part_i[par * 16 + (lane & 15)];
-        row16_argmax(v, vi);
-        far = __builtin_amdgcn_readfirstlane(vi);                     // torch.max(distance,-1)[1] (:329)
+        const unsigned long long vk = row16_argmax_key(part_k[par * 16 + (lane & 15)]);   // the 16 wave winners, one per lane of every row
+        far = __builtin_amdgcn_readfirstlane(argmax_key_index(vk));   // torch.max(distance,-1)[1] (:329)
         par ^= 1;
     }
 }
@@ -302,12 +350,13 @@ __global__ __launch_bounds__(256) void fps_wave_kernel(const float *__restrict__
             d = d + dz * dz;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                if (d[e] < md[j][e]) md[j][e] = d[e];
-                if (md[j][e] > best) { best = md[j][e]; bi = lane + (2 * j + e) * 64; }
+                md[j][e] = fminf(md[j][e], d[e]);
+                const bool up = md[j][e] > best;                     // ascending index, strict '>'
+                best = up ? md[j][e] : best;
+                bi = up ? lane + (2 * j + e) * 64 : bi;
             }
         }
-        wave_argmax(best, bi);
-        far = __builtin_amdgcn_readfirstlane(bi);
+        far = __builtin_amdgcn_readfirstlane(argmax_key_index(wave_argmax_key(argmax_key(best, bi))));
     }
 }
 
@@ -358,11 +407,15 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
 template <int PPT>
 static int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int64_t *out, hipStream_t st)
 {
-    const int use_lds = (size_t)N * 12 + 256 <= 150 * 1024;
+    const bool use_lds = (size_t)N * 12 + 256 <= 150 * 1024;
     const size_t shmem = 256 + (use_lds ? (size_t)N * 12 : 0);
-    PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<PPT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(fps_kernel<PPT>, dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out, use_lds);
+    if (use_lds) {
+        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<PPT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((fps_kernel<PPT, true>), dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<PPT, false>), dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out);
+    }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -26,8 +26,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    """kernel name WITH its template arguments (dec_main_kernel<false, 2> is the f32 decoder, <true, 2> the bf16x3 one: a pass that runs
+    every arithmetic mode must not average them), without the parameter list"""
     name = re.sub(r"^void\s+", "", name)
-    return re.split(r"[<(]", name)[0].strip()
+    depth, out = 0, []
+    for ch in name:
+        if ch == "(" and depth == 0:
+            break
+        depth += ch == "<"
+        depth -= ch == ">"
+        out.append(ch)
+    return "".join(out).strip()
 
 
 def load(d):
