@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void dec_main_h2_kernel(const uint4 *__rest
     const int g_t = lane_t >> 4, n_t = lane_t & 15;
     const int tile0_t = blk * 4 * NT + NT * wu;
     const float *meta = hb + DEC_H2_META;                      // the six layer multipliers: wave-uniform, read after the loop, kept in SGPRs
-    asm volatile("" : "+s"(meta));
+    asm volatile("" : "+s"(meta));                             // (the laundered pointer loses its address space: two FLAT loads per workgroup,
+                                                               //  once; mfma_chain.h's opaque_uniform keeps it global but costs two spilled VGPRs here)
     auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
     const float rho0 = uni(meta[H2D_RHO0]), sig_q = uni(meta[H2D_SIG_Q]), rho1 = uni(meta[H2D_RHO1]);
     const float rho2 = uni(meta[H2D_RHO2]), rho3 = uni(meta[H2D_RHO3]), inv_out = uni(meta[H2D_INV_OUT]);
