@@ -39,7 +39,10 @@ class StepArena:
 
     def begin(self, device):
         self.off, self.need, self.active = 0, 0, True
-        if self.buf is not None and self.buf.device != torch.device(device):
+        dv = torch.device(device)
+        if dv.type == "cuda" and dv.index is None:
+            dv = torch.device("cuda", torch.cuda.current_device())
+        if self.buf is not None and self.buf.device != dv:
             self.buf = None
         if self.buf is not None:
             _lib.call("pccx_zero_bytes", self.buf.data_ptr(), self.buf.numel(), _stream())

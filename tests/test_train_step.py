@@ -544,3 +544,90 @@ def test_round3_training_kernels_against_float64():
         rows = xn[np.arange(Bn * Pn) % mod] if mod else xn               # float64 on the host (no library GEMM on the GPU in a test)
         want = np.maximum(np.repeat(bn_, Pn, axis=0) + rows @ wn.T, 0.0)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_round4_training_entry_points_equal_the_forms_they_replace():
+    """The training step's round-4 entry points against what they replaced: BatchNorm-ReLU forward / backward in two launches
+    (pccx_bn_relu_train_forward / _backward) BIT-IDENTICAL to pccx_bn_train_stats + pccx_bn_relu_forward / pccx_bn_relu_backward on cleared
+    sums (also with the caller-cleared flag), pccx_col_sum_w = pccx_col_sum onto zeros, pccx_chamfer_mean against the float64 formula,
+    pccx_add_i64_table, pccx_zero_bytes, pccx_gather_backward_acc, and the step arena handing out cleared memory."""
+    from pccx import _lib, train
+    from pccx.ops import _stream
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for M, C in ((5000, 64), (37, 128), (70000, 256)):
+        z = torch.randn(M, C, device="cuda", generator=g) * 2 + 0.3
+        gamma, beta = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g)
+        rm0, rv0 = torch.randn(C, device="cuda", generator=g), torch.rand(C, device="cuda", generator=g) + 0.5
+        outs = []
+        for fused, pre in ((False, 0), (True, 0), (True, 4)):
+            sums = torch.full((2 * C,), 7.0, device="cuda", dtype=torch.float64)       # dirty unless the caller says it cleared them
+            if pre:
+                sums.zero_()
+            mean, rstd, y = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(z)
+            rm, rv = rm0.clone(), rv0.clone()
+            if fused:
+                _lib.call("pccx_bn_relu_train_forward", z.data_ptr(), M, C, 1e-5, 0.1, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
+                          mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), y.data_ptr(), pre, _stream())
+            else:
+                _lib.call("pccx_bn_train_stats", z.data_ptr(), M, C, 1e-5, 0.1, sums.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rm.data_ptr(),
+                          rv.data_ptr(), _stream())
+                _lib.call("pccx_bn_relu_forward", z.data_ptr(), M, C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
+                          y.data_ptr(), _stream())
+            dy = torch.randn(M, C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+            dz, gg, gb = torch.empty_like(z), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+            if pre:
+                sums.zero_()
+            if fused:
+                gg.fill_(float("nan")); gb.fill_(float("nan"))                          # written, not accumulated
+                _lib.call("pccx_bn_relu_train_backward", dy.data_ptr(), y.data_ptr(), z.data_ptr(), M, C, mean.data_ptr(), rstd.data_ptr(),
+                          gamma.data_ptr(), sums.data_ptr(), dz.data_ptr(), gg.data_ptr(), gb.data_ptr(), pre, _stream())
+            else:
+                _lib.call("pccx_bn_relu_backward", dy.data_ptr(), y.data_ptr(), z.data_ptr(), M, C, mean.data_ptr(), rstd.data_ptr(),
+                          gamma.data_ptr(), sums.data_ptr(), dz.data_ptr(), gg.data_ptr(), gb.data_ptr(), _stream())
+            outs.append((y, mean, rstd, rm, rv, dz, gg, gb))
+        # the moments are double atomics (order-dependent in the last bits of a double); after the cast to float every product of the
+        # three forms agrees to the last bit or one ulp -- compared exactly first, then within an ulp
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert torch.equal(a, b) or float((a - b).abs().max()) <= 2.0 ** -22 * float(b.abs().max()), (M, C)
+        ref = torch.nn.functional.batch_norm(z.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5).clamp_min(0)
+        assert float((outs[1][0].double() - ref).abs().max()) < 1e-4
+        db0, db1 = torch.zeros(C, device="cuda"), torch.full((C,), float("nan"), device="cuda")
+        s2 = torch.empty(2 * C, device="cuda", dtype=torch.float64)
+        _lib.call("pccx_col_sum", dy.data_ptr(), M, C, s2.data_ptr(), db0.data_ptr(), _stream())
+        _lib.call("pccx_col_sum_w", dy.data_ptr(), M, C, s2.data_ptr(), db1.data_ptr(), 0, _stream())
+        assert torch.equal(db0, db1) or float((db0 - db1).abs().max()) <= 2.0 ** -22 * float(db0.abs().max())
+    # Chamfer value, counters, clears
+    dxy, dyx = torch.rand(3, 5000, device="cuda", generator=g), torch.rand(3, 777, device="cuda", generator=g)
+    out = torch.empty((), device="cuda")
+    _lib.call("pccx_chamfer_mean", dxy.data_ptr(), dyx.data_ptr(), 3, 5000, 777, out.data_ptr(), _stream())
+    want = float((dxy.double().mean(1) + dyx.double().mean(1)).mean())
+    assert abs(float(out) - want) <= 2e-7 * want
+    ctrs = [torch.tensor(v, device="cuda", dtype=torch.int64) for v in (0, 41, 7)]
+    table = torch.tensor([c.data_ptr() for c in ctrs], device="cuda", dtype=torch.int64)
+    _lib.call("pccx_add_i64_table", table.data_ptr(), 3, 2, _stream())
+    assert [int(c) for c in ctrs] == [2, 43, 9]
+    buf = torch.full((1000,), 3.0, device="cuda")
+    _lib.call("pccx_zero_bytes", buf.data_ptr() + 16, 4 * 900, _stream())
+    assert float(buf[:4].sum()) == 12.0 and float(buf[4:904].abs().sum()) == 0.0 and float(buf[904:].sum()) == 3.0 * 96
+    with pytest.raises(_lib.PccxError):
+        _lib.call("pccx_zero_bytes", buf.data_ptr(), 6, _stream())
+    # the step arena: measuring pass (torch.zeros), then slices of one cleared buffer; dirtied slices come back cleared on the next begin()
+    ar = train.StepArena()
+    ar.begin("cuda")
+    a0, from_arena = ar.zeros((10, 3), torch.float32, "cuda")
+    assert not from_arena and float(a0.abs().sum()) == 0.0
+    ar.zeros(5, torch.float64, "cuda")
+    ar.end("cuda")
+    for it in range(2):
+        ar.begin(torch.device("cuda", torch.cuda.current_device()))
+        a1, f1 = ar.zeros((10, 3), torch.float32, "cuda")
+        a2, f2 = ar.zeros(5, torch.float64, "cuda")
+        assert f1 and f2 and float(a1.abs().sum()) == 0.0 and float(a2.abs().sum()) == 0.0
+        assert a1.data_ptr() % 16 == 0 and a2.data_ptr() % 16 == 0 and a2.data_ptr() >= a1.data_ptr() + 120
+        a1.fill_(5.0); a2.fill_(-1.0)
+        a3, f3 = ar.zeros(1 << 20, torch.float32, "cuda")                      # more than the arena holds: falls back; the next step's arena has grown
+        assert f3 == (it == 1) and float(a3.abs().sum()) == 0.0
+        a3.fill_(2.0)
+        ar.end("cuda")
