@@ -763,7 +763,8 @@ def bench_pppe_train(args, rk):
     import torch
     from pccx import families, synth, train
 
-    def run(Bt, steps, warmup):
+    def run(Bt, steps, warmup, autocast=None):
+        autocast = args.autocast if autocast is None else autocast
         model = families.PointCloudAE(64, 16, N_POINTS)
         model.load_state_dict(seeded_state_dict(model, 32))
         for k, v in model.state_dict().items():                  # sane BatchNorm statistics
@@ -777,10 +778,10 @@ def bench_pppe_train(args, rk):
         starts = [[rng.integers(0, N_POINTS, Bt), rng.integers(0, N_POINTS, Bt)], rng.integers(0, 512, Bt), rng.integers(0, 128, Bt)]
         keep = {}
         kw = dict(lam=1e-3, data_parallel=rk.world > 1)
-        if args.autocast:
+        if autocast:
             kw["autocast"] = True
         if args.graph:
-            gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=args.autocast, warmup=max(warmup, 1),
+            gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=autocast, warmup=max(warmup, 1),
                                            data_parallel=rk.world > 1)     # N > 1: two graphs cut at the gradient all-reduce
             dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), steps, torch.cuda.synchronize)
             keep["o"] = tuple(float(t) for t in keep["o"])
@@ -804,6 +805,14 @@ def bench_pppe_train(args, rk):
             sweep[str(b_)] = {"clouds_per_s": rk.world * b_ * st_ / dtb, "ms_per_step": 1e3 * dtb / st_}
         for v in sweep.values():
             v["patches_per_s"] = v["clouds_per_s"] * 512
+    other = None
+    if not args.one_mode:
+        # the step in the OTHER arithmetic beside the quoted one (bf16 autocast <-> fp32): the reference's CUDA branch is fp16 autocast with a
+        # GradScaler (three more mantissa bits than bf16), so the fp32 step is the conservative figure to read the bf16 one against
+        torch.cuda.empty_cache()
+        st_ = max(3, args.steps // 2)
+        dto, losso, _, _, _, _ = run(Bt, st_, max(args.warmup, 1), autocast=not args.autocast)
+        other = {"dtype": "f32" if args.autocast else "bf16 autocast", "clouds_per_s": rk.world * Bt * st_ / dto, "ms_per_step": 1e3 * dto / st_, "loss": losso}
     if rk.rank == 0:
         cpu = None
         if rk.world == 1 and args.cpu_clouds > 0:
@@ -829,7 +838,7 @@ def bench_pppe_train(args, rk):
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
                        "launch": ("one hipGraph replay per step" if rk.world == 1 else "two hipGraph replays per step around the RCCL gradient all-reduce")
                                  if args.graph else "eager" + (" (gradient all-reduce overlapped with backward)" if rk.world > 1 else "")},
-            "batch_sweep": sweep or None,
+            "batch_sweep": sweep or None, "other_arithmetic": other,
             "roofline": rf, "cpu_baseline": cpu,
             "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": loss}), flush=True)
 

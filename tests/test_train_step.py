@@ -631,3 +631,37 @@ def test_round4_training_entry_points_equal_the_forms_they_replace():
         assert f3 == (it == 1) and float(a3.abs().sum()) == 0.0
         a3.fill_(2.0)
         ar.end("cuda")
+
+
+@pytest.mark.gpu
+def test_autocast_run_of_twenty_steps_stays_in_a_band_of_the_fp32_run():
+    """Convergence of the bf16-autocast step against the fp32 step over a short RUN (advisor, round 3: one step and "distortion decreases"
+    do not pin the optimisation; the reference trains in fp16 autocast with a GradScaler, train_pppe_pcd_ae.py:193,280, which this image
+    cannot run).  Twenty clipped Adam steps from the same weights on the same 16-cloud batch with the same FPS draws, in fp32 and in bf16
+    autocast: both bring the distortion below 2 % of its initial value, and the autocast run's distortion stays within 35 % of the fp32
+    run's at steps 5 and 10 (single trajectories diverge at the level of the quantiser's bin flips and of max-pool winners: measured
+    gaps of 2-22 %, in either direction)."""
+    import copy
+    from pccx import families, synth as cloud_synth, train
+    o = _models(2048)
+    Bn = 16
+    x = torch.from_numpy(np.stack([cloud_synth.cad_cloud(800 + i, 2048) for i in range(Bn)]).astype(np.float32)).cuda()
+    rng = np.random.default_rng(21)
+    starts = [[rng.integers(0, 2048, Bn), rng.integers(0, 2048, Bn)], rng.integers(0, 512, Bn), rng.integers(0, 128, Bn)]
+    base = families.PointCloudAE(64, 16, 2048)
+    base.load_state_dict(o.state_dict())
+    base = base.cuda()
+    hist = {}
+    for name, ac in (("f32", False), ("bf16", True)):
+        m = copy.deepcopy(base)
+        opt = train.Adam(m.parameters(), lr=1e-3)
+        hist[name] = [train.train_step(m, opt, x, starts, lam=1e-3, autocast=ac)[1] for _ in range(20)]
+        assert all(np.isfinite(v) for v in hist[name])
+    print("distortion f32 ", ["%.5f" % v for v in hist["f32"][::5] + hist["f32"][-1:]])
+    print("distortion bf16", ["%.5f" % v for v in hist["bf16"][::5] + hist["bf16"][-1:]])
+    for name in hist:
+        assert hist[name][-1] < 0.02 * hist[name][0], (name, hist[name][0], hist[name][-1])     # measured: 0.5 % of the initial distortion after 20 steps
+    for t in (4, 9):
+        a, b = hist["f32"][t], hist["bf16"][t]
+        assert abs(a - b) <= 0.35 * a, (t, a, b)
+    # by step 20 the fp32 run itself moves by +-20 % from run to run (0.0059 .. 0.0085 over three runs): no tighter band is meaningful there
