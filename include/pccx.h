@@ -369,6 +369,10 @@ PCCX_API int pccx_group_planes(const float *f0, int C0, int ld0, const float *f1
  * the C0 channels of f0 row (mod0 > 0 ? r % mod0 : r) then the C1 channels of f1 row r / div1. */
 PCCX_API int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
                               float *planes, void *stream);
+/* act(base[r / div] + x[mod ? r % mod : r] @ w^T), r < M -- pccx_rows_affine_small's values (same fmaf chain) -- written as the operand
+ * planes of the next layer (pccx_planes_floats(M, C) floats) instead of fp32 rows: FoldingNet's first layers, PPPF_AE.py:99-107 */
+PCCX_API int pccx_rows_affine_planes(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                     int relu, int64_t M, float *planes, void *stream);
 PCCX_API size_t pccx_planes_gemm_weight_floats(int N, int K);
 PCCX_API int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream);
 PCCX_API int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,

@@ -7,6 +7,7 @@
 // These rows are correctness-first (unfused, activations round-trip through HBM); the fused chains
 // in encoder.hip / decoder.hip are the tuned path for the IPDAE configuration.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "mfma_chain.h"
@@ -513,6 +514,57 @@ __global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__r
   }
 }
 
+// The same reduction with the cloud's WHOLE index table held in LDS as 16-bit entries (M * ns * 2 bytes: 32 / 16 / 8 KB for the three
+// set-abstraction levels of PPPF_AE.py:29-34) and the channel chunks walked INSIDE the workgroup: the int64 table (8 bytes per entry)
+// is read from memory once per cloud instead of once per channel chunk -- it was 1.07 GB of the first level's 1.6 GB per 2048 patches --
+// and a group's walk chains LDS reads only.  Workgroup = cloud; tile = `chunk` channels of all N rows.
+__global__ __launch_bounds__(GM_THREADS) void gather_max_lds_idx_kernel(const float *__restrict__ y, int B, int N, int C, const int64_t *__restrict__ idx,
+                                                                        int M, int ns, int chunk, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float gm_tile[];
+    const int tid = threadIdx.x, q4 = chunk >> 2, ldy4 = C >> 2;
+    unsigned short *sidx = (unsigned short *)(gm_tile + (size_t)N * chunk);          // [M][ns] after the tile
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t *ib = idx + (size_t)b * M * ns;
+    for (int i = tid; i < M * ns; i += GM_THREADS) {
+        const long long j = ib[i];
+        sidx[i] = (unsigned short)(j < 0 ? 0 : j);                                    // idx.clamp(min=0), pointnet_sa_module.py:27
+    }
+    for (int c0 = 0; c0 < C; c0 += chunk) {
+        const int cw = min(chunk, C - c0);
+        const float4 *y4 = (const float4 *)(y + (size_t)b * N * C + c0);
+        float4 *t4w = (float4 *)gm_tile;
+        __syncthreads();                                                              // the previous chunk's walks are done (and sidx is written)
+        for (int i = tid; i < N * q4; i += GM_THREADS) {
+            const int row = i / q4, q = i - row * q4;
+            if (4 * q < cw) t4w[i] = y4[(size_t)row * ldy4 + q];
+        }
+        __syncthreads();
+        const float4 *t4 = (const float4 *)gm_tile;
+        for (int it = tid; it < M * q4; it += GM_THREADS) {
+            const int g = it / q4, q = it - g * q4;
+            if (4 * q >= cw) continue;
+            const unsigned short *ig = sidx + (size_t)g * ns;
+            float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            int s_ = 0;
+            for (; s_ + 8 <= ns; s_ += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = t4[(int)ig[s_ + u] * q4 + q];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w); }
+            }
+            for (; s_ < ns; ++s_) {
+                const float4 v = t4[(int)ig[s_] * q4 + q];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+            ((float4 *)(out + ((size_t)b * M + g) * C + c0))[q] = m;
+        }
+    }
+    __syncthreads();                                                                  // sidx / the tile are rewritten for the next cloud
+  }
+}
+
 extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream)
 {
     if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
@@ -520,6 +572,20 @@ extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_
     PCCX_CHECK_ARG(B > 0 && N >= 1 && M >= 1 && ns >= 1 && C >= 4 && C % 4 == 0, "pccx_gather_max: bad shape B=%d N=%d C=%d M=%d ns=%d (C %% 4 == 0)",
                    B, N, C, M, ns);
     const unsigned gy = (unsigned)(B < 65535 ? B : 65535);
+    {
+        // index table in LDS (16-bit) + a 32 KB tile = at most 64 KB per workgroup: two workgroups per CU as before
+        const size_t ib = ((size_t)M * ns * 2 + 15) / 16 * 16;
+        int ck = (int)((size_t)32768 / ((size_t)N * 4)) & ~3;
+        if (ck > C) ck = C;
+        if (N <= 65536 && ck >= 16 && ib <= 32768 && !getenv("PCCX_GATHER_MAX_PLAIN")) {
+            PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_max_lds_idx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               64 * 1024));
+            hipLaunchKernelGGL(gather_max_lds_idx_kernel, dim3(gy), dim3(GM_THREADS), (size_t)N * ck * 4 + ib, (hipStream_t)stream, y, B, N, C, idx, M,
+                               ns, ck, out);
+            PCCX_CHECK_LAUNCH();
+            return PCCX_OK;
+        }
+    }
     int chunk = (int)((size_t)65536 / ((size_t)N * 4)) & ~3;                  // channels of all N rows in 64 KB
     if (chunk > C) chunk = C;
     if (chunk >= 16) {

@@ -115,6 +115,68 @@ extern "C" int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, 
     return PCCX_OK;
 }
 
+// ---- the per-point part of FoldingNet's first layers straight into operand planes -------------------------------------------------
+// act(base[r / div] + x[mod ? r % mod : r] @ w^T) for r < M (linear.hip: rows_affine_small_kernel -- the same fmaf chain per element, k
+// ascending on top of base, so the values are bit-identical) written as the planes of the NEXT layer's operand instead of fp32 rows:
+// round 3 wrote the rows (1.07 GB for the 512-wide MLP of 2048 patches), read them back in group_planes_kernel and wrote the planes.
+// One wave per row tile, as group_planes_kernel; lane (g, n) forms channels 32 t + 16 h + 4 g .. + 3 of row 16 tile + n.
+__global__ __launch_bounds__(256) void rows_affine_planes_kernel(const float *__restrict__ base, int C, unsigned div, const float *__restrict__ x,
+                                                                 int ldx, int Ks, unsigned mod, const float *__restrict__ w, int relu,
+                                                                 long long M, int KT32, long long ntiles, uint4 *__restrict__ planes)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    long long r = tile * 16 + n;
+    if (r >= M) r = M - 1;                                   // padded rows repeat the last one (never read back as results)
+    const float *xr = x + (size_t)(mod ? (unsigned long long)r % mod : (unsigned long long)r) * ldx;
+    float xk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xk[k] = k < Ks ? xr[k] : 0.f;
+    const float *br = base + (size_t)((unsigned long long)r / div) * C;
+    for (int t = 0; t < KT32; ++t) {
+        f32x4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 32 * t + 16 * h + 4 * g;
+            if (c + 3 < C) {
+                const f32x4 b4 = *(const f32x4 *)(br + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float a = b4[u];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < Ks) a = fmaf(xk[k], w[(size_t)(c + u) * Ks + k], a);
+                    v[h][u] = relu ? fmaxf(a, 0.f) : a;
+                }
+            } else {
+                v[h] = f32x4{0.f, 0.f, 0.f, 0.f};             // C % 4 == 0: a block is inside the layer or beyond it
+            }
+        }
+        bf16x8 pl[3];
+        b3_split8(v[0], v[1], pl);
+        uint4 *d = planes + (((size_t)t * ntiles + tile) * 3) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+    }
+}
+
+extern "C" int pccx_rows_affine_planes(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                       int relu, int64_t M, float *planes, void *stream)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(base && x && w && planes, "pccx_rows_affine_planes: null pointer");
+    PCCX_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0 && Ks >= 1 && Ks <= 4 && ldx >= Ks && div >= 1 && div < 0x7fffffffLL && mod >= 0 && mod < 0x7fffffffLL &&
+                       ((uintptr_t)base & 15) == 0,
+                   "pccx_rows_affine_planes: bad arguments (C=%d a multiple of 4, Ks=%d in 1..4, base 16-byte aligned)", C, Ks);
+    const long long ntiles = (M + 15) / 16;
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_rows_affine_planes: M too large");
+    hipLaunchKernelGGL(rows_affine_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, base, C, (unsigned)div, x, ldx, Ks,
+                       (unsigned)mod, w, relu, (long long)M, pg_kt32(C), ntiles, (uint4 *)planes);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // ---- weight stream: [m-block][t][MB m-tiles][plane] fragments out of pccx_pack_linear_b3's [t][MT][plane] ------------
 extern "C" size_t pccx_planes_gemm_weight_floats(int N, int K)
 {

@@ -272,6 +272,16 @@ def rows_affine_small(base, div, x, mod, w_small, relu, M):
     return out
 
 
+def rows_affine_planes(base, div, x, mod, w_small, relu, M):
+    """rows_affine_small's values written as the operand planes of the next layer (pccx_rows_affine_planes): no fp32 rows in between."""
+    x = x.contiguous()
+    Cc, Ks = int(base.shape[-1]), int(w_small.shape[1])
+    out = torch.empty(_lib.load().pccx_planes_floats(M, Cc), device=base.device, dtype=torch.float32)
+    _lib.call("pccx_rows_affine_planes", base.contiguous().data_ptr(), Cc, int(div), x.data_ptr(), int(x.shape[-1]), Ks, int(mod),
+              w_small.data_ptr(), int(bool(relu)), int(M), out.data_ptr(), _stream())
+    return out
+
+
 def gather_max(y, idx):
     """max over nsample of y[b, idx.clamp(min=0)] (pointnet_sa_module.py:27-28,91): y (B,N,C) rows, idx (B,M,ns) int64 -> (B,M,C)."""
     B, N, Cc = y.shape
@@ -457,6 +467,14 @@ class PPPF_AE(_Packable):
             # The folding inputs [grid | latent] and [coarse | latent] (:99-106) are never built: their 1024-wide latent part is the
             # same for the P points of a patch, so the first layer of each MLP is W_lat latent + bias once per PATCH (a Linear on B
             # rows) plus a 2- / 3-term per-point update with ReLU (pccx_rows_affine_small); the remaining layers run on the P rows.
+            if pk["mlp1"][1].mode() == "bf16x3":
+                # ... and the per-point update writes the next layer's operand PLANES directly (the fp32 rows of the 512-wide MLP were 1 GB
+                # written, read back and split per 2048 patches)
+                pl = rows_affine_planes(pk["mlp1_lat"](lat_dec), P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P)
+                x = run_stack_planes(pk["mlp1"][1:], pl, B * P)                                              # :104 coarse
+                pl = rows_affine_planes(pk["mlp2_lat"](lat_dec), P, x, 0, pk["mlp2_small"], pk["mlp2"][0].relu, B * P)
+                x = run_stack_planes(pk["mlp2"][1:], pl, B * P)                                              # :107 fine
+                return x.view(B, P, 3), latent, q
             h = rows_affine_small(pk["mlp1_lat"](lat_dec), P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P)
             x = run_stack(pk["mlp1"][1:], h)                                                                 # :104 coarse
             h = rows_affine_small(pk["mlp2_lat"](lat_dec), P, x, 0, pk["mlp2_small"], pk["mlp2"][0].relu, B * P)

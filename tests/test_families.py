@@ -137,6 +137,11 @@ def test_pointnet_sa_module_on_source_rows_equals_the_grouped_evaluation_bit_for
         idx = torch.from_numpy(rng.integers(-1, N, size=(B, M, ns))).cuda()
         want = torch.gather(y[:, None].expand(B, M, N, Cc), 2, idx.clamp(min=0)[..., None].expand(B, M, ns, Cc)).amax(dim=2)
         assert torch.equal(families.gather_max(y, idx), want)
+        try:                                                 # the form without the index table in LDS (what larger tables take)
+            os.environ["PCCX_GATHER_MAX_PLAIN"] = "1"
+            assert torch.equal(families.gather_max(y, idx), want)
+        finally:
+            del os.environ["PCCX_GATHER_MAX_PLAIN"]
 
 
 @pytest.mark.gpu
