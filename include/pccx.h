@@ -477,6 +477,10 @@ PCCX_API int pccx_bn_relu_train_backward(const float *dY, const float *Y, const 
                                          const float *rstd, const float *gamma, double *sums, float *dZ, float *g_gamma,
                                          float *g_beta, int flags, void *stream);
 PCCX_API int pccx_col_sum_w(const float *dY, int64_t M, int C, double *sums, float *g_bias, int flags, void *stream);
+/* `sums` of the three entry points above holds pccx_train_sums_doubles(C) doubles (eight replicas of the 2 C column sums: a workgroup adds
+ * into replica blockIdx % 8, the consuming kernel adds the replicas up -- the same-address atomics at the end of a reduction are an eighth
+ * as deep); the older pccx_bn_train_stats / pccx_bn_relu_backward / pccx_col_sum keep their 2 C doubles. */
+PCCX_API size_t pccx_train_sums_doubles(int C);
 /* clear `bytes` (a multiple of 4) with a kernel (as a hipGraph node it is ordered like every other kernel: DESIGN.md section 7) */
 PCCX_API int pccx_zero_bytes(void *p, size_t bytes, void *stream);
 /* *table[i] += delta for n int64 counters whose device addresses sit in table_dev (BatchNorm's num_batches_tracked of a whole model) */

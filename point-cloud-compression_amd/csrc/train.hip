@@ -328,8 +328,12 @@ __global__ void col_reduce_kernel(int mode, const float *__restrict__ A, const f
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce4_kernel(const float *__restrict__ A, const float *__restrict__ Y, const float *__restrict__ Z,
                                                          const float *__restrict__ mean, const float *__restrict__ rstd, long M, int C,
-                                                         long rows_per_block, double *__restrict__ out0, double *__restrict__ out1)
+                                                         long rows_per_block, double *__restrict__ out0, double *__restrict__ out1, int nrep)
 {
+    // nrep > 1: workgroup b adds into replica b % nrep of the sums (replicas 2 C doubles apart; the consumer adds them up): the kernel
+    // ends with one double atomic per column per workgroup on the same 2 C addresses, which serialise at L2 -- spread over eight
+    // replicas that tail is an eighth as deep
+    const size_t ro = nrep > 1 ? (size_t)(blockIdx.x % nrep) * 2 * C : 0;
     __shared__ double red[2][4][256];
     const int cv = C >> 2, tid = threadIdx.x;
     const int cq = tid % cv, rl = tid / cv, rstep = 256 / cv;          // column group, row lane, rows per step
@@ -385,15 +389,16 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(const float *__restric
         for (int u = 0; u < 4; ++u) {
             double t0 = 0, t1 = 0;
             for (int l = 0; l < rstep; ++l) { t0 += red[0][u][l * cv + tid]; t1 += red[1][u][l * cv + tid]; }
-            atomicAdd(&out0[4 * tid + u], t0);
-            if (MODE != 2) atomicAdd(&out1[4 * tid + u], t1);
+            atomicAdd(&out0[ro + 4 * tid + u], t0);
+            if (MODE != 2) atomicAdd(&out1[ro + 4 * tid + u], t1);
         }
     }
 }
 
 // prezeroed: the caller cleared o0 / o1 already (train.py's step arena: ONE clear per training step instead of one per reduction)
+#define PCCX_SUM_REPLICAS 8
 static int launch_col_reduce(int mode, const float *A, const float *Y, const float *Z, const float *mean, const float *rstd,
-                             int64_t M, int C, double *o0, double *o1, hipStream_t st, bool prezeroed = false)
+                             int64_t M, int C, double *o0, double *o1, hipStream_t st, bool prezeroed = false, int nrep = 1)
 {
     const int cv = C >> 2;
     if (C % 4 == 0 && cv >= 1 && cv <= 256 && (cv & (cv - 1)) == 0 && ((uintptr_t)A & 15) == 0 && (!Y || ((uintptr_t)Y & 15) == 0) &&
@@ -407,23 +412,29 @@ static int launch_col_reduce(int mode, const float *A, const float *Y, const flo
         rpb = (rpb + rstep - 1) / rstep * rstep;
         const unsigned blocks = (unsigned)((M + rpb - 1) / rpb);
         if (prezeroed) {
+        } else if (nrep > 1) {
+            PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * 2 * C * nrep, st));   // replicas [r][2][C], o1 == o0 + C
         } else if (o1 == o0 + C) {
             PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * 2 * C, st));          // both sums in one launch
         } else {
             PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
             if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
         }
-        if (mode == 0) hipLaunchKernelGGL(col_reduce4_kernel<0>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1);
-        else if (mode == 1) hipLaunchKernelGGL(col_reduce4_kernel<1>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1);
-        else hipLaunchKernelGGL(col_reduce4_kernel<2>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1);
+        if (mode == 0) hipLaunchKernelGGL(col_reduce4_kernel<0>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1, nrep);
+        else if (mode == 1) hipLaunchKernelGGL(col_reduce4_kernel<1>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1, nrep);
+        else hipLaunchKernelGGL(col_reduce4_kernel<2>, dim3(blocks), dim3(256), 0, st, A, Y, Z, mean, rstd, (long)M, C, rpb, o0, o1 ? o1 : o0 + C, nrep);
         PCCX_CHECK_LAUNCH();
         return PCCX_OK;
     }
     dim3 grid((C + 63) / 64, (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
     PCCX_CHECK_ARG(grid.y <= 65535u, "column reduction: M=%ld rows too many", (long)M);
     if (!prezeroed) {
-        PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
-        if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
+        if (nrep > 1) {
+            PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * 2 * C * nrep, st));   // the generic kernel fills replica 0; the others stay zero
+        } else {
+            PCCX_CHECK_HIP(pccx_zero_async(o0, sizeof(double) * C, st));
+            if (o1) PCCX_CHECK_HIP(pccx_zero_async(o1, sizeof(double) * C, st));
+        }
     }
     hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, st, mode, A, Y, Z, mean, rstd, (long)M, C, o0, o1);
     PCCX_CHECK_LAUNCH();
@@ -509,6 +520,19 @@ __global__ void cast_d2f_kernel(const double *__restrict__ a, int n, float *__re
     if (i < n) o[i] = accumulate ? o[i] + (float)a[i] : (float)a[i];
 }
 
+// o[i] = sum over the nrep replicas (2 C doubles apart) of a[i]
+__global__ void cast_rep_d2f_kernel(const double *__restrict__ a, int C, int nrep, float *__restrict__ o)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    double t = 0;
+    for (int r = 0; r < nrep; ++r) t += a[(size_t)r * 2 * C + i];
+    o[i] = (float)t;
+}
+
+// the doubles of `sums` the training step's three reductions take (pccx_bn_relu_train_forward / _backward, pccx_col_sum_w)
+extern "C" size_t pccx_train_sums_doubles(int C) { return (size_t)PCCX_SUM_REPLICAS * 2 * (size_t)(C > 0 ? C : 0); }
+
 // g_gamma[i] += sums[i], g_beta[i] += sums[C + i] in one launch
 __global__ void cast2_d2f_kernel(const double *__restrict__ a, int C, float *__restrict__ o0, float *__restrict__ o1)
 {
@@ -544,13 +568,15 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_fused_kernel(const float *__r
                                                                 const double *__restrict__ s1, float eps, float momentum,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                                                                 float *__restrict__ Y, float *__restrict__ mean_out, float *__restrict__ rstd_out,
-                                                                float *__restrict__ running_mean, float *__restrict__ running_var)
+                                                                float *__restrict__ running_mean, float *__restrict__ running_var, int nrep)
 {
     extern __shared__ float bnsm[];                                    // mean[C] | rstd[C]
     float *smean = bnsm, *srstd = bnsm + C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mu = s0[c] / (double)M;
-        double var = s1[c] / (double)M - mu * mu;
+        double t0 = 0, t1 = 0;
+        for (int r = 0; r < nrep; ++r) { t0 += s0[(size_t)r * 2 * C + c]; t1 += s1[(size_t)r * 2 * C + c]; }     // the replicas in order
+        const double mu = t0 / (double)M;
+        double var = t1 / (double)M - mu * mu;
         if (var < 0) var = 0;
         const float mf = (float)mu, rf = (float)(1.0 / sqrt(var + (double)eps));
         smean[c] = mf;
@@ -580,12 +606,12 @@ extern "C" int pccx_bn_relu_train_forward(const float *Z, int64_t M, int C, floa
     if (M == 0) return PCCX_OK;
     PCCX_CHECK_ARG(Z && sums && gamma && beta && mean && rstd && Y && C >= 1 && C <= 4096, "pccx_bn_relu_train_forward: bad arguments (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_col_reduce(0, Z, nullptr, nullptr, nullptr, nullptr, M, C, sums, sums + C, st, (flags & 4) != 0);
+    int rc = launch_col_reduce(0, Z, nullptr, nullptr, nullptr, nullptr, M, C, sums, sums + C, st, (flags & 4) != 0, PCCX_SUM_REPLICAS);
     if (rc) return rc;
     long blocks = ((long)M * C + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_relu_fwd_fused_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 2 * C, st, Z, (long)M * C, C, (long)M, sums,
-                       sums + C, eps, momentum, gamma, beta, relu, Y, mean, rstd, running_mean, running_var);
+                       sums + C, eps, momentum, gamma, beta, relu, Y, mean, rstd, running_mean, running_var, PCCX_SUM_REPLICAS);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
@@ -596,18 +622,26 @@ __global__ void bn_relu_bwd_apply_w_kernel(const float *__restrict__ dY, const f
                                            long n, int C, long M, const float *__restrict__ mean, const float *__restrict__ rstd,
                                            const float *__restrict__ gamma, const double *__restrict__ dgamma,
                                            const double *__restrict__ dbeta, float *__restrict__ dZ, float *__restrict__ g_gamma,
-                                           float *__restrict__ g_beta)
+                                           float *__restrict__ g_beta, int nrep)
 {
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            g_gamma[c] = (float)dgamma[c];
-            g_beta[c] = (float)dbeta[c];
+    extern __shared__ double bwsm[];                                   // dgamma[C] | dbeta[C]: the replicas added up, in order
+    double *sg = bwsm, *sb = bwsm + C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double t0 = 0, t1 = 0;
+        for (int r = 0; r < nrep; ++r) { t0 += dgamma[(size_t)r * 2 * C + c]; t1 += dbeta[(size_t)r * 2 * C + c]; }
+        sg[c] = t0;
+        sb[c] = t1;
+        if (blockIdx.x == 0) {
+            g_gamma[c] = (float)t0;
+            g_beta[c] = (float)t1;
         }
+    }
+    __syncthreads();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const double d = Y[i] > 0.f ? dY[i] : 0.f;
         const double xh = (double)((Z[i] - mean[c]) * rstd[c]);
-        dZ[i] = (float)((double)gamma[c] * rstd[c] / (double)M * ((double)M * d - dbeta[c] - xh * dgamma[c]));
+        dZ[i] = (float)((double)gamma[c] * rstd[c] / (double)M * ((double)M * d - sb[c] - xh * sg[c]));
     }
 }
 
@@ -618,12 +652,12 @@ extern "C" int pccx_bn_relu_train_backward(const float *dY, const float *Y, cons
     if (M == 0) return PCCX_OK;
     PCCX_CHECK_ARG(dY && Y && Z && mean && rstd && gamma && sums && dZ && g_gamma && g_beta, "pccx_bn_relu_train_backward: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_col_reduce(1, dY, Y, Z, mean, rstd, M, C, sums, sums + C, st, (flags & 4) != 0);
+    int rc = launch_col_reduce(1, dY, Y, Z, mean, rstd, M, C, sums, sums + C, st, (flags & 4) != 0, PCCX_SUM_REPLICAS);
     if (rc) return rc;
     long blocks = ((long)M * C + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_relu_bwd_apply_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dY, Y, Z, (long)M * C, C, (long)M, mean, rstd,
-                       gamma, sums, sums + C, dZ, g_gamma, g_beta);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_w_kernel, dim3((unsigned)blocks), dim3(256), sizeof(double) * 2 * C, st, dY, Y, Z, (long)M * C, C, (long)M, mean, rstd,
+                       gamma, sums, sums + C, dZ, g_gamma, g_beta, PCCX_SUM_REPLICAS);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
@@ -633,9 +667,9 @@ extern "C" int pccx_col_sum_w(const float *dY, int64_t M, int C, double *sums, f
 {
     if (M == 0) return PCCX_OK;
     PCCX_CHECK_ARG(dY && sums && g_bias, "pccx_col_sum_w: null pointer");
-    int rc = launch_col_reduce(2, dY, nullptr, nullptr, nullptr, nullptr, M, C, sums, nullptr, (hipStream_t)stream, (flags & 4) != 0);
+    int rc = launch_col_reduce(2, dY, nullptr, nullptr, nullptr, nullptr, M, C, sums, nullptr, (hipStream_t)stream, (flags & 4) != 0, PCCX_SUM_REPLICAS);
     if (rc) return rc;
-    hipLaunchKernelGGL(cast_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, g_bias, 0);
+    hipLaunchKernelGGL(cast_rep_d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, PCCX_SUM_REPLICAS, g_bias);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -121,6 +121,7 @@ _SIGNATURES = {
     "pccx_bn_relu_train_forward": [_P, C.c_int64, C.c_int, C.c_float, C.c_float, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P],
     "pccx_bn_relu_train_backward": [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P],
     "pccx_col_sum_w": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P],
+    "pccx_train_sums_doubles": [C.c_int],
     "pccx_zero_bytes": [_P, C.c_size_t, _P],
     "pccx_add_i64_table": [_P, C.c_int, C.c_int64, _P],
     "pccx_gather_backward_acc": [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
@@ -140,7 +141,7 @@ _SIGNATURES = {
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
-_RESTYPES = {"pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
+_RESTYPES = {"pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_train_sums_doubles": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
              "pccx_ae_encode_h2_workspace_bytes": C.c_size_t, "pccx_ae_decode_h2_workspace_floats": C.c_size_t,
              "pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,

@@ -83,13 +83,14 @@ ops.zeros_hook = _zeros       # the Chamfer backward's two gradient buffers come
 
 def _sums(C, device):
     """2*C doubles of column-sum scratch and the flag the reduction takes: 4 when the step's arena has cleared them already"""
+    n = int(_lib.load().pccx_train_sums_doubles(C))          # eight replicas of the 2 C sums (csrc/train.hip: PCCX_SUM_REPLICAS)
     if _ARENA is not None:
-        t, pre = _ARENA.zeros(2 * C, torch.float64, device)
+        t, pre = _ARENA.zeros(n, torch.float64, device)
         if pre:
             return t, 4
     t = _SCRATCH.get((C, str(device)))
     if t is None:
-        t = _SCRATCH[(C, str(device))] = torch.empty(2 * C, device=device, dtype=torch.float64)
+        t = _SCRATCH[(C, str(device))] = torch.empty(n, device=device, dtype=torch.float64)
     return t, 0
 
 

@@ -561,7 +561,8 @@ def test_round4_training_entry_points_equal_the_forms_they_replace():
         rm0, rv0 = torch.randn(C, device="cuda", generator=g), torch.rand(C, device="cuda", generator=g) + 0.5
         outs = []
         for fused, pre in ((False, 0), (True, 0), (True, 4)):
-            sums = torch.full((2 * C,), 7.0, device="cuda", dtype=torch.float64)       # dirty unless the caller says it cleared them
+            nsum = int(_lib.load().pccx_train_sums_doubles(C)) if fused else 2 * C     # the fused forms keep eight replicas of the sums
+            sums = torch.full((nsum,), 7.0, device="cuda", dtype=torch.float64)        # dirty unless the caller says it cleared them
             if pre:
                 sums.zero_()
             mean, rstd, y = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(z)
@@ -594,7 +595,7 @@ def test_round4_training_entry_points_equal_the_forms_they_replace():
         ref = torch.nn.functional.batch_norm(z.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5).clamp_min(0)
         assert float((outs[1][0].double() - ref).abs().max()) < 1e-4
         db0, db1 = torch.zeros(C, device="cuda"), torch.full((C,), float("nan"), device="cuda")
-        s2 = torch.empty(2 * C, device="cuda", dtype=torch.float64)
+        s2 = torch.empty(int(_lib.load().pccx_train_sums_doubles(C)), device="cuda", dtype=torch.float64)
         _lib.call("pccx_col_sum", dy.data_ptr(), M, C, s2.data_ptr(), db0.data_ptr(), _stream())
         _lib.call("pccx_col_sum_w", dy.data_ptr(), M, C, s2.data_ptr(), db1.data_ptr(), 0, _stream())
         assert torch.equal(db0, db1) or float((db0 - db1).abs().max()) <= 2.0 ** -22 * float(db0.abs().max())
