@@ -302,25 +302,32 @@ class Ranks:
             self.dev = torch.device("cpu")
         self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where the tiny collectives live
         self.info = {"rccl_world": 1, "dist_backend": None, "rank_devices": [self.local if self.gpu else None]}
-        if self.world > 1:
+        # PCCX_DIST_SINGLE_RANK=1: a ONE-rank process group whose collectives really run (pccx.dist.collectives_active) -- the rehearsal of
+        # the RCCL plumbing a one-GPU box allows; the line then says dist_backend "rccl ... one-rank rehearsal"
+        self.grouped = self.world > 1 or os.environ.get("PCCX_DIST_SINGLE_RANK") == "1"
+        if self.grouped:
             import torch.distributed as dist
+            if self.world == 1:
+                os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
             launch.init_process_group(self.backend, self.dev if self.backend == "nccl" else None)
             # what the driver can check an N-rank run by: the size of the process group the collectives ran on and the device
             # index every rank bound (one all_gather of an int, outside every timed region)
             mine = torch.tensor([self.local if self.gpu else -1], dtype=torch.int64, device=self.cdev)
             got = [torch.zeros_like(mine) for _ in range(self.world)]
             dist.all_gather(got, mine)
-            self.info = {"rccl_world": dist.get_world_size(), "dist_backend": "rccl (torch 'nccl')" if self.backend == "nccl" else "gloo",
+            self.info = {"rccl_world": dist.get_world_size(),
+                         "dist_backend": ("rccl (torch 'nccl')" if self.backend == "nccl" else "gloo") + (", one-rank rehearsal" if self.world == 1 else ""),
                          "rank_devices": [int(t[0]) if int(t[0]) >= 0 else None for t in got]}
 
     def barrier(self):
-        if self.world > 1:
+        if self.grouped:
             import torch.distributed as dist
             dist.barrier()
 
     def max_seconds(self, dt):
         from pccx import dist as pdist
-        return pdist.max_over_ranks(dt, self.cdev) if self.world > 1 else dt
+        return pdist.max_over_ranks(dt, self.cdev) if self.grouped else dt
 
     def summaries(self, local_vec):
         """RCCL all_gather of the dist.SUMMARY_FIELDS vector (bits, points, psnr_sum, chamfer_sum, files, seconds)."""
@@ -328,7 +335,7 @@ class Ranks:
         return pdist.reduce_summaries(pdist.gather_summaries(local_vec, self.cdev))
 
     def close(self):
-        if self.world > 1:
+        if self.grouped:
             import torch.distributed as dist
             dist.destroy_process_group()
 
@@ -777,12 +784,12 @@ def bench_pppe_train(args, rk):
         rng = np.random.default_rng(rk.rank)
         starts = [[rng.integers(0, N_POINTS, Bt), rng.integers(0, N_POINTS, Bt)], rng.integers(0, 512, Bt), rng.integers(0, 128, Bt)]
         keep = {}
-        kw = dict(lam=1e-3, data_parallel=rk.world > 1)
+        kw = dict(lam=1e-3, data_parallel=rk.grouped)
         if autocast:
             kw["autocast"] = True
         if args.graph:
             gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=autocast, warmup=max(warmup, 1),
-                                           data_parallel=rk.world > 1)     # N > 1: two graphs cut at the gradient all-reduce
+                                           data_parallel=rk.grouped)     # N > 1: two graphs cut at the gradient all-reduce
             dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), steps, torch.cuda.synchronize)
             keep["o"] = tuple(float(t) for t in keep["o"])
         else:
@@ -836,8 +843,8 @@ def bench_pppe_train(args, rk):
                      if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": f"pppe PointCloudAE training step (configs[4]), batch {Bt} x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
-                       "launch": ("one hipGraph replay per step" if rk.world == 1 else "two hipGraph replays per step around the RCCL gradient all-reduce")
-                                 if args.graph else "eager" + (" (gradient all-reduce overlapped with backward)" if rk.world > 1 else "")},
+                       "launch": ("one hipGraph replay per step" if not rk.grouped else "two hipGraph replays per step around the RCCL gradient all-reduce")
+                                 if args.graph else "eager" + (" (gradient all-reduce overlapped with backward)" if rk.grouped else "")},
             "batch_sweep": sweep or None, "other_arithmetic": other,
             "roofline": rf, "cpu_baseline": cpu,
             "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": loss}), flush=True)

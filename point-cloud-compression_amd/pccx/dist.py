@@ -2,11 +2,22 @@
 i mod world, no data-path collective.  The only exchanges are a MAX of wall time and an all-gather of
 tiny per-rank summaries (sum bits, sum points, sum PSNR, sum Chamfer, files, seconds) -- tens of
 bytes over RCCL/xGMI, latency-bound."""
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 SUMMARY_FIELDS = ("bits", "points", "psnr_sum", "chamfer_sum", "files", "seconds")
+
+
+def collectives_active():
+    """True when the exchanges below really go through the process group: more than one rank -- or ONE rank with
+    PCCX_DIST_SINGLE_RANK=1, the rehearsal of the RCCL path a one-GPU box allows (RCCL refuses two ranks on one device, but a one-rank
+    communicator runs the same ncclAllReduce / ncclAllGather kernels on the same streams; tests/test_gpu_dp.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PCCX_DIST_SINGLE_RANK") == "1"
 
 
 def shard_indices(n_files, rank, world):
@@ -23,7 +34,7 @@ def fps_start_index(seed, file_index, n_points):
 def gather_summaries(local, device=None):
     """all_gather of a per-rank fp64 summary vector -> (world, len) tensor on every rank."""
     t = torch.as_tensor(local, dtype=torch.float64, device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return t[None]
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
@@ -42,7 +53,7 @@ def reduce_summaries(gathered):
 
 def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
 
@@ -53,7 +64,7 @@ def allreduce_mean_(tensors, bucket_bytes=64 << 20):
     a few large messages beat many small ones; the pppe model is 116 MB of fp32 gradients = 2 buckets),
     all-reduce each bucket over the default process group (RCCL on GPUs, gloo in the CPU rehearsal) and
     scatter the averages back in place.  No-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return 0
     world = dist.get_world_size()
     n_buckets, cur, size = 0, [], 0
@@ -119,7 +130,7 @@ class GradBuckets:
         self.enabled = False
 
     def active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return collectives_active()
 
     def begin(self):
         """Call before backward()."""
