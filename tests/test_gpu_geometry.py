@@ -262,6 +262,38 @@ def test_chamfer_backward_matches_autograd_of_the_definition(P, Q):
     np.testing.assert_allclose(yg.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-4, atol=1e-9)
 
 
+def test_chamfer_backward_with_thousands_of_points_sharing_a_neighbour():
+    """The scatter half of the gradient when the reconstruction is a blob (an untrained decoder): every target point's nearest
+    neighbour is one of a handful of reconstructed points, so the kernel's per-wave combining rounds carry almost all of the sum;
+    a second cloud pair has all rows distinct inside most waves (the plain path).  The expected gradient is the definition's
+    (AE.py:57-70: 2 (x - y_nn) / (B P) to x and its negative scattered to y_nn, and symmetrically) summed in float64 over the
+    assignment the GPU's own nearest-neighbour pass made -- inside the blob the float32 and float64 arg-mins differ for a few points,
+    which is the search's rounding (tested above), not the gradient kernel's business."""
+    rng = np.random.default_rng(77)
+    P = Q = 4096
+    x = np.stack([0.5 + 1e-3 * rng.random((P, 3)), rng.random((P, 3))]).astype(np.float32)
+    x[0, :5] = rng.random((5, 3))                               # five points outside the blob: a few distinct heavy rows
+    y = rng.random((2, Q, 3)).astype(np.float32)
+    xg, yg = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    loss, _ = ops.chamfer_distance(xg, yg)
+    loss.backward()
+    nxy = ops.nn_dist(dev(x), dev(y), return_idx=True)[1].cpu().numpy()
+    nyx = ops.nn_dist(dev(y), dev(x), return_idx=True)[1].cpu().numpy()
+    assert np.unique(nyx[0]).size < 64                          # the case is what it claims: < 64 distinct neighbours for 4096 points
+    gx, gy = np.zeros((2, P, 3)), np.zeros((2, Q, 3))
+    for b in range(2):
+        dx = 2.0 * (x[b].astype(np.float64) - y[b][nxy[b]]) / (2 * P)
+        dy = 2.0 * (y[b].astype(np.float64) - x[b][nyx[b]]) / (2 * Q)
+        gx[b] += dx
+        np.add.at(gy[b], nxy[b], -dx)
+        gy[b] += dy
+        np.add.at(gx[b], nyx[b], -dy)
+    scale = float(np.abs(gx).max())
+    assert scale > 100 * float(np.abs(gx[1]).max())             # the heavy rows really carry thousands of contributions
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), gx, rtol=1e-4, atol=2e-6 * scale)
+    np.testing.assert_allclose(yg.grad.cpu().numpy(), gy, rtol=1e-4, atol=2e-6 * scale)
+
+
 def test_radix_sort_is_the_stable_sort_and_block_gather_scatter_are_its_inverse_pair():
     """csrc/sort.hip (configs[3]'s block partition): pccx_sort_keys_u64 = torch.sort(keys, stable=True) -- keys sorted in place and
     the permutation identical, ties in input order -- on sizes around the 4096-key tile, with heavy duplication, with keys that use
