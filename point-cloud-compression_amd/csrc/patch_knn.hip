@@ -47,17 +47,40 @@ __global__ __launch_bounds__(256) void patch_knn16_kernel(const float *__restric
 #else
             const float *cand = sx;                      // LDS broadcast reads
 #endif
-            for (int j0 = 0; j0 < K; j0 += PK_UNROLL) {  // K % 16 == 0; PK_UNROLL candidates in flight
-                float d[PK_UNROLL];
+            // Candidate ORDER and SKIPS (round 4).  The 17 smallest keys do not depend on the order the candidates arrive in (the
+            // keys are distinct: the index is part of the key), and a key >= tk[16] leaves the ladder as it is -- so a group of
+            // PK_UNROLL candidates whose keys are >= tk[16] in EVERY lane of the wave is skipped outright (one ballot), bit-identical
+            // by construction.  To make that happen the wave starts with the 16-candidate chunks around its own points and walks
+            // outwards in both directions: a patch is sorted by distance from its centre (compress.py:105-108, knn_points returns
+            // sorted neighbours), a wave's 64 queries are a ring of it, after the nearby rings tk[16] is close to its final
+            // value, and the far rings' points are farther than that from every query of the ring (|r_c - r_q| <= d(c, q)).
+            const int nch = K / 16;
+            const int c0 = __builtin_amdgcn_readfirstlane(i >> 4) & ~3;   // first chunk of the wave's own 64 points
+            int up = c0, down = c0 - 1;
+            for (int t = 0; t < nch; ++t) {
+                // own four chunks first, then alternately one chunk above / one below while both sides last
+                int ch;
+                if (t < 4 || down < 0 || (up < nch && ((t & 1) == 0))) ch = up < nch ? up++ : down--;
+                else ch = down--;
+                for (int j0 = 16 * ch; j0 < 16 * ch + 16; j0 += PK_UNROLL) {  // PK_UNROLL candidates in flight
+                    float d[PK_UNROLL];
+                    unsigned key[PK_UNROLL];
 #pragma unroll
-                for (int u = 0; u < PK_UNROLL; ++u)
-                    d[u] = pccx_sqdist(px, py, pz, cand[3 * (j0 + u)], cand[3 * (j0 + u) + 1], cand[3 * (j0 + u) + 2]);
+                    for (int u = 0; u < PK_UNROLL; ++u)
+                        d[u] = pccx_sqdist(px, py, pz, cand[3 * (j0 + u)], cand[3 * (j0 + u) + 1], cand[3 * (j0 + u) + 2]);
+                    unsigned kmin = 0xFFFFFFFFu;
 #pragma unroll
-                for (int u = 0; u < PK_UNROLL; ++u) {
-                    const unsigned key = (__float_as_uint(d[u]) & ~jmask) | (unsigned)(j0 + u);
+                    for (int u = 0; u < PK_UNROLL; ++u) {
+                        key[u] = (__float_as_uint(d[u]) & ~jmask) | (unsigned)(j0 + u);
+                        kmin = min(kmin, key[u]);
+                    }
+                    if (__ballot(kmin < tk[16]) == 0ull) continue;
 #pragma unroll
-                    for (int s = 16; s >= 1; --s) tk[s] = pk_umed3(tk[s - 1], key, tk[s]);
-                    tk[0] = min(tk[0], key);
+                    for (int u = 0; u < PK_UNROLL; ++u) {
+#pragma unroll
+                        for (int s = 16; s >= 1; --s) tk[s] = pk_umed3(tk[s - 1], key[u], tk[s]);
+                        tk[0] = min(tk[0], key[u]);
+                    }
                 }
             }
             IDX out[16];
