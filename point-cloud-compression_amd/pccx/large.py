@@ -50,6 +50,39 @@ def morton_order(pc):
     return order
 
 
+_SIDE = {}
+
+
+def morton_orders(clouds, streams=8):
+    """morton_order of several clouds, each on a side stream of its own (up to ``streams``): one room's sort is 16 launches of ~180
+    workgroups, less than the chip's 256 CUs, so eight rooms' sorts run side by side instead of one after the other (configs[3]: 3.1 ->
+    ~0.8 ms of the step).  Every buffer is allocated on the CURRENT stream before the fork and the current stream waits for all side
+    streams before this returns, so callers see ordinary stream semantics."""
+    if len(clouds) <= 1 or not clouds[0].is_cuda:
+        return [morton_order(pc) for pc in clouds]
+    dev = clouds[0].device
+    main = torch.cuda.current_stream(dev)
+    pool = _SIDE.setdefault(str(dev), [])
+    while len(pool) < min(streams, len(clouds)):
+        pool.append(torch.cuda.Stream(device=dev))
+    lib = _lib.load()
+    bufs = []
+    for pc in clouds:
+        n = int(pc.shape[0])
+        bufs.append((torch.empty(n, device=dev, dtype=torch.int64), torch.empty(6, device=dev, dtype=torch.int32),
+                     torch.empty(n, device=dev, dtype=torch.int64), torch.empty(lib.pccx_sort_keys_workspace_bytes(n), device=dev, dtype=torch.uint8)))
+    used = pool[:min(streams, len(clouds))]
+    for st in used:
+        st.wait_stream(main)
+    for i, (pc, (keys, bbox, order, ws)) in enumerate(zip(clouds, bufs)):
+        h = used[i % len(used)].cuda_stream
+        _lib.call("pccx_morton_keys_auto", pc.data_ptr(), pc.shape[0], keys.data_ptr(), bbox.data_ptr(), h)
+        _lib.call("pccx_sort_keys_u64", keys.data_ptr(), pc.shape[0], 63, order.data_ptr(), ws.data_ptr(), h)
+    for st in used:
+        main.wait_stream(st)
+    return [b[2] for b in bufs]
+
+
 def gather_blocks(pc, order, block=8192, first=0, stride=1, count=None, out=None):
     """Blocks first, first + stride, ... (count of them; default: every block) of pc in the order `order`, as (count, block, 3); the
     last block of the cloud is completed with copies of its final point.  ``out``: a (count, block, 3) slice to write into."""
@@ -166,9 +199,9 @@ def compress_large_many(codec, clouds, seed=11, rank=0, world=1, block=8192, bat
     from . import dist
     metas, first = [], 0
     clouds = [_f32c(pc, "compress_large_many") for pc in clouds]
-    for pc in clouds:
+    for pc, order in zip(clouds, morton_orders(clouds)):
         nb = (int(pc.shape[0]) + block - 1) // block
-        metas.append((first, nb, morton_order(pc), int(pc.shape[0])))
+        metas.append((first, nb, order, int(pc.shape[0])))
         first += nb
     mine = dist.shard_indices(first, rank, world)
     parts = []

@@ -320,6 +320,13 @@ def test_radix_sort_is_the_stable_sort_and_block_gather_scatter_are_its_inverse_
     idx = torch.cat([order, order[-1:].expand(nb * block - pc.shape[0])])
     want = pc[idx].view(nb, block, 3)
     assert torch.equal(large.gather_blocks(pc, order, block), want)
+    # several clouds at once: each sort on a side stream of its own, results as from one-by-one calls on the current stream
+    many = [torch.from_numpy(rng.random((n, 3)).astype(np.float32)).cuda() for n in (70_001, 5, 8192, 300_000, 1, 4097, 65_536, 9, 12_345, 100)]
+    got = large.morton_orders(many)
+    total = sum(int(o.sum()) for o in got)                           # consumed on the current stream right away: the join must hold
+    for pc_i, o in zip(many, got):
+        assert torch.equal(o, large.morton_order(pc_i))
+    assert total == sum(n * (n - 1) // 2 for n in (70_001, 5, 8192, 300_000, 1, 4097, 65_536, 9, 12_345, 100))
     assert torch.equal(large.gather_blocks(pc, order, block, first=1, stride=2), want[1::2])
     back = large.unsplit_blocks(want, list(range(nb)), order, pc.shape[0], block)
     assert torch.equal(back, pc)
