@@ -98,7 +98,7 @@
 // W0 [17 kt][32 mt], then for each pair of layer-1 output tiles mp: W1 [32 kt][2mp..2mp+1] and W2 k-tiles 2mp, 2mp+1 [8 mt].
 #define PRB_WS_CHUNK 8
 #define PRB_STREAM (PRB_M_W2 + 32 * 8 * 256)
-#define PRB_STREAM_FRAGS (17 * 32 + 16 * (32 * 2 + 2 * 8))
+#define PRB_STREAM_FRAGS (1 * 32 + 16 * (32 * 2 + 2 * 8))   // layer 0's xyz k-tile, then layers 1 / 2 (its 16 feature k-tiles are read from PRB_M_W0 once per cloud)
 #define PRB_STREAM_CHUNKS (4 * ((PRB_STREAM_FRAGS + 4 * PRB_WS_CHUNK - 1) / (4 * PRB_WS_CHUNK)))      // multiple of the ring depth
 #define PRB_BLOB_FLOATS (PRB_STREAM + (size_t)PRB_STREAM_CHUNKS * PRB_WS_CHUNK * 256)
 

@@ -168,7 +168,7 @@ extern "C" int pccx_pack_prob(const float *p_w0, const float *p_b0, const float 
             memcpy(st + (size_t)f * 256, blob + base + ((size_t)kt * MT + mt) * 256, 256 * sizeof(float));
             ++f;
         };
-        for (int kt = 0; kt < 17; ++kt) for (int mt = 0; mt < 32; ++mt) put(PRB_M_W0, 32, kt, mt);
+        for (int mt = 0; mt < 32; ++mt) put(PRB_M_W0, 32, 16, mt);          // layer 0: only the xyz k-tile is per centre (prob.hip)
         for (int mp = 0; mp < 16; ++mp) {
             for (int kt = 0; kt < 32; ++kt) for (int m = 0; m < 2; ++m) put(PRB_M_W1, 32, kt, 2 * mp + m);
             for (int k2 = 0; k2 < 2; ++k2) for (int mt = 0; mt < 8; ++mt) put(PRB_M_W2, 8, 2 * mp + k2, mt);

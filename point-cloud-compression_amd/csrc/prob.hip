@@ -3,7 +3,11 @@
 //
 // Workgroup = one cloud (S decoded patch centres, S % 16 == 0), 4 waves.
 //   pass 1: PointNet 3->64->128->256 on every centre tile, max over all S centres -> LDS feature
-//   pass 2: per tile, Conv 259->512->512->d*L (feature broadcast + xyz), logits -> LDS,
+//   pass 1b: the first Conv's contribution of the 256 feature channels, b0 + W0[:, :256] feat -- the same 512 numbers for every
+//           centre of the cloud (AE.py:115-116 concatenates the repeated feature) -- ONCE per cloud, a quarter of the rows per wave,
+//           by the same MFMA chain in the same order a centre's column would run (bit-identical to evaluating it per centre,
+//           which rounds 1-3 did: 28 % of pass 2's matrix work)
+//   pass 2: per tile, Conv 259->512->512->d*L (that vector + the xyz k-tile), logits -> LDS,
 //           softmax over L per (centre, latent dim), cumsum, clamp, integer CDF.
 // Runs on both sides of the codec from bit-identical centres with a fixed summation order, so the
 // encoder's and the decoder's integer CDFs are identical (a range-coder requirement).
@@ -19,6 +23,7 @@ __global__ __launch_bounds__(256, 2) void prob_forward_kernel(const float *__res
 {
     __shared__ __attribute__((aligned(16))) f32x4 swt[4 * PRB_WS_CHUNK * 64];   // 32 KiB weight ring, four chunks deep
     __shared__ __attribute__((aligned(16))) float sfeat[256];
+    __shared__ __attribute__((aligned(16))) float su[512];
     __shared__ float smax[4][256];
     __shared__ __attribute__((aligned(16))) float slog[4][16][128];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -72,6 +77,22 @@ __global__ __launch_bounds__(256, 2) void prob_forward_kernel(const float *__res
     sfeat[tid] = fmaxf(fmaxf(smax[0][tid], smax[1][tid]), fmaxf(smax[2][tid], smax[3][tid]));
     __syncthreads();
 
+    // ---- pass 1b: u = b0 + W0[:, feature channels] feat, rows 128 w .. 128 w + 127 in wave w (fragments from L2, as pass 1's)
+    {
+        const float *bl = opaque_uniform(blob);
+        f32x4 fin[1][16];
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) fin[0][kt] = *(const f32x4 *)(sfeat + 16 * kt + 4 * g);
+        f32x4 u[1][8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) u[0][m] = *(const f32x4 *)(bl + PRB_M_B0 + 16 * (8 * wu + m) + 4 * g);
+        dense_acc<16, 8, 1, 32>((const f32x4 *)(bl + PRB_M_W0), lane, fin, u, 0, 8 * wu);
+        if (n == 0)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) *(f32x4 *)(su + 16 * (8 * wu + m) + 4 * g) = u[0][m];
+    }
+    __syncthreads();
+
     // ---- pass 2: model_mlp (AE.py:97-105,115-118) + softmax (AE.py:120) + cdf
     const int Lp = L + 1;
     for (int tile0 = 0; tile0 < ntiles; tile0 += 4) {
@@ -91,19 +112,14 @@ __global__ __launch_bounds__(256, 2) void prob_forward_kernel(const float *__res
             int f = 0;
             f32x4 a0[1][32];
 #pragma unroll
-            for (int mt = 0; mt < 32; ++mt) a0[0][mt] = *(const f32x4 *)(bl + PRB_M_B0 + 16 * mt + 4 * g);
-#pragma unroll
-            for (int kt = 0; kt < 17; ++kt) {
+            for (int mt = 0; mt < 32; ++mt) a0[0][mt] = *(const f32x4 *)(su + 16 * mt + 4 * g);       // bias + the feature k-tiles (pass 1b)
+            {
                 f32x4 in[1][1];
-                if (kt < 16) {
-                    in[0][0] = *(const f32x4 *)(sfeat + 16 * kt + 4 * g);      // feature, same for every centre
-                } else {
-                    in[0][0][0] = g == 0 ? cp[3 * c] : 0.f;
-                    in[0][0][1] = g == 0 ? cp[3 * c + 1] : 0.f;
-                    in[0][0][2] = g == 0 ? cp[3 * c + 2] : 0.f;
-                    in[0][0][3] = 0.f;
-                }
-                dense_acc_stream<1, 32, 1>(ws, f, in, a0);
+                in[0][0][0] = g == 0 ? cp[3 * c] : 0.f;
+                in[0][0][1] = g == 0 ? cp[3 * c + 1] : 0.f;
+                in[0][0][2] = g == 0 ? cp[3 * c + 2] : 0.f;
+                in[0][0][3] = 0.f;
+                dense_acc_stream<1, 32, 1>(ws, f, in, a0);                                              // the xyz k-tile, last as before
             }
 #pragma unroll
             for (int mt = 0; mt < 32; ++mt) a0[0][mt] = relu4(a0[0][mt]);
