@@ -398,14 +398,9 @@ def roofline_of(stages, steps, P, matmul, batch):
     else:
         peak, note = F32_MATRIX_PEAK_TFLOPS, "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) against the fp32 matrix peak"
     traffic, src = committed_traffic(dom, batch, matmul)
+    # every stage of STAGE_FLOP brackets ONE kernel (the in-patch neighbour tables of the fused encoders are a stage of their own,
+    # "patch_knn16", since round 4): `achieved` is the kernel's algorithmic FLOPs over the HIP-event duration of its launches
     stage_kernels = [stage_kernel(dom, matmul)]
-    if dom == "sa_pn_forward":
-        # the stage's HIP events bracket TWO kernels: the in-patch neighbour tables (patch_knn16_kernel, no matrix work) and the fused encoder;
-        # `achieved` divides the encoder's FLOPs by the time of both (rocprofv3 lists them separately: profiles/*_kernel_stats.csv)
-        stage_kernels = ["patch_knn16_kernel"] + stage_kernels
-        t2, _ = committed_traffic_of("patch_knn16_kernel", batch)
-        if traffic is not None and t2 is not None:
-            traffic += t2
     rf = {"kernel": dom, "kernel_name": stage_kernel(dom, matmul), "stage_kernels": stage_kernels, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
           "traffic": traffic, "traffic_source": src, "launch_ms": dur_ms, "flop_per_launch": STAGE_FLOP[dom] * P,
           "arithmetic": matmul, "note": note, "window": "resident leg (single stream; HIP events per stage)",

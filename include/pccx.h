@@ -268,6 +268,12 @@ PCCX_API size_t pccx_ae_encode_b3_workspace_bytes(int P, int K);
 PCCX_API int pccx_ae_encode_b3_ws(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
                                   const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
                                   float *latent_q, void *workspace, void *stream);
+/* The fused kernel of pccx_ae_encode_b3_ws ALONE, on neighbour tables the caller has filled with pccx_patch_knn16(patches, P, K,
+ * tables, stream): the two launches as two calls, for a host that times or schedules them separately (bench.py's stage table).
+ * Replaces the same lines (compress.py:113-127). */
+PCCX_API int pccx_ae_encode_b3_tables(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
+                                      const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent,
+                                      float *latent_q, const void *tables, void *stream);
 PCCX_API size_t pccx_dec_b3_blob_floats(int k);
 PCCX_API int pccx_pack_ae_decoder_b3(const float *dec_blob_dev, int k, float *b3_blob_dev, void *stream);
 PCCX_API size_t pccx_ae_decode_b3_workspace_floats(int P);
@@ -297,6 +303,9 @@ PCCX_API int pccx_ae_encode_h2_fused_ok(int K);
 PCCX_API size_t pccx_ae_encode_h2_workspace_bytes(int P, int K);
 PCCX_API int pccx_ae_encode_h2_ws(const float *patches, int P, int K, const float *enc_blob, const float *h2_blob, int d, int L,
                                   float *latent_raw, float *latent, float *latent_q, void *workspace, void *stream);
+/* the fused f16x2 kernel alone on caller-filled tables, as pccx_ae_encode_b3_tables (compress.py:113-127) */
+PCCX_API int pccx_ae_encode_h2_tables(const float *patches, int P, int K, const float *enc_blob, const float *h2_blob, int d, int L,
+                                      float *latent_raw, float *latent, float *latent_q, const void *tables, void *stream);
 PCCX_API size_t pccx_ae_decoder_h2_blob_floats(int k);
 PCCX_API int pccx_pack_ae_decoder_h2(const float *ip_w0, const float *ip_b0, const float *ip_w1, const float *ip_b1,
                                      const float *ip_w2, const float *ip_b2, const float *m_w0, const float *m_b0,

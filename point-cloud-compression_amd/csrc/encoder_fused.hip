@@ -425,3 +425,15 @@ extern "C" int pccx_ae_encode_b3_ws(const float *patches, int P, int K, const fl
     return fu_launch(patches, P, K, enc_blob, sa_b3_blob, pn_b3_blob, d, L, latent_raw, latent, latent_q, (const unsigned char *)workspace,
                      (hipStream_t)stream);
 }
+
+// the fused kernel alone, on neighbour tables the caller has filled with pccx_patch_knn16 (see pccx_ae_encode_h2_tables)
+extern "C" int pccx_ae_encode_b3_tables(const float *patches, int P, int K, const float *enc_blob, const float *sa_b3_blob,
+                                        const float *pn_b3_blob, int d, int L, float *latent_raw, float *latent, float *latent_q,
+                                        const void *workspace, void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    FU_CHECK("pccx_ae_encode_b3_tables");
+    PCCX_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0, "pccx_ae_encode_b3_tables: null or misaligned tables");
+    return fu_launch(patches, P, K, enc_blob, sa_b3_blob, pn_b3_blob, d, L, latent_raw, latent, latent_q, (const unsigned char *)workspace,
+                     (hipStream_t)stream);
+}

@@ -388,6 +388,8 @@ extern "C" int pccx_ae_encode_h2_fused_ok(int K)
 }
 
 extern "C" size_t pccx_ae_encode_h2_workspace_bytes(int P, int K) { return pccx_patch_knn16_bytes(P, K); }
+extern "C" int pccx_ae_encode_h2_tables(const float *patches, int P, int K, const float *enc_blob, const float *h2_blob, int d, int L,
+                                        float *latent_raw, float *latent, float *latent_q, const void *workspace, void *stream);
 
 // patches (P, K, 3) -> latent_raw / latent / latent_q (P, d) each.  enc_blob: pccx_pack_ae_encoder (conv0 runs in fp32 from it),
 // h2_blob: pccx_pack_ae_encoder_h2, both on the device; workspace: pccx_ae_encode_h2_workspace_bytes(P, K) bytes for the in-patch
@@ -396,11 +398,23 @@ extern "C" int pccx_ae_encode_h2_ws(const float *patches, int P, int K, const fl
                                     float *latent_raw, float *latent, float *latent_q, void *workspace, void *stream)
 {
     if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(patches && enc_blob && h2_blob && latent_raw && latent && latent_q && workspace, "pccx_ae_encode_h2_ws: null pointer");
+    PCCX_CHECK_ARG(patches && workspace, "pccx_ae_encode_h2_ws: null pointer");
     PCCX_CHECK_ARG(P >= 0 && pccx_ae_encode_h2_fused_ok(K), "pccx_ae_encode_h2_ws: K=%d does not fit the fused kernel (pccx_ae_encode_h2_fused_ok)", K);
-    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode_h2_ws: unsupported d=%d L=%d", d, L);
     const int rc = pccx_patch_knn16(patches, P, K, workspace, stream);
     if (rc != PCCX_OK) return rc;
+    return pccx_ae_encode_h2_tables(patches, P, K, enc_blob, h2_blob, d, L, latent_raw, latent, latent_q, workspace, stream);
+}
+
+// the fused kernel alone, on neighbour tables the caller has filled with pccx_patch_knn16 (the two launches of pccx_ae_encode_h2_ws as
+// two calls: what a host that times or schedules the kernels separately uses -- bench.py's stage table)
+extern "C" int pccx_ae_encode_h2_tables(const float *patches, int P, int K, const float *enc_blob, const float *h2_blob, int d, int L,
+                                        float *latent_raw, float *latent, float *latent_q, const void *workspace, void *stream)
+{
+    if (P == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(patches && enc_blob && h2_blob && latent_raw && latent && latent_q && workspace, "pccx_ae_encode_h2_tables: null pointer");
+    PCCX_CHECK_ARG(P >= 0 && pccx_ae_encode_h2_fused_ok(K), "pccx_ae_encode_h2_tables: K=%d does not fit the fused kernel (pccx_ae_encode_h2_fused_ok)", K);
+    PCCX_CHECK_ARG(d >= 1 && d <= 16 && L >= 1, "pccx_ae_encode_h2_tables: unsupported d=%d L=%d", d, L);
+    PCCX_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "pccx_ae_encode_h2_tables: the tables must be 16-byte aligned");
     const float spread = (float)((double)L - 0.2);
     const float half = (float)(((double)L - 0.2) / 2);
     const int grid = P < 2048 ? P : 2048;

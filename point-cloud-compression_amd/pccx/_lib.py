@@ -65,6 +65,7 @@ _SIGNATURES = {
     "pccx_patch_knn16": [_P, C.c_int, C.c_int, _P, _P],
     "pccx_ae_encode_b3_workspace_bytes": [C.c_int, C.c_int],
     "pccx_ae_encode_b3_ws": [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "pccx_ae_encode_b3_tables": [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_dec_b3_blob_floats": [C.c_int],
     "pccx_pack_ae_decoder_b3": [_P, C.c_int, _P, _P],
     "pccx_ae_decode_b3_workspace_floats": [C.c_int],
@@ -74,6 +75,7 @@ _SIGNATURES = {
     "pccx_ae_encode_h2_fused_ok": [C.c_int],
     "pccx_ae_encode_h2_workspace_bytes": [C.c_int, C.c_int],
     "pccx_ae_encode_h2_ws": [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "pccx_ae_encode_h2_tables": [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "pccx_ae_decoder_h2_blob_floats": [C.c_int],
     "pccx_pack_ae_decoder_h2": [_P] * 14 + [C.c_int, C.c_int, _P],
     "pccx_ae_decode_h2_workspace_floats": [C.c_int],
