@@ -36,6 +36,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "point-cloud-compression_amd"))
 
+# The host-to-host window overlaps its copies (packed streams out and back, 100 MB of XYZ out per step) with the kernels of the neighbouring
+# steps.  That only holds while the copies run on the DMA ENGINES: as blit kernels (`__amd_rocclr_copyBuffer`, what the runtime uses with
+# HSA_ENABLE_SDMA=0 and under rocprofv3) a 100 MB device-to-host copy stalls whatever kernel runs beside it for its whole 1.8 ms (the
+# kernel's end-of-kernel release waits for the shader's PCIe writes; profiles/round4_kernel_trace.csv: normalize_kernel 52 us alone, 1838 us
+# beside the copy) -- measured +2.2 ms per step with SDMA off against +0.0-0.3 with it on.  Said before the runtime starts; a value the
+# environment already holds is left alone and reported in the line (`copy_engine`).
+os.environ.setdefault("HSA_ENABLE_SDMA", "1")
+
 N_POINTS, K_PATCH, ALPHA, N0, D_LAT, L_LEV = 8192, 256, 2, 1024, 16, 7
 S_PATCH = N_POINTS * ALPHA // K_PATCH
 AE_SEED, PROB_SEED = 11, 12
@@ -570,6 +578,7 @@ def bench_ipdae(args, rk):
             "value": rk.world * pts / main["dt_host"], "unit": "points/s",
             "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * main["dt_host"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "copy_engine": "HSA_ENABLE_SDMA=" + os.environ.get("HSA_ENABLE_SDMA", "unset"),
             "window": "host-to-host: cloud in HBM -> .s/.p/.c bytes on the host (compress.py:85-154) -> XYZ on the host "
                       "(decompress.py:77-118); kernels on one stream, copies overlapped on a copy stream",
             "value_resident": rk.world * pts / main["dt_res"], "ms_per_step_resident": 1e3 * main["dt_res"] / args.steps,
