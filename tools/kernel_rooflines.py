@@ -129,7 +129,9 @@ def main():
         row(f"ae_decode (head + main) [{mode}]", timed(lambda: ae.decode(lq, matmul=mode), args.iters), "mfma", B * S * 41.4e6, "TFLOP/s",
             round(peak, 1), "AE.py:19-27")
     ms = timed(lambda: prob.run(centres, ("cdf_int",)), args.iters)
-    row("prob_forward", ms, "mfma", B * 0.063e9, "TFLOP/s", MFMA_F32_PEAK, "one workgroup per cloud, NT=1: latency/L2 bound")
+    # executed FLOPs per cloud: model_pn 5.27 M + model_mlp per centre 2 (3 x 512 + 512 x 512 + 512 x 112) x 64 + the first Conv's feature part
+    # ONCE per cloud (2 x 256 x 512) = 46.6 M; the reference's formulation (feature part per centre) counts 63.1 M
+    row("prob_forward", ms, "mfma", B * 0.0466e9, "TFLOP/s", MFMA_F32_PEAK, "one workgroup per cloud, NT=1; executed FLOPs (the reference's per-centre form counts 1.35x)")
     cdf = prob.run(centres, ("cdf_int",))["cdf_int"]
     q = torch.randint(-3, 4, (B, S * d), device=dev).float()
     ms = timed(lambda: models.range_encode(cdf, q, L), args.iters)
