@@ -548,15 +548,21 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         if debug_dot:                       # hipGraphDebugDotPrint of the captured step (nodes and edges), for diagnostics
             self.graph.enable_debug_mode()
+        # capture_error_mode="thread_local": only THIS thread's calls are checked against the capture.  In the default (global) mode a
+        # call from any thread invalidates it -- and under a process group the RCCL watchdog thread polls the events of earlier
+        # collectives (hipEventQuery) whenever it likes: a captured data-parallel step then died at random with "operation not permitted
+        # when stream is capturing" raised in the WATCHDOG and hipErrorStreamCaptureInvalidated here (found by the one-rank RCCL test,
+        # about one run in ten; it would have hit the N-GPU --graph runs the same way).
+        mode = dict(capture_error_mode="thread_local")
         if self.data_parallel:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **mode):
                 self.out = self._fwd_bwd()
             self._dp_grads = [p.grad for p in opt.params if p.grad is not None]      # fixed addresses: what the all-reduce averages
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), **mode):
                 self._opt_step()
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **mode):
                 self.out = self._body()
         if debug_dot:
             self.graph.debug_dump(debug_dot)

@@ -69,19 +69,10 @@ def test_one_rank_rccl_communicator_runs_both_step_forms_and_the_summary_exchang
     if p.returncode != 0:                     # the child's own words, untruncated (pytest shows captured stdout of a failing test)
         print(o[-3000:])
         print("\n".join(l for l in e.splitlines() if not l.startswith("frame #"))[-8000:])
-    # the subject is the collectives.  torch's one-rank RCCL process aborted (SIGABRT from a c10d thread, no Python traceback, nothing from
-    # the GPU) once in about ten runs on these boxes and not again in six repeats of the same worker; cause not found.  After the worker
-    # has printed its checks that is a warning; before, the test SKIPS with the child's words -- unless they name a GPU fault or a Python
-    # error, which fail as they should.
-    if p.returncode != 0:
-        gpu_or_python = any(k in e for k in ("Memory access fault", "Traceback", "HSA_STATUS", "hipError"))
-        if "stage: checks done" in e and not gpu_or_python:
-            import warnings
-            warnings.warn(f"dp_worker exited with {p.returncode} after its checks were done (process-group teardown)")
-        elif p.returncode == -6 and not gpu_or_python:
-            pytest.skip("one-rank RCCL worker aborted inside torch.distributed before its checks: " + e[-600:])
-        else:
-            assert p.returncode == 0
+    # (This test found a real fault: about one run in ten the worker died with SIGABRT -- the RCCL watchdog thread polling an earlier
+    # collective's event while GraphedTrainStep was capturing, which in the default global capture mode invalidates the capture.  The step now
+    # captures in thread-local mode, train.py.)
+    assert p.returncode == 0
     r = json.loads([l for l in o.splitlines() if l.startswith("{")][-1])
     assert r["ok"] and r["backend"] == "nccl" and r["world"] == 1, json.dumps(r)
     assert r["eager_calls"] >= 2 and r["graph_calls"] >= 1 and r["two_graphs"]
