@@ -155,8 +155,8 @@ def seeded_state_dict(module, seed, gain=1.0, last_gain=None):
     return sd
 
 
-def host_cores():
-    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+def host_cores_available():
+    """Cores this process may use: the affinity mask capped by the cgroup CPU quota (the CPU leg runs on all of them)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -170,13 +170,26 @@ def host_cores():
                 n = min(n, max(1, q // per))
         except (OSError, ValueError):
             pass
-    # a one-GPU box is given a 16-core share of its host (more threads only thrash)
-    return max(1, min(n, int(os.environ.get("PCCX_CPU_THREADS", "16"))))
+    return max(1, n)
+
+
+def host_cores():
+    """Threads of the CPU legs: every core this process may use, unless PCCX_CPU_THREADS names a number (then `cores` in the line is that
+    number and `cores_available` beside it shows what was left unused)."""
+    n = host_cores_available()
+    forced = os.environ.get("PCCX_CPU_THREADS")
+    return max(1, min(n, int(forced))) if forced else n
+
+
+def cores_fields():
+    return {"cores": host_cores(), "cores_available": host_cores_available(), "cpu_count": os.cpu_count()}
 
 
 def cpu_baseline(max_clouds, budget_s):
     """Reference-structured CPU loop (oracle) on a bounded sample of the same workload: all host cores for ~2/3 of the
     budget (the reported value, with bpp and D1-PSNR of those clouds), then one thread for the rest."""
+    from pccx import launch as _launch
+    _launch.restore_affinity()                 # the CPU leg runs on every core the process was given, not only the GPU's NUMA node
     import numpy as np
     import torch
     from oracle import ref_model, ref_pipeline
@@ -205,7 +218,7 @@ def cpu_baseline(max_clouds, budget_s):
     cores = host_cores()
     n, tot, bpp, psnr, q32 = leg(cores, max_clouds, 4, budget_s * 2 / 3)
     n1, tot1, _, _, _ = leg(1, max(2, max_clouds // 4), 2, budget_s / 3)
-    return {"value": n * N_POINTS / tot, "unit": "points/s", "cores": cores, "kind": "port",
+    return {"value": n * N_POINTS / tot, "unit": "points/s", **cores_fields(), "kind": "port",
             "sample": f"{n} synthetic 8192-pt clouds (the first {n} of the GPU leg's seeds), compress+decompress windows of "
                       f"compress.py:85-154 / decompress.py:77-118, CPU restatement of the reference loop (torch CPU fp32 + C oracle)",
             "ms_per_cloud": 1e3 * tot / n, "bpp": bpp, "d1_psnr_db": psnr,
@@ -217,6 +230,8 @@ def cpu_baseline_blocks(blocks, starts, budget_s):
     """configs[3] beside the GPU number: the CPU restatement of the reference loop (oracle/ref_pipeline.py) on a bounded sample of the
     SAME 8192-point Morton blocks the GPU leg compresses (handed over from the device: the partition itself, one sort per room, is not
     re-done on the CPU), compress + decompress windows as in cpu_baseline()."""
+    from pccx import launch as _launch
+    _launch.restore_affinity()                 # the CPU leg runs on every core the process was given, not only the GPU's NUMA node
     import torch
     from oracle import ref_model, ref_pipeline
     ae = ref_model.AE(K_PATCH, K_SMALL, D_LAT, L_LEV).eval()
@@ -234,7 +249,7 @@ def cpu_baseline_blocks(blocks, starts, budget_s):
         bits += 8 * (len(o["s"]) + len(o["p"]) + len(o["c"]))
         psnr += ref_pipeline.d1_psnr(blocks[n], rec)
         n += 1
-    return {"value": n * N_POINTS / tot, "unit": "points/s", "cores": cores, "kind": "port",
+    return {"value": n * N_POINTS / tot, "unit": "points/s", **cores_fields(), "kind": "port",
             "sample": f"the first {n} of the GPU leg's 8192-point Morton blocks (room 0), compress+decompress windows of compress.py:85-154 / "
                       f"decompress.py:77-118 per block, CPU restatement of the reference loop (torch CPU fp32 + C oracle); partition not re-done",
             "ms_per_block": 1e3 * tot / n, "bpp": bits / (n * N_POINTS), "d1_psnr_db": psnr / n}
@@ -243,6 +258,8 @@ def cpu_baseline_blocks(blocks, starts, budget_s):
 def cpu_baseline_pppf(state_dict, patches, Kp, budget_s):
     """configs[2] beside the GPU number: the oracle's PPPF_AE forward (oracle/ref_families.py, torch CPU fp32, eval mode) on a bounded
     sample of the same patches, 8 patches (one cloud) per call as the reference's patch loop feeds the model."""
+    from pccx import launch as _launch
+    _launch.restore_affinity()                 # the CPU leg runs on every core the process was given, not only the GPU's NUMA node
     import torch
     from oracle import ref_families
     m = ref_families.PPPF_AE(K=Kp, k=Kp // ALPHA, d=16, L=7).eval()
@@ -258,7 +275,7 @@ def cpu_baseline_pppf(state_dict, patches, Kp, budget_s):
             m(x[n:n + 8])
             tot += time.time() - t1
             n += 8
-    return {"value": n * Kp / tot, "unit": "points/s", "cores": cores, "kind": "port",
+    return {"value": n * Kp / tot, "unit": "points/s", **cores_fields(), "kind": "port",
             "sample": f"the first {n} of the GPU leg's {Kp}-point patches, PPPF_AE forward (encode + decode) 8 patches per call, CPU restatement of "
                       f"PPPF_AE.py:114-150 (torch CPU fp32)", "ms_per_patch": 1e3 * tot / n}
 
@@ -267,6 +284,8 @@ def cpu_baseline_pppe_train(state_dict, x, starts, budget_s):
     """configs[4] beside the GPU number: the oracle's training iteration (oracle/ref_train.py: torch autograd + torch.optim.Adam on the
     restated PointCloudAE) on the same batch; the brute-force Chamfer of an 8192-point cloud makes one step seconds long, so the sample
     is a few steps (at least one after the warm-up)."""
+    from pccx import launch as _launch
+    _launch.restore_affinity()                 # the CPU leg runs on every core the process was given, not only the GPU's NUMA node
     import torch
     from oracle import ref_families, ref_train
     m = ref_families.PointCloudAE(64, 16, N_POINTS)
@@ -282,7 +301,7 @@ def cpu_baseline_pppe_train(state_dict, x, starts, budget_s):
         loss, _, _ = ref_train.train_step(m, opt, xb, starts, lam=1e-3)
         tot += time.time() - t1
         n += 1
-    return {"value": n * xb.shape[0] / tot, "unit": "clouds/s", "cores": cores, "kind": "port",
+    return {"value": n * xb.shape[0] / tot, "unit": "clouds/s", **cores_fields(), "kind": "port",
             "sample": f"{n} optimisation step(s) on the GPU leg's batch of {xb.shape[0]} x {N_POINTS} points, CPU restatement of "
                       f"train_pppe_pcd_ae.py:184-226 without autocast (torch autograd + torch.optim.Adam)", "ms_per_step": 1e3 * tot / n, "loss": loss}
 
@@ -309,7 +328,11 @@ class Ranks:
         else:
             self.dev = torch.device("cpu")
         self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where the tiny collectives live
-        self.info = {"rccl_world": 1, "dist_backend": None, "rank_devices": [self.local if self.gpu else None]}
+        numa = getattr(args, "numa", None) or {"numa_node": -1, "cpus_bound": 0, "mempolicy": False}
+        self.info = {"rccl_world": 1, "dist_backend": None, "rank_devices": [self.local if self.gpu else None],
+                     "rank_numa": [{"rank": 0, "numa_node": numa["numa_node"], "cpus_bound": numa["cpus_bound"], "mempolicy": bool(numa["mempolicy"]),
+                                    "note": numa.get("note")}]}
+        self.rank_seconds = {}
         # PCCX_DIST_SINGLE_RANK=1: a ONE-rank process group whose collectives really run (pccx.dist.collectives_active) -- the rehearsal of
         # the RCCL plumbing a one-GPU box allows; the line then says dist_backend "rccl ... one-rank rehearsal"
         self.grouped = self.world > 1 or os.environ.get("PCCX_DIST_SINGLE_RANK") == "1"
@@ -321,21 +344,38 @@ class Ranks:
             launch.init_process_group(self.backend, self.dev if self.backend == "nccl" else None)
             # what the driver can check an N-rank run by: the size of the process group the collectives ran on and the device
             # index every rank bound (one all_gather of an int, outside every timed region)
-            mine = torch.tensor([self.local if self.gpu else -1], dtype=torch.int64, device=self.cdev)
+            mine = torch.tensor([self.local if self.gpu else -1, numa["numa_node"], numa["cpus_bound"], int(bool(numa["mempolicy"]))],
+                                dtype=torch.int64, device=self.cdev)
             got = [torch.zeros_like(mine) for _ in range(self.world)]
             dist.all_gather(got, mine)
+            got = [[int(v) for v in t.tolist()] for t in got]
             self.info = {"rccl_world": dist.get_world_size(),
                          "dist_backend": ("rccl (torch 'nccl')" if self.backend == "nccl" else "gloo") + (", one-rank rehearsal" if self.world == 1 else ""),
-                         "rank_devices": [int(t[0]) if int(t[0]) >= 0 else None for t in got]}
+                         "rank_devices": [t[0] if t[0] >= 0 else None for t in got],
+                         # where every rank's host threads and new pages were placed BEFORE its first GPU call (pccx/launch.py)
+                         "rank_numa": [{"rank": r, "numa_node": t[1], "cpus_bound": t[2], "mempolicy": bool(t[3])} for r, t in enumerate(got)]}
 
     def barrier(self):
         if self.grouped:
             import torch.distributed as dist
             dist.barrier()
 
-    def max_seconds(self, dt):
+    def max_seconds(self, dt, tag=None):
+        """MAX over ranks of a timed region's wall time; with `tag`, every rank's own time is kept too (rank_seconds[tag]: a straggler
+        is visible in the line as per-rank ms_per_step min / max)."""
         from pccx import dist as pdist
-        return pdist.max_over_ranks(dt, self.cdev) if self.grouped else dt
+        if not self.grouped:
+            if tag:
+                self.rank_seconds[tag] = [dt]
+            return dt
+        if tag:
+            self.rank_seconds[tag] = [float(v) for v in pdist.gather_summaries([dt], self.cdev)[:, 0].tolist()]
+            return max(self.rank_seconds[tag])
+        return pdist.max_over_ranks(dt, self.cdev)
+
+    def rank_ms(self, tag, steps):
+        v = [1e3 * s_ / max(steps, 1) for s_ in self.rank_seconds.get(tag, [])]
+        return {"min": min(v), "max": max(v), "per_rank": [round(x, 4) for x in v]} if v else None
 
     def summaries(self, local_vec):
         """RCCL all_gather of the dist.SUMMARY_FIELDS vector (bits, points, psnr_sum, chamfer_sum, files, seconds)."""
@@ -348,32 +388,60 @@ class Ranks:
             dist.destroy_process_group()
 
 
-def timed(rk, fn, steps, sync):
-    """EXACTLY ``steps`` calls of fn between barrier + synchronize on both sides; MAX over ranks."""
+def timed(rk, fn, steps, sync, tag=None):
+    """EXACTLY ``steps`` calls of fn between barrier + synchronize on both sides; MAX over ranks.  With `tag`, each rank's time up to its
+    own synchronize (before the closing barrier) is kept as well (Ranks.rank_ms)."""
     rk.barrier()
     sync()
     t0 = time.perf_counter()
     for i in range(steps):
         fn(i)
     sync()
+    own = time.perf_counter() - t0
     rk.barrier()
-    return rk.max_seconds(time.perf_counter() - t0)
+    dt = time.perf_counter() - t0
+    if tag:
+        rk.max_seconds(own, tag)
+    return rk.max_seconds(dt)
 
 
 # =====================================================================================================================
 # workloads
 # =====================================================================================================================
+def cpu_leg_allowed(args, rk):
+    """The CPU baseline runs on rank 0 at N = 1 only (with N > 1 the ranks would wait in a barrier for a leg that says nothing about them)."""
+    return rk.world == 1 and args.cpu_clouds > 0
+
+
+def run_launch_stub(args, rk):
+    """A secondary 'workload' without GPU work, for the launch-check: one timed region (the same barriers as the real ones), a dict from rank 0."""
+    dt = timed(rk, lambda i: None, args.steps, lambda: None)
+    if rk.rank != 0:
+        return None
+    return {"metric": "launch-check stub", "value": float(rk.world), "n_gpus": rk.world, "steps": args.steps, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+            "cpu_baseline": {"value": 1.0, "cores": 1, "kind": "port", "sample": "none"} if cpu_leg_allowed(args, rk) else None}
+
+
 def bench_launch_check(args, rk):
     """No GPU: proves the self-launch (rank environment, rendezvous on 127.0.0.1, one JSON line from rank 0) and the
     summary all-gather; used by tests/test_sharding_gloo.py on CPU."""
     local = [1000.0 * (rk.rank + 1), 8192.0 * (rk.rank + 1), 30.0 + rk.rank, 1e-4 * (rk.rank + 1), float(rk.rank + 1), 0.5 + rk.rank]
     dt = timed(rk, lambda i: None, args.steps, lambda: None)
     s = rk.summaries(local)
+    res = None
     if rk.rank == 0:
-        print(json.dumps({"metric": "launch-check", "value": float(s["files"]), "unit": "files", "n_gpus": rk.world, **rk.info, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
-                          "config": {"workload": "launch-check (no GPU work)", "dist_backend": rk.backend}, "summary": s}), flush=True)
+        res = {"metric": "launch-check", "value": float(s["files"]), "unit": "files", "n_gpus": rk.world, **rk.info, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+               "config": {"workload": "launch-check (no GPU work)", "dist_backend": rk.backend}, "summary": s,
+               "cpu_baseline": {"value": 1.0, "cores": 1, "kind": "port", "sample": "none"} if cpu_leg_allowed(args, rk) else None}
+    # the default line's secondary block, with stubs for the three workloads: every rank runs them, rank 0 alone emits, once
+    if not args.no_secondary:
+        sec = run_secondaries(args, rk, res, specs=(("stub_a", "run_launch_stub", {}), ("stub_b", "run_launch_stub", {})))
+        if res is not None:
+            res["secondary"] = sec
+    if res is not None:
+        print(json.dumps(res), flush=True)
 
 
 def build_codec(rk, matmul, octree_mode):
@@ -417,6 +485,31 @@ def roofline_of(stages, steps, P, matmul, batch):
     return rf, per_step_ms, tfl
 
 
+def compare_modes(a, b, B, s_stride, p_cap, codec):
+    """The default arithmetic against the exact-fp32 one on the SAME clouds of the timed legs: quantised symbols, the bytes of the three files
+    per cloud, the reconstruction (absolute, in units of the cloud's longest side as the parity tests state it)."""
+    import torch
+    ca, cb = (codec.Compressed.from_packed(x["packed"], B, s_stride, p_cap, N_POINTS) for x in (a, b))
+
+    def rows_equal(ra, na, rb, nb):
+        m = torch.arange(ra.shape[1])[None, :] < na.long()[:, None]
+        return (na == nb) & ((ra == rb) | ~m).all(dim=1)
+    same_s = rows_equal(ca.s_bytes, ca.s_nbytes, cb.s_bytes, cb.s_nbytes)
+    same_p = rows_equal(ca.p_bytes, ca.p_nbytes, cb.p_bytes, cb.p_nbytes)
+    same_c = (ca.c.view(torch.int32) == cb.c.view(torch.int32)).all(dim=1)
+    qa, qb = a["q"].view(B, -1), b["q"].view(B, -1)
+    sym_same = (qa == qb).all(dim=1)
+    diff = (a["out"] - b["out"]).abs().amax(dim=(1, 2)) / a["longest"]
+    agree = diff[sym_same]
+    return {"clouds": B, "symbols": int(qa.numel()), "symbols_differing": int((qa != qb).sum()),
+            "clouds_with_identical_files": int((same_s & same_p & same_c).sum()),
+            "clouds_with_identical_s_bin": int(same_s.sum()), "clouds_with_identical_p_bin": int(same_p.sum()), "clouds_with_identical_c_bin": int(same_c.sum()),
+            "max_recon_diff": float((a["out"] - b["out"]).abs().max()), "max_recon_diff_over_longest": float(diff.max()),
+            "max_recon_diff_over_longest_where_symbols_agree": float(agree.max()) if agree.numel() else None,
+            "note": "both codecs run on the batch of the timed legs after them; a symbol differs only where the two arithmetics land on "
+                    "opposite sides of a rounding boundary (tests allow <= 1e-5 of the symbols); .p.bin may also differ by an integer-CDF entry +-1"}
+
+
 def bench_ipdae(args, rk):
     import numpy as np
     import torch
@@ -443,7 +536,7 @@ def bench_ipdae(args, rk):
     row = codec.packed_layout(1, s_stride, p_cap)[-1]                             # bytes per cloud
     nb_ = min(B, int(base.shape[0]))                # the unturned base shapes = the CPU leg's first clouds (cpu_baseline.same_clouds_as_gpu)
 
-    def measure(cd, with_files=False):
+    def measure(cd, with_files=False, keep_for_compare=False, rank_tag=None):
         """Both legs of one (arithmetic mode, octree mode): resident (per-stage events) and host-to-host (the reference's window)."""
         keep = {}
 
@@ -510,7 +603,7 @@ def bench_ipdae(args, rk):
         for i in range(nw):
             step_host(i, last=nw)
         sync()
-        r["dt_host"] = timed(rk, step_host, args.steps, sync)
+        r["dt_host"] = timed(rk, step_host, args.steps, sync, tag=rank_tag)
         last = (args.steps - 1) % 2
         r["host_equals_resident"] = bool(torch.equal(pin_out[last], out.cpu()))
         hc = codec.Compressed.from_packed(pin_comp[last], B, s_stride, p_cap, N_POINTS)
@@ -518,43 +611,94 @@ def bench_ipdae(args, rk):
         r["d2h_bytes_per_step"] = row * B + B * N_POINTS * 12
         del copy_stream, pin_comp, pin_out
         if with_files:
-            # ---- the window WITH the file system in it (compress.py:139-152 writes the three files inside its timer,
-            # decompress.py:80-91 reads them back inside its own): files on tmpfs, plain Python I/O as the reference does,
-            # synchronous (a secondary figure: 3 x B small files per step are the host's work, not the GPU's)
+            # ---- the window WITH the file system in it (compress.py:139-152 writes the three files of a cloud inside its timer,
+            # decompress.py:80-91,113 reads them back inside its own): the host-to-host leg with the files between its two copies.
+            # compress(i) -> D2H of the packed streams -> [host: pccx_write_streams_host cuts the 3 x B files out of that one buffer;
+            # pccx_read_streams_host fills the upload buffer from them] -> H2D -> decompress(i).  The host work of step i is done
+            # while the GPU runs compress(i + 1) (the kernels are queued before the host waits for the D2H), like the copies.
             import shutil
             import tempfile
             tmp = tempfile.mkdtemp(prefix="pccx_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            names = [f"{b_:05d}" for b_ in range(B)]
+            copy_stream = torch.cuda.Stream(device=dev)
+            pin_comp = [torch.empty(row * B, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            pin_up = [torch.zeros(row * B, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            pin_out = [torch.empty(B, N_POINTS, 3, dtype=torch.float32).pin_memory() for _ in range(2)]
+            pending, host_s = [], [0.0, 0.0, 0]
             try:
-                def step_files(i):
+                def finish_files(d2h, j):
+                    d2h.synchronize()                                        # the packed streams of that step are on the host
+                    t0 = time.perf_counter()
+                    codec.write_streams(pin_comp[j], B, s_stride, p_cap, tmp, names)          # compress.py:139-152
+                    t1 = time.perf_counter()
+                    codec.read_streams(pin_up[j], B, s_stride, p_cap, tmp, names)             # decompress.py:80-91,113
+                    t2 = time.perf_counter()
+                    host_s[0] += t1 - t0
+                    host_s[1] += t2 - t1
+                    host_s[2] += 1
+                    with torch.cuda.stream(copy_stream):
+                        up = pin_up[j].to(dev, non_blocking=True)
+                        ready = torch.cuda.Event()
+                        ready.record(copy_stream)
+                    up.record_stream(main_stream)
+                    main_stream.wait_event(ready)
+                    o = cd.decompress(codec.Compressed.from_packed(up, B, s_stride, p_cap, N_POINTS), S=S)
+                    done = torch.cuda.Event()
+                    done.record(main_stream)
+                    with torch.cuda.stream(copy_stream):
+                        copy_stream.wait_event(done)
+                        pin_out[j].copy_(o, non_blocking=True)
+                    o.record_stream(copy_stream)
+
+                def step_files(i, last=None):
+                    j = i % 2
                     c = cd.compress(clouds, starts)
-                    for b_ in range(B):
-                        for ext, blob in zip((".s.bin", ".p.bin", ".c.bin"), c.files(b_)):
-                            with open(os.path.join(tmp, f"{b_:05d}{ext}"), "wb") as f:
-                                f.write(blob)
-                    rd = lambda b_, ext: open(os.path.join(tmp, f"{b_:05d}{ext}"), "rb").read()
-                    sb = np.zeros((B, s_stride), dtype=np.uint8)
-                    pb = np.zeros((B, p_cap), dtype=np.uint8)
-                    sn, pn, cc = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros((B, 4), np.float32)
-                    for b_ in range(B):
-                        s_, p_, c_ = rd(b_, ".s.bin"), rd(b_, ".p.bin"), rd(b_, ".c.bin")
-                        sb[b_, :len(s_)] = np.frombuffer(s_, np.uint8); sn[b_] = len(s_)
-                        pb[b_, :len(p_)] = np.frombuffer(p_, np.uint8); pn[b_] = len(p_)
-                        cc[b_] = np.frombuffer(c_, np.float32)
-                    up = codec.Compressed(torch.from_numpy(sb).to(dev), torch.from_numpy(sn).to(dev), torch.from_numpy(pb).to(dev),
-                                          torch.from_numpy(pn).to(dev), torch.from_numpy(cc).to(dev), N_POINTS)
-                    keep["files_out"] = cd.decompress(up, S=S).cpu()
-                step_files(0)
-                nf = max(2, min(args.steps, 3))
-                r["dt_files"], r["files_steps"] = timed(rk, step_files, nf, sync), nf
-                r["files_equal_resident"] = bool(torch.equal(keep["files_out"], out.cpu()))
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)
+                    with torch.cuda.stream(copy_stream):
+                        copy_stream.wait_event(ev)
+                        pin_comp[j].copy_(c.packed, non_blocking=True)
+                        d2h = torch.cuda.Event()
+                        d2h.record(copy_stream)
+                    c.packed.record_stream(copy_stream)
+                    if pending:
+                        finish_files(*pending.pop())
+                    pending.append((d2h, j))
+                    if i == (args.steps if last is None else last) - 1:
+                        finish_files(*pending.pop())
+                copy_stream.wait_stream(main_stream)
+                nw = max(args.warmup, 2)
+                for i in range(nw):
+                    step_files(i, last=nw)
+                sync()
+                host_s[:] = [0.0, 0.0, 0]
+                r["dt_files"], r["files_steps"] = timed(rk, step_files, args.steps, sync), args.steps
+                last = (args.steps - 1) % 2
+                r["files_equal_resident"] = bool(torch.equal(pin_out[last], out.cpu()))
+                # the files themselves against Compressed.files(b) of the resident leg (the bytes compress.py would have written)
+                same = 0
+                for b_ in range(B):
+                    s_, p_, c_ = comp.files(b_)
+                    rd = lambda ext: open(os.path.join(tmp, names[b_] + ext), "rb").read()
+                    same += int(rd(".s.bin") == s_ and rd(".p.bin") == p_ and rd(".c.bin") == c_)
+                r["files_identical"] = same
+                r["files_host_ms"] = {"write": 1e3 * host_s[0] / max(host_s[2], 1), "read": 1e3 * host_s[1] / max(host_s[2], 1)}
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
+            del copy_stream, pin_comp, pin_up, pin_out
+        # what a comparison of two arithmetic modes needs (f16x2_vs_f32), kept on the host: symbols, file bytes, reconstruction
+        if keep_for_compare:
+            cx = cd.compress(clouds, starts, keep_extras=True)
+            r["cmp"] = {"q": cx.extras["latent_q"].to(torch.int8).cpu(), "packed": cx.packed.cpu(), "out": cd.decompress(cx, S=S).cpu(),
+                        "longest": cx.c[:, 3].cpu()}
         return r
 
     res_by_mode = {}
     for mode in modes:
         cd, _, _ = build_codec(rk, mode, args.octree_mode)
-        res_by_mode[mode] = measure(cd, with_files=args.with_files and mode == args.matmul)
+        res_by_mode[mode] = measure(cd, with_files=(not args.no_files) and mode == args.matmul,
+                                    keep_for_compare=mode in (args.matmul, "f32") and "f32" in modes and args.matmul != "f32",
+                                    rank_tag="host" if mode == args.matmul else None)   # the leg whose per-rank times go into the line
         del cd
         torch.cuda.empty_cache()
     # the same clouds in the OTHER octree mode, default arithmetic: "reference" reproduces octree_np.decode as written (<= 8 distinct
@@ -577,6 +721,7 @@ def bench_ipdae(args, rk):
             "metric": "points/sec compress+decompress (ModelNet40-shaped 8192 K=256)",
             "value": rk.world * pts / main["dt_host"], "unit": "points/s",
             "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * main["dt_host"] / args.steps,
+            "rank_ms_per_step": rk.rank_ms("host", args.steps),      # each rank's own time for the same steps (before the closing barrier)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "copy_engine": "HSA_ENABLE_SDMA=" + os.environ.get("HSA_ENABLE_SDMA", "unset"),
             "window": "host-to-host: cloud in HBM -> .s/.p/.c bytes on the host (compress.py:85-154) -> XYZ on the host "
@@ -620,25 +765,90 @@ def bench_ipdae(args, rk):
                 "the top-level line is the reference's decode as written (octree_np.py:47-112: <= 8 distinct centres per cloud)" if other_mode == "full" else "")
             res[other_mode + "_mode"] = rec
         if "dt_files" in main:
-            res["with_files"] = {"value": rk.world * B * N_POINTS * main["files_steps"] / main["dt_files"], "unit": "points/s",
-                                 "ms_per_step": 1e3 * main["dt_files"] / main["files_steps"], "steps": main["files_steps"],
-                                 "decoded_equals_resident": main["files_equal_resident"],
-                                 "note": "secondary figure: the three .bin files of every cloud written to and read back from tmpfs INSIDE the "
-                                         "timed window (compress.py:139-152, decompress.py:80-91), plain synchronous Python file I/O"}
+            wf = rk.world * B * N_POINTS * main["files_steps"] / main["dt_files"]
+            res["with_files"] = {"value": wf, "unit": "points/s", "ms_per_step": 1e3 * main["dt_files"] / main["files_steps"], "steps": main["files_steps"],
+                                 "frac_of_value": wf / res["value"], "decoded_equals_resident": main["files_equal_resident"],
+                                 "clouds_with_files_identical_to_resident": main["files_identical"], "clouds": B,
+                                 "host_ms_per_step": {k_: round(v, 3) for k_, v in main["files_host_ms"].items()},
+                                 "note": "the reference's window in full: the three .bin files of every cloud are written to and read back from tmpfs "
+                                         "INSIDE the timed region (compress.py:139-152, decompress.py:80-91,113) by the library's host threads "
+                                         "(pccx_write_streams_host / pccx_read_streams_host, csrc/hostio.hip), between the D2H of the packed streams "
+                                         "and their H2D; the host work of step i runs while the GPU executes compress(i+1)"}
+        if "cmp" in main and "cmp" in res_by_mode.get("f32", {}):
+            res[args.matmul + "_vs_f32"] = compare_modes(main.pop("cmp"), res_by_mode["f32"].pop("cmp"), B, s_stride, p_cap, codec)
         res["cpu_baseline"] = None
         print("[bench] gpu legs done: %.3e points/s host-to-host (%.2f ms/step), %.3e resident; dominant %s %.1f TFLOP/s (%.2f of %s peak)" %
               (res["value"], res["ms_per_step"], res["value_resident"], rf["kernel"], rf["achieved"], rf["frac"], args.matmul),
               file=sys.stderr, flush=True)
-        if rk.world == 1 and args.cpu_clouds > 0:
+        if cpu_leg_allowed(args, rk):
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_clouds, args.cpu_budget)
                 res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
             except Exception as e:   # the GPU line must survive a broken host toolchain
                 res["cpu_baseline_error"] = repr(e)
+    else:
+        res = None
+    # configs[2], [3], [4] in the same run (every rank takes part: their timed regions hold the same barriers), then ONE line from rank 0
+    if not args.no_secondary:
+        sec = run_secondaries(args, rk, res)
+        if res is not None:
+            res["secondary"] = sec
+    if res is not None:
         print(json.dumps(res), flush=True)
 
 
-def bench_s3dis(args, rk):
+SECONDARY = (("pppf", "run_pppf", {"batch": 256}), ("s3dis", "run_s3dis", {"batch": 1024}), ("pppe_train", "run_pppe_train", {"graph": True}))
+
+
+def run_secondaries(args, rk, headline, specs=None):
+    """BASELINE configs[2] (PPPF_AE forward), [3] (room-scale blocks) and [4] (pppe training step, hipGraph) measured by the SAME command
+    as the headline, each with its own roofline, stage table and -- at N = 1 -- CPU baseline (a 3 s sample each).  A leg that raises is
+    reported as {"error": ...}; a leg that HANGS cannot take the headline with it: a watchdog thread prints the line as it stands
+    (rank 0) and ends the process once --secondary-budget seconds have passed."""
+    import copy
+    import threading
+    import traceback
+    import torch
+    out, done = {}, threading.Event()
+    t_start = time.time()
+
+    def watchdog():
+        if done.wait(args.secondary_budget):
+            return
+        if headline is not None:
+            out_ = dict(out)
+            out_["error"] = "secondary workloads exceeded --secondary-budget %.0f s; the line was printed by the watchdog" % args.secondary_budget
+            headline["secondary"] = out_
+            print(json.dumps(headline), flush=True)
+        sys.stderr.write("[bench] secondary workloads timed out on rank %d: exiting\n" % rk.rank)
+        sys.stderr.flush()
+        os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    for name, fn, over in (SECONDARY if specs is None else specs):
+        a = copy.copy(args)
+        vars(a).update(over)
+        a.steps, a.warmup = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+        a.cpu_budget = 2 * args.secondary_cpu_budget                # the legs take cpu_budget / 2
+        t0 = time.time()
+        try:
+            r = globals()[fn](a, rk)
+        except Exception as e:                                      # the headline must survive a broken secondary leg
+            r = {"error": repr(e), "traceback": traceback.format_exc().splitlines()[-6:]}
+            if rk.rank != 0:
+                sys.stderr.write("[bench] rank %d: secondary %s failed: %r\n" % (rk.rank, name, e))
+        if r is not None:
+            r["wall_s"] = round(time.time() - t0, 2)
+            out[name] = r
+        if rk.gpu:
+            torch.cuda.empty_cache()
+        if rk.rank == 0:
+            print("[bench] secondary %s done in %.1f s" % (name, time.time() - t0), file=sys.stderr, flush=True)
+    done.set()
+    out["wall_s"] = round(time.time() - t_start, 2)
+    return out
+
+
+def run_s3dis(args, rk):
     """configs[3]: room-scale clouds (0.5-1 M points, synth.room_cloud(100+i)) cut into 8192-point Morton blocks that shard
     across ranks like files (large.py); a step = compress + decompress of every block of every room owned by this rank,
     reassembled with the inverse permutation.  Total work is fixed, so scaling is strong."""
@@ -679,14 +889,14 @@ def bench_s3dis(args, rk):
         rf, per_step_ms, _ = roofline_of(stages, args.steps, int(blocks) * S_PATCH / n_launch, args.matmul, int(blocks) / n_launch)
         rf["note"] += f"; mean over {n_launch} launches per step of <= {args.batch} blocks x {S_PATCH} patches"
         cpu = None
-        if rk.world == 1 and args.cpu_clouds > 0:
+        if cpu_leg_allowed(args, rk):
             try:
                 from pccx import dist as pdist
                 nb0 = min(int(keep["metas"][0][1]), 64)
                 cpu = cpu_baseline_blocks(flat[:nb0].cpu().numpy(), [pdist.fps_start_index(11, j, N_POINTS) for j in range(nb0)], args.cpu_budget / 2)
             except Exception as e:
                 cpu = {"error": repr(e)}
-        print(json.dumps({
+        return ({
             "metric": "points/sec compress+decompress, room-scale clouds in 8192-pt Morton blocks", "value": n_pts * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -697,10 +907,11 @@ def bench_s3dis(args, rk):
             "roofline": rf, "stage_ms_per_step": {k_: round(v, 4) for k_, v in sorted(per_step_ms.items(), key=lambda kv: -kv[1])},
             "cpu_baseline": cpu, "gpu_over_cpu": (n_pts * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None,
             "bpp_padded_blocks": summ["bpp"], "d1_psnr_db_blockwise": summ["d1_psnr_db"],
-            "blocks": int(summ["files"])}), flush=True)
+            "blocks": int(summ["files"])})
+    return None
 
 
-def bench_pppf(args, rk):
+def run_pppf(args, rk):
     """configs[2]: PPPF_AE (PointNet++ encoder + FoldingNet decoder, PPPF_AE.py:114-150) forward on K=512-point patches of
     2048-pt clouds (S = N*ALPHA/K = 8 patches per cloud), the model call of the reference's patch loop."""
     import numpy as np
@@ -728,13 +939,19 @@ def bench_pppf(args, rk):
     keep = {}
     for _ in range(args.warmup):
         model(patches)
-    timer = ops.StageTimer()
     dt = timed(rk, lambda i: keep.__setitem__("o", model(patches)), args.steps, torch.cuda.synchronize)
+    # the stage table comes from passes of their own AFTER the timed ones (HIP events around every stage, not inside the timed region)
+    timer = ops.StageTimer()
+    ops.set_timer(timer)
+    for _ in range(args.steps):
+        model(patches)
+    ops.set_timer(None)
+    stage_ms = {k_: round(ms / args.steps, 4) for k_, (ms, n_) in sorted(timer.totals_ms().items(), key=lambda kv: -kv[1][0])}
     flop_ref = families.pppf_flops_per_patch(model)                       # the reference's count: stacks on every grouped row
     flop = families.pppf_flops_per_patch(model, executed=True, n_points=Kp)  # what runs here: stacks on the source rows only
     if rk.rank == 0:
         cpu = None
-        if rk.world == 1 and args.cpu_clouds > 0:
+        if cpu_leg_allowed(args, rk):
             try:
                 cpu = cpu_baseline_pppf(model.state_dict(), patches[:min(patches.shape[0], 256)], Kp, args.cpu_budget / 2)
             except Exception as e:
@@ -753,7 +970,7 @@ def bench_pppf(args, rk):
                           "from that (pccx_gather_max) -- bit-identical outputs for 1/%.1f of the reference's matrix work "
                           "(reference_flop_per_patch); the forward is no longer matrix-bound: gather-max (LDS), the FoldingNet layers and "
                           "FPS / ball query share it (DESIGN.md section 7)" % (flop_ref / flop)}
-        print(json.dumps({
+        return ({
             "metric": "points/sec PPPF_AE forward (encode+decode) on K=512 patches", "value": rk.world * B * S * Kp * args.steps / dt,
             "unit": "points/s", "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -761,11 +978,12 @@ def bench_pppf(args, rk):
             "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": eff_matmul,
                        "matmul_requested": args.matmul,
                        "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
-            "roofline": rf, "cpu_baseline": cpu,
-            "gpu_over_cpu": (rk.world * B * S * Kp * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None}), flush=True)
+            "roofline": rf, "stage_ms_per_step": stage_ms, "cpu_baseline": cpu,
+            "gpu_over_cpu": (rk.world * B * S * Kp * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None})
+    return None
 
 
-def bench_pppe_train(args, rk):
+def run_pppe_train(args, rk):
     """configs[4]: one optimisation step of the pppe fast path per "step" (forward in train mode, Chamfer rate-distortion
     loss as the script builds it, backward, clip, Adam; data-parallel gradient all-reduce over RCCL when N > 1).  The line is
     quoted at --train-batch clouds per GPU (4 = train_pppe_pcd_ae.py's batch_size); `batch_sweep` repeats the measurement at
@@ -791,19 +1009,60 @@ def bench_pppe_train(args, rk):
         kw = dict(lam=1e-3, data_parallel=rk.grouped)
         if autocast:
             kw["autocast"] = True
+        extra = {}
         if args.graph:
+            pre = not args.no_prefetch
             gstep = train.GraphedTrainStep(model, opt, x, starts, lam=1e-3, autocast=autocast, warmup=max(warmup, 1),
-                                           data_parallel=rk.grouped)     # N > 1: two graphs cut at the gradient all-reduce
-            dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), steps, torch.cuda.synchronize)
+                                           data_parallel=rk.grouped, prefetch=pre)     # N > 1: two graphs cut at the gradient all-reduce
+            if pre:
+                # the loop of train_pppe_pcd_ae.py:184-226 software-pipelined: the FPS / kNN tables of batch i+1 (functions of the
+                # coordinates and the start indices only) are computed on a side stream while the captured step i runs
+                def one(i):
+                    keep["o"] = gstep(sync=False)
+                    gstep.prefetch(x, starts)
+                gstep.prefetch(x, starts)
+                one(0)
+                torch.cuda.synchronize()
+                dt = timed(rk, one, steps, torch.cuda.synchronize)
+                gstep(sync=False)                                          # consume the batch the last iteration queued
+                # the pieces by themselves (HIP events): selection on the side stream, and copy + replay with the tables ready
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                sel_ms = rep_ms = lat_ms = 0.0
+                nrep = max(3, min(steps, 10))
+                for _ in range(nrep):
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(gstep._side):
+                        ev[0].record(gstep._side)
+                    gstep.prefetch(x, starts)
+                    with torch.cuda.stream(gstep._side):
+                        ev[1].record(gstep._side)
+                    torch.cuda.synchronize()
+                    ev[2].record()
+                    gstep(sync=False)
+                    ev[3].record()
+                    torch.cuda.synchronize()
+                    sel_ms += ev[0].elapsed_time(ev[1])
+                    rep_ms += ev[2].elapsed_time(ev[3])
+                    t0 = time.perf_counter()                               # one isolated step, nothing in flight before or after it
+                    gstep(x, starts, sync=False)
+                    torch.cuda.synchronize()
+                    lat_ms += 1e3 * (time.perf_counter() - t0)
+                extra = {"stage_ms_per_step": {"graph_replay (forward + backward + clip + Adam, one hipGraph)": round(rep_ms / nrep, 4),
+                                               "selection (FPS + kNN tables of the next batch, side stream, overlapped)": round(sel_ms / nrep, 4)},
+                         "latency_ms_isolated_step": round(lat_ms / nrep, 4),
+                         "pipelining": "selection of batch i+1 on a side stream under the replay of step i (GraphedTrainStep(prefetch=True))"}
+            else:
+                dt = timed(rk, lambda i: keep.__setitem__("o", gstep(sync=False)), steps, torch.cuda.synchronize)
             keep["o"] = tuple(float(t) for t in keep["o"])
         else:
             for _ in range(warmup):
                 train.train_step(model, opt, x, starts, **kw)
             dt = timed(rk, lambda i: keep.__setitem__("o", train.train_step(model, opt, x, starts, **kw)), steps, torch.cuda.synchronize)
-        return dt, keep["o"][0], model, sd0, x, starts
+        keep["extra"] = extra
+        return dt, keep["o"][0], model, sd0, x, starts, keep["extra"]
 
     Bt = args.train_batch
-    dt, loss, model, sd0, x, starts = run(Bt, args.steps, args.warmup)
+    dt, loss, model, sd0, x, starts, extra = run(Bt, args.steps, args.warmup)
     sweep = {}
     if not args.one_mode:
         for b_ in (4, 16, 64):
@@ -812,7 +1071,7 @@ def bench_pppe_train(args, rk):
                 continue
             torch.cuda.empty_cache()
             st_ = max(3, args.steps // 2)
-            dtb, _, _, _, _, _ = run(b_, st_, max(args.warmup, 1))
+            dtb, _, _, _, _, _, _ = run(b_, st_, max(args.warmup, 1))
             sweep[str(b_)] = {"clouds_per_s": rk.world * b_ * st_ / dtb, "ms_per_step": 1e3 * dtb / st_}
         for v in sweep.values():
             v["patches_per_s"] = v["clouds_per_s"] * 512
@@ -822,11 +1081,11 @@ def bench_pppe_train(args, rk):
         # GradScaler (three more mantissa bits than bf16), so the fp32 step is the conservative figure to read the bf16 one against
         torch.cuda.empty_cache()
         st_ = max(3, args.steps // 2)
-        dto, losso, _, _, _, _ = run(Bt, st_, max(args.warmup, 1), autocast=not args.autocast)
+        dto, losso, _, _, _, _, _ = run(Bt, st_, max(args.warmup, 1), autocast=not args.autocast)
         other = {"dtype": "f32" if args.autocast else "bf16 autocast", "clouds_per_s": rk.world * Bt * st_ / dto, "ms_per_step": 1e3 * dto / st_, "loss": losso}
     if rk.rank == 0:
         cpu = None
-        if rk.world == 1 and args.cpu_clouds > 0:
+        if cpu_leg_allowed(args, rk):
             try:
                 cpu = cpu_baseline_pppe_train(sd0, x, starts, args.cpu_budget / 2)
             except Exception as e:
@@ -835,10 +1094,14 @@ def bench_pppe_train(args, rk):
         rf = None
         if flop:
             ach = flop * args.steps / dt / 1e12
-            rf = {"kernel": "training step (forward + backward GEMMs)", "bound": "mfma", "achieved": ach, "peak": F32_MATRIX_PEAK_TFLOPS,
-                  "unit": "TFLOP/s", "frac": ach / F32_MATRIX_PEAK_TFLOPS, "traffic": None, "flop_per_step": flop,
-                  "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): small, launch-bound layers"}
-        print(json.dumps({
+            peak = BF16_DENSE_PEAK_TFLOPS if args.autocast else F32_MATRIX_PEAK_TFLOPS     # the peak of the arithmetic that RUNS
+            rf = {"kernel": "training step (forward + backward GEMMs)", "bound": "mfma", "achieved": ach, "peak": peak,
+                  "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "flop_per_step": flop,
+                  "arithmetic": "bf16 operands on the bf16 matrix cores, fp32 accumulate (autocast)" if args.autocast else "f32",
+                  "frac_of_f32_matrix_peak": ach / F32_MATRIX_PEAK_TFLOPS,
+                  "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): a chain of ~200 small launches at batch 4 -- "
+                          "latency-bound, not arithmetic-bound (DESIGN.md: training step); the batch sweep shows the rate a fuller chip reaches"}
+        return ({
             "metric": "clouds/sec, pppe fast-path training step (forward+backward+Adam)", "value": rk.world * Bt * args.steps / dt,
             "unit": "clouds/s", "points_per_s": rk.world * Bt * N_POINTS * args.steps / dt, "patches_per_s": rk.world * Bt * 512 * args.steps / dt,
             "n_gpus": rk.world, **rk.info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -847,11 +1110,24 @@ def bench_pppe_train(args, rk):
                      if args.autocast else "f32", "data": "synthetic",
             "config": {"workload": f"pppe PointCloudAE training step (configs[4]), batch {Bt} x 8192 points per GPU",
                        "parallelism": f"dp{rk.world}", "weights": "seeded random",
-                       "launch": ("one hipGraph replay per step" if not rk.grouped else "two hipGraph replays per step around the RCCL gradient all-reduce")
+                       "launch": (("one hipGraph replay per step" if not rk.grouped else "two hipGraph replays per step around the RCCL gradient all-reduce") +
+                                  ("" if args.no_prefetch else "; FPS / kNN tables of the next batch on a side stream"))
                                  if args.graph else "eager" + (" (gradient all-reduce overlapped with backward)" if rk.grouped else "")},
-            "batch_sweep": sweep or None, "other_arithmetic": other,
+            "batch_sweep": sweep or None, "other_arithmetic": other, **extra,
             "roofline": rf, "cpu_baseline": cpu,
-            "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": loss}), flush=True)
+            "gpu_over_cpu": (rk.world * Bt * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, "loss": loss})
+    return None
+
+
+def _printer(fn):
+    def run(args, rk):
+        res = fn(args, rk)
+        if res is not None:
+            print(json.dumps(res), flush=True)
+    return run
+
+
+bench_s3dis, bench_pppf, bench_pppe_train = _printer(run_s3dis), _printer(run_pppf), _printer(run_pppe_train)
 
 
 def main():
@@ -879,8 +1155,15 @@ def main():
                          "configs[4] names bf16)")
     ap.add_argument("--fp32", action="store_true", help="pppe-train: the fp32 step instead of the bf16 autocast one")
     ap.add_argument("--graph", action="store_true", help="pppe-train: capture the step once as a hipGraph and replay it (N > 1: two graphs around the gradient all-reduce)")
-    ap.add_argument("--with-files", action="store_true",
-                    help="ipdae: also time a leg with the three .bin files of every cloud written to / read from tmpfs inside the window")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="pppe-train --graph: keep FPS / kNN inside the captured step (the round-4 form) instead of computing the next batch's tables on a side stream")
+    ap.add_argument("--with-files", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-files", action="store_true",
+                    help="ipdae: skip the leg with the three .bin files of every cloud written to / read from tmpfs inside the window")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="ipdae: skip the secondary block (configs[2] PPPF forward, [3] room-scale blocks, [4] training step) of the default line")
+    ap.add_argument("--secondary-budget", type=float, default=300.0, help="seconds after which a hung secondary leg is abandoned (the line is still printed)")
+    ap.add_argument("--secondary-cpu-budget", type=float, default=3.0, help="seconds of CPU work per secondary workload's cpu_baseline")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo only to rehearse the N>1 path on one GPU / on CPU")
     args = ap.parse_args()
@@ -899,6 +1182,9 @@ def main():
         sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     args.autocast = not args.fp32 if args.autocast is None else bool(args.autocast)
+    # NUMA placement of this rank's host side, from sysfs, BEFORE anything touches the GPU (pccx/launch.py)
+    _, local_, _ = launch.rank_env()
+    args.numa = launch.bind_rank_to_gpu_numa(local_) if args.workload != "launch-check" else None
     import pccx
     if args.matmul is None:
         args.matmul = pccx.DEFAULT_MATMUL

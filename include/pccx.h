@@ -338,6 +338,27 @@ PCCX_API int pccx_range_decode(const int32_t *cdf_int, const uint8_t *in, int st
  * cdf (nrows, Lp) f32 in [0,1] -> cdf_int (nrows, Lp) int32 holding 16-bit values. */
 PCCX_API int pccx_cdf_float_to_int(const float *cdf, int64_t nrows, int Lp, int32_t *cdf_int, void *stream);
 
+/* ---- the three files of every cloud (HOST side; no HIP call) ------------------------------------ */
+
+/* compress.py:139-152 writes <name>.p.bin, <name>.s.bin and <name>.c.bin inside its timer and decompress.py:80-91,113 reads them back
+ * inside its own, one Python open/write/close per file.  Here the files of a whole batch are cut from / filled into the HOST copy of the
+ * batch's packed stream buffer by `threads` host threads (0 = min(8, hardware threads)).  packed_host: the buffer of
+ * pccx_streams_packed_bytes(B, s_stride, p_cap) bytes laid out as
+ *     s_nbytes (B) int32 | p_nbytes (B) int32 | c (B,4) f32 [cx,cy,cz,longest] | s_bytes (B,s_stride) u8 | p_bytes (B,p_cap) u8
+ * (what the octree / range-coder entry points above write when handed views of one device buffer, copied to the host in one piece).
+ * File b is <dir>/<names + name_off[b]><ext> (names: NUL-terminated strings; name_off: (B) int64 offsets into it).  Formats are the
+ * reference's: .s.bin = the first s_nbytes[b] bytes of row b, .p.bin = the first p_nbytes[b] bytes of row b, .c.bin = 16 bytes.
+ * Write refuses (before touching the file system) a byte count that is negative or exceeds its row.  Read fills the counts and rows
+ * (tails cleared) and fails on a missing file, a file longer than its row or a .c.bin that is not 16 bytes.  Both block until done. */
+PCCX_API size_t pccx_streams_packed_bytes(int B, int s_stride, int p_cap);
+PCCX_API int pccx_write_streams_host(const void *packed_host, int B, int s_stride, int p_cap, const char *dir, const char *names,
+                                     const int64_t *name_off, int threads);
+PCCX_API int pccx_read_streams_host(void *packed_host, int B, int s_stride, int p_cap, const char *dir, const char *names,
+                                    const int64_t *name_off, int threads);
+/* Sizes in bytes of <name>.s.bin and <name>.p.bin of B clouds (-1 = no such file): what a reader sizes s_stride / p_cap from. */
+PCCX_API int pccx_stream_sizes_host(int B, const char *dir, const char *names, const int64_t *name_off, int64_t *s_sizes,
+                                    int64_t *p_sizes, int threads);
+
 /* ---- generic layers for the other model families (PPPF_AE.py, pointnet_sa_module.py,
  *      pppe_pcd_ae.py:556-917): correctness-first building blocks ------------------------------- */
 
@@ -492,6 +513,9 @@ PCCX_API int pccx_col_sum_w(const float *dY, int64_t M, int C, double *sums, flo
 PCCX_API size_t pccx_train_sums_doubles(int C);
 /* clear `bytes` (a multiple of 4) with a kernel (as a hipGraph node it is ordered like every other kernel: DESIGN.md section 7) */
 PCCX_API int pccx_zero_bytes(void *p, size_t bytes, void *stream);
+/* dst[0 .. bytes) = src[0 .. bytes) by a kernel (both 16-byte aligned, bytes % 16 == 0): how a training loop hands the next batch and its
+ * FPS / kNN tables (functions of the coordinates only, pppe_pcd_ae.py:596-632) to the fixed buffers a captured step reads. */
+PCCX_API int pccx_copy_bytes(const void *src, void *dst, size_t bytes, void *stream);
 /* *table[i] += delta for n int64 counters whose device addresses sit in table_dev (BatchNorm's num_batches_tracked of a whole model) */
 PCCX_API int pccx_add_i64_table(const int64_t *table_dev, int n, int64_t delta, void *stream);
 PCCX_API int pccx_relu_backward(const float *dY, const float *Y, int64_t n, float *dZ, void *stream);

@@ -42,14 +42,11 @@ def main():
             torch.cuda.synchronize()
             t0 = time.time()                                                                     # compress.py:85
             comp = cd.compress(pc, starts)
-            blobs = [comp.files(b) for b in range(len(batch))]                                   # D2H of the streams
-            for (i, f, _), (s, p, c) in zip(batch, blobs):
-                name = os.path.split(f)[1]
-                for ext, data in (('.p.bin', p), ('.s.bin', s), ('.c.bin', c)):
-                    with open(os.path.join(args.compressed_path, name + ext), 'wb') as fout:
-                        fout.write(data)
+            # ONE D2H of the batch's packed streams, then the library's host threads cut the three files of every cloud out of it
+            # (pccx_write_streams_host): <name>.p.bin / .s.bin / .c.bin, the bytes of compress.py:139-152
+            nbytes = comp.write_files(args.compressed_path, [os.path.split(f)[1] for _, f, _ in batch])
             times += [(time.time() - t0) / len(batch)] * len(batch)                              # compress.py:154
-            bits += sum(8 * (len(s) + len(p) + len(c)) for s, p, c in blobs)
+            bits += 8 * nbytes
             points += n0 * len(batch)
     g = dist.gather_summaries([bits, points, 0.0, 0.0, len(times), float(np.sum(times))], _common.summary_device(args))
     if rank == 0 and float(g[:, 4].sum()) > 0:

@@ -25,14 +25,6 @@ parser.add_argument('--bin-ply-suffix', action='store_true',
                     help="Write <name>.bin.ply (what eval.py:172 looks for) instead of <name> (decompress.py:121).")
 
 
-def _pad(rows, dev):
-    n = max(len(r) for r in rows)
-    out = np.zeros((len(rows), max(n, 1)), dtype=np.uint8)
-    for i, r in enumerate(rows):
-        out[i, :len(r)] = np.frombuffer(r, dtype=np.uint8)
-    return torch.from_numpy(out).to(dev), torch.tensor([len(r) for r in rows], dtype=torch.int32, device=dev)
-
-
 def main():
     args = parser.parse_args()
     print(f"Processing on device (gpu/cpu): {args.device}")
@@ -48,10 +40,10 @@ def main():
             chunk = names[b0:b0 + args.batch]
             torch.cuda.synchronize()
             t0 = time.time()                                                                     # decompress.py:77
-            rd = lambda n, e: open(os.path.join(args.compressed_path, n + e), 'rb').read()
-            s_b, s_n = _pad([rd(n, '.s.bin') for n in chunk], args.device)
-            p_b, p_n = _pad([rd(n, '.p.bin') for n in chunk], args.device)
-            c = torch.from_numpy(np.stack([np.frombuffer(rd(n, '.c.bin'), dtype=np.float32) for n in chunk])).to(args.device)
+            # the three files of every cloud of the chunk into ONE packed host buffer by the library's host threads
+            # (pccx_read_streams_host; decompress.py:80-91,113 reads them one by one), then one upload
+            up = codec.Compressed.read_files(args.compressed_path, chunk, device=args.device)
+            s_b, s_n, p_b, p_n, c = up.s_bytes, up.s_nbytes, up.p_bytes, up.p_nbytes, up.c
             # number of centres each stream holds (decompress.py:85 takes S from the decoded array)
             _, count = ops.octree_decode(s_b, s_n, args.octree_mode, 64 if args.octree_mode == 'reference' else 1)
             count = count.cpu().numpy()

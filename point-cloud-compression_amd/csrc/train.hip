@@ -716,6 +716,26 @@ extern "C" int pccx_zero_bytes(void *p, size_t bytes, void *stream)
     return PCCX_OK;
 }
 
+// dst[0 .. bytes) = src[0 .. bytes) with a kernel (16-byte aligned buffers, a multiple of 16 bytes): the training loop hands the NEXT batch
+// and its selection tables to the captured step's fixed buffers this way (train.py GraphedTrainStep(prefetch=True)), one launch in
+// front of the graph replay instead of a copy node per tensor inside it
+__global__ void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+extern "C" int pccx_copy_bytes(const void *src, void *dst, size_t bytes, void *stream)
+{
+    if (bytes == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(src && dst && bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                   "pccx_copy_bytes: needs 16-byte aligned buffers of a multiple of 16 bytes");
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
 // *table[i] += delta for n int64 counters whose addresses sit in a device table (BatchNorm's num_batches_tracked: one launch per step
 // instead of one torch add per layer)
 __global__ void add_i64_table_kernel(const int64_t *__restrict__ table, int n, long long delta)

@@ -84,6 +84,10 @@ _SIGNATURES = {
     "pccx_range_encode": [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P],
     "pccx_range_decode": [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P],
     "pccx_cdf_float_to_int": [_P, C.c_int64, C.c_int, _P, _P],
+    "pccx_streams_packed_bytes": [C.c_int, C.c_int, C.c_int],
+    "pccx_write_streams_host": [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, _P, C.c_int],
+    "pccx_read_streams_host": [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, _P, C.c_int],
+    "pccx_stream_sizes_host": [C.c_int, C.c_char_p, C.c_char_p, _P, _P, _P, C.c_int],
     "pccx_packed_linear_floats": [C.c_int, C.c_int],
     "pccx_pack_linear": [_P, C.c_int, C.c_int, _P],
     "pccx_linear": [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
@@ -125,6 +129,7 @@ _SIGNATURES = {
     "pccx_col_sum_w": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P],
     "pccx_train_sums_doubles": [C.c_int],
     "pccx_zero_bytes": [_P, C.c_size_t, _P],
+    "pccx_copy_bytes": [_P, _P, C.c_size_t, _P],
     "pccx_add_i64_table": [_P, C.c_int, C.c_int64, _P],
     "pccx_gather_backward_acc": [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_chamfer_grad_dev_acc": [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P],
@@ -143,7 +148,7 @@ _SIGNATURES = {
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
-_RESTYPES = {"pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_train_sums_doubles": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
+_RESTYPES = {"pccx_streams_packed_bytes": C.c_size_t, "pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_train_sums_doubles": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
              "pccx_ae_encode_h2_workspace_bytes": C.c_size_t, "pccx_ae_decode_h2_workspace_floats": C.c_size_t,
              "pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,

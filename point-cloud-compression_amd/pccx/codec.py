@@ -10,6 +10,7 @@ right-aligned), ``.p.bin`` = range-coder bytes of the S*d latent symbols, ``.c.b
 [cx, cy, cz, longest].
 """
 import dataclasses
+import os
 
 import numpy as np
 import torch
@@ -74,7 +75,8 @@ class Compressed:
                 packed = comp.packed
             else:
                 packed = self.packed
-            h = Compressed.from_packed(packed.cpu(), B, self.s_bytes.shape[1], self.p_bytes.shape[1], self.n_points)
+            self._host_packed = packed if not packed.is_cuda else packed.cpu()
+            h = Compressed.from_packed(self._host_packed, B, self.s_bytes.shape[1], self.p_bytes.shape[1], self.n_points)
             sn, pn = h.s_nbytes.numpy(), h.p_nbytes.numpy()
             if (pn < 0).any() or (sn < 0).any():
                 from ._lib import PccxError
@@ -87,6 +89,80 @@ class Compressed:
         """The three byte strings compress.py:139-152 writes for cloud b."""
         sb, sn, pb, pn, c = self.to_host()
         return bytes(sb[b, :sn[b]]), bytes(pb[b, :pn[b]]), c[b].tobytes()
+
+    def write_files(self, directory, names, threads=0):
+        """<directory>/<names[b]>.p.bin / .s.bin / .c.bin for every cloud (compress.py:139-152), cut from ONE host copy of the packed
+        buffer by the library's host threads (pccx_write_streams_host).  Returns the total number of bytes of the three files."""
+        B = self.s_bytes.shape[0]
+        if len(names) != B:
+            raise ValueError(f"write_files: {len(names)} names for {B} clouds")
+        self.to_host()                                         # ONE D2H (cached); raises on a negative byte count
+        host = self._host_packed
+        write_streams(host, B, self.s_bytes.shape[1], self.p_bytes.shape[1], directory, names, threads)
+        return int(self._host[1].sum()) + int(self._host[3].sum()) + 16 * B
+
+    @classmethod
+    def read_files(cls, directory, names, n_points=0, s_stride=None, p_cap=None, device=None, threads=0, out=None):
+        """The inverse (decompress.py:80-91,113): the three files of every name into one packed host buffer (rows sized from the largest
+        file unless s_stride / p_cap are given; `out` = a host uint8 tensor to fill, e.g. pinned), then -- with `device` -- ONE upload."""
+        B = len(names)
+        if s_stride is None or p_cap is None:
+            ss, ps = stream_sizes(directory, names, threads)
+            if B and (ss.min() < 0 or ps.min() < 0):
+                from ._lib import PccxError
+                raise PccxError("missing .s.bin / .p.bin for: " + ", ".join(n for n, a, b_ in zip(names, ss, ps) if a < 0 or b_ < 0))
+            s_stride = int(max(1, ss.max() if B else 1)) if s_stride is None else s_stride
+            p_cap = int(max(1, ps.max() if B else 1)) if p_cap is None else p_cap
+        need = packed_layout(B, s_stride, p_cap)[-1]
+        host = out if out is not None else torch.empty(need, dtype=torch.uint8)
+        if host.numel() != need or host.dtype != torch.uint8 or host.is_cuda:
+            raise ValueError(f"read_files: `out` must be a host uint8 tensor of {need} bytes")
+        read_streams(host, B, s_stride, p_cap, directory, names, threads)
+        packed = host.to(device, non_blocking=True) if device is not None else host
+        return cls.from_packed(packed, B, s_stride, p_cap, n_points)
+
+
+def _name_table(names):
+    blob, off, o = bytearray(), np.zeros(max(len(names), 1), dtype=np.int64), 0
+    for i, n in enumerate(names):
+        e = os.fsencode(n)
+        if b"\0" in e or b"/" in e:
+            raise ValueError(f"stream name {n!r}: a file name without directory part is expected")
+        off[i] = o
+        blob += e + b"\0"
+        o += len(e) + 1
+    return bytes(blob) or b"\0", off
+
+
+def _host_u8(t, need, who):
+    if not isinstance(t, torch.Tensor) or t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous() or t.numel() != need:
+        raise ValueError(f"{who}: a contiguous host uint8 tensor of {need} bytes is expected (codec.packed_layout)")
+    return t
+
+
+def write_streams(packed_host, B, s_stride, p_cap, directory, names, threads=0):
+    """pccx_write_streams_host: the files of B clouds from the host copy of a packed buffer (no GPU call)."""
+    from . import _lib
+    blob, off = _name_table(names)
+    _host_u8(packed_host, packed_layout(B, s_stride, p_cap)[-1], "write_streams")
+    _lib.call("pccx_write_streams_host", packed_host.data_ptr(), B, s_stride, p_cap, os.fsencode(directory), blob, off.ctypes.data, int(threads))
+
+
+def read_streams(packed_host, B, s_stride, p_cap, directory, names, threads=0):
+    """pccx_read_streams_host: the files of B clouds into a packed host buffer (counts, centres, rows; row tails cleared)."""
+    from . import _lib
+    blob, off = _name_table(names)
+    _host_u8(packed_host, packed_layout(B, s_stride, p_cap)[-1], "read_streams")
+    _lib.call("pccx_read_streams_host", packed_host.data_ptr(), B, s_stride, p_cap, os.fsencode(directory), blob, off.ctypes.data, int(threads))
+
+
+def stream_sizes(directory, names, threads=0):
+    """(sizes of <name>.s.bin, sizes of <name>.p.bin) as int64 arrays, -1 where the file does not exist."""
+    from . import _lib
+    blob, off = _name_table(names)
+    ss, ps = np.zeros(max(len(names), 1), np.int64), np.zeros(max(len(names), 1), np.int64)
+    _lib.call("pccx_stream_sizes_host", len(names), os.fsencode(directory), blob, off.ctypes.data, ss.ctypes.data, ps.ctypes.data, int(threads))
+    return ss[:len(names)], ps[:len(names)]
 
 
 class Codec:

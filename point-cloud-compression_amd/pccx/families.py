@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .ops import _stream
+from .ops import _stream, stage
 
 
 class FoldedLinear:
@@ -360,9 +360,16 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
     def run(self, stack, xyz, feats):
         """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C'))."""
         B = xyz.shape[0]
-        new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)                   # :66-68 (start index 0)
-        idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx           # :71 (-1 padded; gather clamps, :27)
+        with stage("fps"):
+            new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)               # :66-68 (start index 0)
+        with stage("ball_query"):
+            idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx       # :71 (-1 padded; gather clamps, :27)
         if self.dedup and B > 0 and stack[-1].N % 4 == 0:
+            return new_xyz, self._run_dedup(stack, xyz, feats, idx, B)
+        return self._run_grouped(stack, xyz, feats, idx, new_xyz, B)
+
+    def _run_dedup(self, stack, xyz, feats, idx, B):
+        with stage("sa_stack_%d" % stack[-1].N):
             if stack[0].mode() == "bf16x3":
                 # :83 features first, xyz last, one row per SOURCE point -- split straight into the first layer's operand planes from the
                 # two tables (pccx_group_planes without indices): the concatenated rows (two torch copies per level in round 3) never exist
@@ -385,7 +392,10 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
             else:
                 rows = cat_rows([feats, xyz] if feats is not None else [xyz])
                 y = run_stack(stack, rows)
-            return new_xyz, gather_max(y.view(B, xyz.shape[1], -1), idx)            # :91 max over the group's members
+        with stage("gather_max"):
+            return gather_max(y.view(B, xyz.shape[1], -1), idx)                     # :91 max over the group's members
+
+    def _run_grouped(self, stack, xyz, feats, idx, new_xyz, B):
         if stack[0].mode() == "bf16x3" and self.nsample in (32, 64, 128) and B > 0:
             # gather + concat + split in one pass, every layer on planes, the max over nsample in the last layer's epilogue
             if getattr(self, "_chain_of", None) is not stack:                       # new pack -> new stream
@@ -457,10 +467,11 @@ class PPPF_AE(_Packable):
         pts, feats = ops._f32c(xyz, "PPPF_AE"), None
         for mod, stack in zip((self.encoder.sa1, self.encoder.sa2, self.encoder.sa3), pk["sa"]):
             pts, feats = mod.run(stack, pts, feats)
-        g = group_max(feats)                                                        # :44 max over the 32 points
-        latent = sigmoid_spread(g, self.L)                                          # :136-137
-        q = round_(pk["enc"](latent))                                               # :139-142
-        lat_dec = pk["dec"](q)                                                      # :145
+        with stage("latent"):
+            g = group_max(feats)                                                    # :44 max over the 32 points
+            latent = sigmoid_spread(g, self.L)                                      # :136-137
+            q = round_(pk["enc"](latent))                                           # :139-142
+            lat_dec = pk["dec"](q)                                                  # :145
         P = self.decoder.num_points
         pow2x4 = lambda n: n % 4 == 0 and n <= 1024 and (n // 4) & (n // 4 - 1) == 0     # widths pccx_rows_affine_small takes
         if self.split_fold and B > 0 and pow2x4(pk["mlp1"][0].N) and pow2x4(pk["mlp2"][0].N):
@@ -470,10 +481,12 @@ class PPPF_AE(_Packable):
             if pk["mlp1"][1].mode() == "bf16x3":
                 # ... and the per-point update writes the next layer's operand PLANES directly (the fp32 rows of the 512-wide MLP were 1 GB
                 # written, read back and split per 2048 patches)
-                pl = rows_affine_planes(pk["mlp1_lat"](lat_dec), P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P)
-                x = run_stack_planes(pk["mlp1"][1:], pl, B * P)                                              # :104 coarse
-                pl = rows_affine_planes(pk["mlp2_lat"](lat_dec), P, x, 0, pk["mlp2_small"], pk["mlp2"][0].relu, B * P)
-                x = run_stack_planes(pk["mlp2"][1:], pl, B * P)                                              # :107 fine
+                with stage("fold_mlp1"):
+                    pl = rows_affine_planes(pk["mlp1_lat"](lat_dec), P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P)
+                    x = run_stack_planes(pk["mlp1"][1:], pl, B * P)                                          # :104 coarse
+                with stage("fold_mlp2"):
+                    pl = rows_affine_planes(pk["mlp2_lat"](lat_dec), P, x, 0, pk["mlp2_small"], pk["mlp2"][0].relu, B * P)
+                    x = run_stack_planes(pk["mlp2"][1:], pl, B * P)                                          # :107 fine
                 return x.view(B, P, 3), latent, q
             h = rows_affine_small(pk["mlp1_lat"](lat_dec), P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P)
             x = run_stack(pk["mlp1"][1:], h)                                                                 # :104 coarse

@@ -295,26 +295,54 @@ class SmoothL1Fn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
-def _sa_train(mod, xyz, feats, start, fps_idx=None):
-    """PointNetSetAbstraction.forward (pppe_pcd_ae.py:586-611) in train mode, channels-last.  fps_idx: the module's FPS indices
-    when the caller has drawn them already (the MSG branches' draws share one launch, forward_train)."""
+def _select(mod, xyz, start, fps_idx=None):
+    """The part of PointNetSetAbstraction.forward (pppe_pcd_ae.py:593-600) that depends on COORDINATES and the FPS start index only --
+    never on a weight: FPS, the centroids, kNN grouping of the coordinates.  -> (new_xyz (B,S,3), grouped (B,S,K,3) = nn - centroid,
+    idx (B,S,K) int64).  fps_idx: the module's FPS indices when the caller has drawn them already."""
     B, N, _ = xyz.shape
     S = mod.npoint
     if fps_idx is None and S != N:
         fps_idx = ops.farthest_point_sample_batch(xyz, S, start)
     new_xyz = xyz if S == N else ops.index_points(xyz, fps_idx)
     nn_ = ops.knn_points(new_xyz, xyz, mod.K, patch_scale=1.0)
-    grouped = nn_.knn                                                       # no gradient: xyz is data
+    return new_xyz, nn_.knn, nn_.idx
+
+
+def selection_tables(model, x, starts):
+    """Every FPS / kNN result of PointNet2EncoderFull.forward (pppe_pcd_ae.py:596-632, pn_kit.py:309-330) for one batch, in module order:
+    [MSG branch 0, MSG branch 1, sa_modules[1], sa_modules[2]], each (new_xyz, grouped, idx).  They are functions of the batch and of
+    the explicit start indices alone, so a training loop can compute them for batch i+1 while step i runs (GraphedTrainStep(prefetch=True))."""
+    sa = model.encoder.sa_modules
+    brs = list(sa[0].branches)
+    B = x.shape[0]
+    fps_of = [None] * len(brs)
+    if len(brs) > 1 and all(b_.npoint == brs[0].npoint != x.shape[1] for b_ in brs):
+        # the branches draw independent FPS samples of the SAME cloud from their own start indices (pppe_pcd_ae.py:624-632): FPS is a
+        # chain of npoint dependent rounds on one CU per cloud, so the draws of all branches go into ONE launch (B x branches clouds)
+        st_all = torch.cat([torch.as_tensor(s_).to(device=x.device, dtype=torch.int32).reshape(-1) for s_ in starts[0]])
+        idx_all = ops.farthest_point_sample_batch(x.repeat(len(brs), 1, 1), brs[0].npoint, st_all)
+        fps_of = list(idx_all.view(len(brs), B, -1))
+    tables = [_select(br, x, st, fi) for br, st, fi in zip(brs, starts[0], fps_of)]
+    tables.append(_select(sa[1], tables[-1][0], starts[1]))          # the last branch's centroids win (pppe_pcd_ae.py:631)
+    tables.append(_select(sa[2], tables[-1][0], starts[2]))
+    return tables
+
+
+def _sa_train(mod, table, feats):
+    """PointNetSetAbstraction.forward (pppe_pcd_ae.py:586-611) in train mode, channels-last, on the module's selection table."""
+    new_xyz, grouped, idx = table                                           # no gradient: xyz is data
+    B, S = new_xyz.shape[0], new_xyz.shape[1]
     if feats is not None:
-        grouped = torch.cat([grouped, GatherFn.apply(feats, nn_.idx)], dim=-1)
+        grouped = torch.cat([grouped, GatherFn.apply(feats, idx)], dim=-1)
     x = grouped.reshape(-1, grouped.shape[-1])
     for layer in mod.mlp_stack:                                             # conv (no bias) -> BN -> ReLU
         x = BnReluFn.apply(LinearFn.apply(x, layer[0].weight, None), layer[1].weight, layer[1].bias, layer[1])
     return new_xyz, GroupMaxFn.apply(x.view(B * S, mod.K, -1)).view(B, S, -1)
 
 
-def forward_train(model, x, starts):
-    """PointCloudAE.forward (pppe_pcd_ae.py:858-877) with BatchNorm in train mode.
+def forward_train(model, x, starts, tables=None):
+    """PointCloudAE.forward (pppe_pcd_ae.py:858-877) with BatchNorm in train mode.  tables: selection_tables(model, x, starts) when the
+    caller has them already (then `starts` is not looked at).
     -> (coarse (B,512,3), fine (B,N,3), cond (B,512), y_q (B,d))."""
     global _BN_COUNTED
     enc, dec = model.encoder, model.decoder
@@ -323,7 +351,10 @@ def forward_train(model, x, starts):
     outs, new_xyz = [], None
     _BN_COUNTED = _advance_bn_counters(model, x.device)    # every BatchNorm's num_batches_tracked += 1, one launch
     try:
-        return _forward_train_body(model, x, starts, enc, dec, B, sa, outs, new_xyz)
+        with ops.stage("selection"):
+            tables = selection_tables(model, x, starts) if tables is None else tables
+        with ops.stage("forward"):
+            return _forward_train_body(model, tables, enc, dec, B, sa)
     finally:
         _BN_COUNTED = None
 
@@ -348,21 +379,14 @@ def _advance_bn_counters(model, device):
     return True
 
 
-def _forward_train_body(model, x, starts, enc, dec, B, sa, outs, new_xyz):
-    brs = list(sa[0].branches)
-    fps_of = [None] * len(brs)
-    if len(brs) > 1 and all(b_.npoint == brs[0].npoint != x.shape[1] for b_ in brs):
-        # the branches draw independent FPS samples of the SAME cloud from their own start indices (pppe_pcd_ae.py:624-632): FPS is a
-        # chain of npoint dependent rounds on one CU per cloud, so the draws of all branches go into ONE launch (B x branches clouds)
-        st_all = torch.cat([torch.as_tensor(s_).to(device=x.device, dtype=torch.int32).reshape(-1) for s_ in starts[0]])
-        idx_all = ops.farthest_point_sample_batch(x.repeat(len(brs), 1, 1), brs[0].npoint, st_all)
-        fps_of = list(idx_all.view(len(brs), B, -1))
-    for br, st, fi in zip(brs, starts[0], fps_of):
-        new_xyz, f = _sa_train(br, x, None, st, fi)
+def _forward_train_body(model, tables, enc, dec, B, sa):
+    outs = []
+    for br, tb in zip(sa[0].branches, tables):
+        _, f = _sa_train(br, tb, None)
         outs.append(f)
     feats = torch.cat(outs, dim=-1)
-    xyz, feats = _sa_train(sa[1], new_xyz, feats, starts[1])
-    xyz, feats = _sa_train(sa[2], xyz, feats, starts[2])
+    _, feats = _sa_train(sa[1], tables[-2], feats)
+    _, feats = _sa_train(sa[2], tables[-1], feats)
     cond = GroupMaxFn.apply(feats)                                          # global max over the 32 points
     gc = enc.global_conv
     h = BnReluFn.apply(LinearFn.apply(cond, gc[0].weight, None), gc[1].weight, gc[1].bias, gc[1])
@@ -521,10 +545,23 @@ class GraphedTrainStep:
     iterations run before the capture are REAL optimisation steps on the construction batch (they also size the scratch buffers).
     data_parallel=True (one replica per GPU under torch.distributed): the iteration is captured as TWO graphs cut at the only
     exchange of the step -- forward + backward, then clip + Adam -- and the bucketed gradient all-reduce over RCCL
-    (dist.allreduce_mean_, on the gradients' fixed graph-pool addresses) runs between the two replays on the same stream."""
+    (dist.allreduce_mean_, on the gradients' fixed graph-pool addresses) runs between the two replays on the same stream.
+    prefetch=True takes SELECTION out of the captured step: every FPS / kNN result of the encoder is a function of the batch and the
+    start indices alone (selection_tables), FPS is 512 dependent rounds on 8 of the 256 CUs (0.56 ms of a 3.3 ms step at batch 4), so
+    the tables of batch i+1 are computed on a SIDE stream while the graph of step i runs.  The graph reads the batch and the tables
+    from one fixed buffer (`cur`); prefetch(batch, starts) fills a second one (`nxt`) on the side stream; __call__ moves nxt -> cur
+    with one copy kernel in front of the replay, and the next prefetch waits only for that copy, not for the replay.
+
+        step.prefetch(x0, s0)
+        for i in ...:
+            out = step()                       # consumes batch i (waits for its tables), replays
+            step.prefetch(x[i+1], s[i+1])      # side stream: overlaps the replay just queued
+
+    __call__(batch_x, starts) without a pending prefetch runs the selection first and then the graph (the un-pipelined LATENCY of one
+    step); results are the same either way (tests/test_train_step.py)."""
 
     def __init__(self, model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, loss_type="chamfer", autocast=False, warmup=2,
-                 data_parallel=False, debug_dot=None):
+                 data_parallel=False, debug_dot=None, prefetch=False):
         if loss_type != "chamfer":
             raise _lib.PccxError("GraphedTrainStep: loss_type='chamfer' (what train_pppe_pcd_ae.py:48 builds) is the captured loss; "
                                  "the smooth-L1 backward still reads its upstream gradient on the host")
@@ -537,6 +574,24 @@ class GraphedTrainStep:
         self.x = batch_x.detach().clone().contiguous()
         self.starts = [[as_dev(s_) for s_ in starts[0]], as_dev(starts[1]), as_dev(starts[2])]
         self.lam = torch.tensor(float(lam), device=dev, dtype=torch.float32)
+        self.prefetch_mode, self.tables, self._pending = bool(prefetch), None, False
+        if self.prefetch_mode:
+            # one flat buffer per side: the batch, then every table tensor, each at a 16-byte aligned offset
+            probe = [self.x] + [t for tb in selection_tables(model, self.x, self.starts) for t in tb]
+            offs, o = [], 0
+            for t in probe:
+                offs.append(o)
+                o += (t.numel() * t.element_size() + 15) // 16 * 16
+            self._flat = [torch.zeros(o, device=dev, dtype=torch.uint8) for _ in range(2)]           # cur, nxt
+            views = lambda buf: [buf[a:a + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for a, t in zip(offs, probe)]
+            self._cur, self._nxt = views(self._flat[0]), views(self._flat[1])
+            for dst, src in zip(self._cur, probe):
+                dst.copy_(src)
+            self.x = self._cur[0]
+            self.tables = [tuple(self._cur[1 + 3 * i:4 + 3 * i]) for i in range((len(probe) - 1) // 3)]
+            self._side = torch.cuda.Stream(device=dev)
+            self._sel_done, self._copied = torch.cuda.Event(), torch.cuda.Event()
+            self._copied.record(torch.cuda.current_stream())
         if warmup > 0:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -582,7 +637,7 @@ class GraphedTrainStep:
         _ARENA = self.arena
         self.arena.begin(self.x.device)
         try:
-            coarse, fine, cond, y_q = forward_train(self.model, self.x, self.starts)
+            coarse, fine, cond, y_q = forward_train(self.model, self.x, self.starts, tables=self.tables)
             fbpp = estimate_bits_per_point(self.model, y_q, cond.detach())
             loss, dist, rate = rd_loss(fine, self.x, fbpp, self.lam, self.loss_type)
             _AUTOCAST = False
@@ -609,15 +664,52 @@ class GraphedTrainStep:
         self._opt_step()
         return out
 
+    def prefetch(self, batch_x, starts):
+        """Queue the selection of the NEXT batch on the side stream (prefetch=True only): FPS / kNN tables of (batch_x, starts) into the
+        `nxt` buffer.  Returns at once; the next __call__() consumes it."""
+        if not self.prefetch_mode:
+            raise _lib.PccxError("GraphedTrainStep.prefetch needs prefetch=True at construction")
+        dev = self.x.device
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)                                           # batch_x / starts may have been produced on the caller's stream
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            self._side.wait_event(self._copied)                      # nxt is free once the previous step has moved it into cur
+            bx = batch_x.detach().to(device=dev, dtype=torch.float32).contiguous()
+            as_dev = lambda s_: torch.as_tensor(s_).to(device=dev, dtype=torch.int32).contiguous()
+            st = [[as_dev(s_) for s_ in starts[0]], as_dev(starts[1]), as_dev(starts[2])]
+            flat = [bx] + [t for tb in selection_tables(self.model, bx, st) for t in tb]
+            for dst, src in zip(self._nxt, flat):
+                dst.copy_(src)
+            self._sel_done.record(self._side)
+            for t in flat:
+                t.record_stream(self._side)
+        self._pending = True
+
     def __call__(self, batch_x=None, starts=None, lam=None, sync=True):
         """One iteration.  Returns (loss, dist, rate) as floats (sync=True) or the device scalars of the graph (sync=False)."""
-        if batch_x is not None:
-            self.x.copy_(batch_x)
-        if starts is not None:
-            for dst, src in zip(self.starts[0], starts[0]):
-                dst.copy_(torch.as_tensor(src).to(dst.device, torch.int32))
-            self.starts[1].copy_(torch.as_tensor(starts[1]).to(self.x.device, torch.int32))
-            self.starts[2].copy_(torch.as_tensor(starts[2]).to(self.x.device, torch.int32))
+        if self.prefetch_mode:
+            if batch_x is not None or starts is not None:
+                if self._pending:
+                    raise _lib.PccxError("GraphedTrainStep: a prefetched batch is pending; call step() without arguments to consume it")
+                if batch_x is None or starts is None:
+                    raise _lib.PccxError("GraphedTrainStep(prefetch=True): batch_x and starts come together (the tables depend on both)")
+                self.prefetch(batch_x, starts)                       # the un-pipelined form: selection, then the graph
+            if self._pending:
+                main = torch.cuda.current_stream()
+                main.wait_event(self._sel_done)
+                _lib.call("pccx_copy_bytes", self._flat[1].data_ptr(), self._flat[0].data_ptr(), self._flat[0].numel(), _stream())
+                self._copied.record(main)
+                self._pending = False
+        else:
+            if batch_x is not None:
+                self.x.copy_(batch_x)
+            if starts is not None:
+                for dst, src in zip(self.starts[0], starts[0]):
+                    dst.copy_(torch.as_tensor(src).to(dst.device, torch.int32))
+                self.starts[1].copy_(torch.as_tensor(starts[1]).to(self.x.device, torch.int32))
+                self.starts[2].copy_(torch.as_tensor(starts[2]).to(self.x.device, torch.int32))
         if lam is not None:
             self.lam.fill_(float(lam))
         self.graph.replay()             # carries pccx_adam_advance_dev: the device counter moves with the replay

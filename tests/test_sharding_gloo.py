@@ -118,6 +118,19 @@ def test_bench_self_launch_two_ranks_gloo():
     assert s["files"] == 3 and abs(s["bpp"] - 3000.0 / (3 * 8192)) < 1e-12
     assert abs(s["d1_psnr_db"] - (30.0 + 31.0) / 3) < 1e-12
     assert abs(s["points_per_s"] - 3 * 8192 / 1.5) < 1e-9      # sum of points / MAX of seconds
+    # the secondary block of the default line (stubs here: no GPU): every rank ran the legs, rank 0 emitted them ONCE, inside the one
+    # line; with N > 1 no leg carries a CPU baseline (bench.cpu_leg_allowed) and every rank's NUMA placement is listed
+    sec = j["secondary"]
+    assert set(sec) == {"stub_a", "stub_b", "wall_s"} and sec["stub_a"]["n_gpus"] == 2
+    assert j["cpu_baseline"] is None and sec["stub_a"]["cpu_baseline"] is None and sec["stub_b"]["cpu_baseline"] is None
+    assert [r_["rank"] for r_ in j["rank_numa"]] == [0, 1]
+    assert r.stdout.count('"secondary"') == 1
+    # ... and at N = 1 the same command carries the CPU legs
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dist-backend", "gloo", "--workload",
+                         "launch-check", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert j1["cpu_baseline"] is not None and j1["secondary"]["stub_b"]["cpu_baseline"] is not None and j1["n_gpus"] == 1
 
 
 def test_launcher_propagates_a_failing_rank(tmp_path):

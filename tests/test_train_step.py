@@ -357,6 +357,68 @@ def test_graphed_training_step_replays_the_eager_step():
 
 
 @pytest.mark.gpu
+def test_prefetched_selection_tables_feed_the_same_step():
+    """GraphedTrainStep(prefetch=True): FPS / kNN of the encoder (functions of the batch and the start indices only,
+    pppe_pcd_ae.py:596-632, pn_kit.py:309-330) computed on a side stream into the `nxt` buffer and moved into the captured step's
+    buffer by one copy kernel.  From the SAME state and on a batch that differs from the construction batch, the first replay must be
+    the step the selection-inside-the-graph form takes (loss / distortion / rate to the noise of the fp32 atomics, parameters to
+    Adam's first-step sensitivity): stale tables or a stale batch would change the loss at once.  Then the software-pipelined loop
+    (step(); prefetch(next)) against the un-pipelined calls of the same graph class on the same batches."""
+    import copy
+    from pccx import _lib, families, train
+    o = _models(2048)
+    ga = families.PointCloudAE(64, 16, 2048)
+    ga.load_state_dict(o.state_dict())
+    ga = ga.cuda()
+    gb, gc = copy.deepcopy(ga), copy.deepcopy(ga)
+    x0 = torch.from_numpy(synth.train_input(2, 2048)).cuda()
+    x1 = torch.from_numpy(synth.train_input(2, 2048)[:, ::-1].copy() * 0.9 + 0.05).cuda()
+    rng = np.random.default_rng(6)
+    mk = lambda: [[rng.integers(0, 2048, 2), rng.integers(0, 2048, 2)], rng.integers(0, 512, 2), rng.integers(0, 128, 2)]
+    s0, s1, s2 = mk(), mk(), mk()
+    oa, ob, oc = (train.Adam(m.parameters(), lr=1e-3) for m in (ga, gb, gc))
+    A = train.GraphedTrainStep(ga, oa, x0, s0, lam=1e-3, warmup=0)                      # selection inside the graph (round 4)
+    Bp = train.GraphedTrainStep(gb, ob, x0, s0, lam=1e-3, warmup=0, prefetch=True)      # selection outside, pipelined use
+    Cp = train.GraphedTrainStep(gc, oc, x0, s0, lam=1e-3, warmup=0, prefetch=True)      # selection outside, un-pipelined use
+    la = A(batch_x=x1, starts=s1)
+    Bp.prefetch(x1, s1)
+    with pytest.raises(_lib.PccxError, match="pending"):
+        Bp(batch_x=x0, starts=s0)
+    lb = Bp()
+    lc = Cp(x1, s1)
+    for other in (lb, lc):
+        for u, v in zip(la, other):
+            assert abs(u - v) <= 1e-5 * abs(u) + 1e-7, (la, lb, lc)
+    dmax, dmed = 0.0, []
+    for (k1, p1), (_, p2) in zip(ga.named_parameters(), gb.named_parameters()):
+        dd = (p1 - p2).abs()
+        dmax = max(dmax, float(dd.max()))
+        dmed.append(float(dd.median()))
+    assert dmax <= 2.2e-3 and np.median(dmed) <= 1e-5, (dmax, np.median(dmed))
+    # the tables the captured step read are those of (x1, s1), bit for bit
+    want = train.selection_tables(gb, x1, [[torch.as_tensor(v) for v in s1[0]], torch.as_tensor(s1[1]), torch.as_tensor(s1[2])])
+    for tb_w, tb_g in zip(want, Bp.tables):
+        for w_, g_ in zip(tb_w, tb_g):
+            assert torch.equal(w_, g_)
+    assert torch.equal(Bp.x, x1)
+    # pipelined loop: the next batch's selection is queued right behind each replay; B and C take the same batches in the same order
+    seq = [(x0, s2), (x1, s0), (x0, s1)]
+    Bp.prefetch(*seq[0])
+    outs_b = []
+    for i in range(len(seq)):
+        outs_b.append(Bp(sync=False))
+        if i + 1 < len(seq):
+            Bp.prefetch(*seq[i + 1])
+        outs_b[-1] = tuple(float(t) for t in outs_b[-1])
+    outs_c = [Cp(bx, st) for bx, st in seq]
+    assert ob.t == oc.t == 4
+    assert all(np.isfinite(v) for o_ in outs_b + outs_c for v in o_)
+    assert abs(outs_b[0][0] - outs_c[0][0]) <= 5e-2 * abs(outs_c[0][0]), (outs_b, outs_c)   # second step: already amplifying first-step noise
+    with pytest.raises(_lib.PccxError, match="prefetch=True"):
+        A.prefetch(x0, s0)
+
+
+@pytest.mark.gpu
 def test_unsynchronised_graph_replays_carry_their_own_adam_step_counter():
     """N replays with sync=False (the CPU runs ahead of the GPU, as bench.py --workload pppe-train --graph does) against N
     eager steps: Adam's step counter and bias corrections live on the device and advance INSIDE the captured step, so every
