@@ -1018,8 +1018,7 @@ def run_pppe_train(args, rk):
                 # the loop of train_pppe_pcd_ae.py:184-226 software-pipelined: the FPS / kNN tables of batch i+1 (functions of the
                 # coordinates and the start indices only) are computed on a side stream while the captured step i runs
                 def one(i):
-                    keep["o"] = gstep(sync=False)
-                    gstep.prefetch(x, starts)
+                    keep["o"] = gstep(sync=False, next_batch=(x, starts))
                 gstep.prefetch(x, starts)
                 one(0)
                 torch.cuda.synchronize()

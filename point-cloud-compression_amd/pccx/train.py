@@ -95,6 +95,9 @@ def _sums(C, device):
 
 
 def _packed(W, transpose):
+    # One small launch in front of every GEMM.  Packing ALL the step's operands in one launch at its start (a table-driven kernel, round 5)
+    # measured no gain at batch 4 (graph replay 2.51 ms either way) and LOST 1.4 ms per step at batches 16 / 64, where the 100 MB decoder
+    # weights are packed too: packed right before its GEMM an operand is read back from the Infinity Cache (tools/experiments/r5/README.md).
     N, K = W.shape
     R, Cc = (K, N) if transpose else (N, K)
     wp = torch.empty(_lib.load().pccx_packed_linear_floats(R, Cc), device=W.device, dtype=torch.float32)
@@ -554,9 +557,11 @@ class GraphedTrainStep:
 
         step.prefetch(x0, s0)
         for i in ...:
-            out = step()                       # consumes batch i (waits for its tables), replays
-            step.prefetch(x[i+1], s[i+1])      # side stream: overlaps the replay just queued
+            out = step(next_batch=(x[i+1], s[i+1]))   # consumes batch i; queues batch i+1's selection; replays
 
+    next_batch is queued BETWEEN the copy and the replay: the side stream is ordered after whatever produced the next batch on the
+    caller's stream (an event recorded there), and that point must lie in front of the replay or the selection would wait for it
+    (calling prefetch() after step() does exactly that: measured 3.5 ms per step against 2.6, tools/experiments/r5/).
     __call__(batch_x, starts) without a pending prefetch runs the selection first and then the graph (the un-pipelined LATENCY of one
     step); results are the same either way (tests/test_train_step.py)."""
 
@@ -589,7 +594,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
             self.x = self._cur[0]
             self.tables = [tuple(self._cur[1 + 3 * i:4 + 3 * i]) for i in range((len(probe) - 1) // 3)]
-            self._side = torch.cuda.Stream(device=dev)
+            self._side, self._upload = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
             self._sel_done, self._copied = torch.cuda.Event(), torch.cuda.Event()
             self._copied.record(torch.cuda.current_stream())
         if warmup > 0:
@@ -673,12 +678,29 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)                                           # batch_x / starts may have been produced on the caller's stream
+        # start indices that live on the HOST go up in one piece on a stream of their own: a pageable copy blocks the calling thread until
+        # everything queued before it on ITS stream is done -- on the side stream that is the previous step's replay (measured: 3.15 ms
+        # per step with the four small uploads there, 2.8 with the indices already on the device)
+        parts = list(starts[0]) + [starts[1], starts[2]]
+        if any(not (isinstance(p_, torch.Tensor) and p_.is_cuda) for p_ in parts):
+            import numpy as np
+            host = np.concatenate([np.asarray(p_.cpu() if isinstance(p_, torch.Tensor) else p_).astype(np.int32).reshape(-1) for p_ in parts])
+            with torch.cuda.stream(self._upload):
+                up = torch.from_numpy(host).to(dev)
+                upl = torch.cuda.Event()
+                upl.record(self._upload)
+            sizes = [int(np.asarray(p_.cpu() if isinstance(p_, torch.Tensor) else p_).size) for p_ in parts]
+            cut = list(torch.split(up, sizes))
+            up.record_stream(self._side)
+        else:
+            upl, cut = None, [p_.to(torch.int32).contiguous() for p_ in parts]
+        st = [cut[:len(starts[0])], cut[-2], cut[-1]]
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
+            if upl is not None:
+                self._side.wait_event(upl)
             self._side.wait_event(self._copied)                      # nxt is free once the previous step has moved it into cur
             bx = batch_x.detach().to(device=dev, dtype=torch.float32).contiguous()
-            as_dev = lambda s_: torch.as_tensor(s_).to(device=dev, dtype=torch.int32).contiguous()
-            st = [[as_dev(s_) for s_ in starts[0]], as_dev(starts[1]), as_dev(starts[2])]
             flat = [bx] + [t for tb in selection_tables(self.model, bx, st) for t in tb]
             for dst, src in zip(self._nxt, flat):
                 dst.copy_(src)
@@ -687,8 +709,12 @@ class GraphedTrainStep:
                 t.record_stream(self._side)
         self._pending = True
 
-    def __call__(self, batch_x=None, starts=None, lam=None, sync=True):
-        """One iteration.  Returns (loss, dist, rate) as floats (sync=True) or the device scalars of the graph (sync=False)."""
+    def __call__(self, batch_x=None, starts=None, lam=None, sync=True, next_batch=None):
+        """One iteration.  Returns (loss, dist, rate) as floats (sync=True) or the device scalars of the graph (sync=False).
+        next_batch = (batch_x, starts) of the FOLLOWING iteration (prefetch=True): its selection is queued on the side stream here, in
+        front of this iteration's replay, and runs under it."""
+        if next_batch is not None and not self.prefetch_mode:
+            raise _lib.PccxError("GraphedTrainStep: next_batch needs prefetch=True at construction")
         if self.prefetch_mode:
             if batch_x is not None or starts is not None:
                 if self._pending:
@@ -702,6 +728,8 @@ class GraphedTrainStep:
                 _lib.call("pccx_copy_bytes", self._flat[1].data_ptr(), self._flat[0].data_ptr(), self._flat[0].numel(), _stream())
                 self._copied.record(main)
                 self._pending = False
+            if next_batch is not None:
+                self.prefetch(*next_batch)
         else:
             if batch_x is not None:
                 self.x.copy_(batch_x)

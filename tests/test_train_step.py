@@ -406,16 +406,16 @@ def test_prefetched_selection_tables_feed_the_same_step():
     Bp.prefetch(*seq[0])
     outs_b = []
     for i in range(len(seq)):
-        outs_b.append(Bp(sync=False))
-        if i + 1 < len(seq):
-            Bp.prefetch(*seq[i + 1])
-        outs_b[-1] = tuple(float(t) for t in outs_b[-1])
+        o_ = Bp(sync=False, next_batch=seq[i + 1] if i + 1 < len(seq) else None)
+        outs_b.append(tuple(float(t) for t in o_))
     outs_c = [Cp(bx, st) for bx, st in seq]
     assert ob.t == oc.t == 4
     assert all(np.isfinite(v) for o_ in outs_b + outs_c for v in o_)
     assert abs(outs_b[0][0] - outs_c[0][0]) <= 5e-2 * abs(outs_c[0][0]), (outs_b, outs_c)   # second step: already amplifying first-step noise
     with pytest.raises(_lib.PccxError, match="prefetch=True"):
         A.prefetch(x0, s0)
+    with pytest.raises(_lib.PccxError, match="prefetch=True"):
+        A(next_batch=(x0, s0))
 
 
 @pytest.mark.gpu
