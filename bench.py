@@ -557,6 +557,16 @@ def bench_ipdae(args, rk):
              "chamfer_sum": float(codec.normalized_chamfer(clouds, out).sum())}
         r["base_shapes"] = {"clouds": nb_, "bpp": float(comp.bits()[:nb_].sum()) / (nb_ * N_POINTS),
                             "d1_psnr_db": float(codec.d1_psnr(clouds[:nb_], out[:nb_]).sum()) / nb_}
+        if rank_tag:
+            # the resident pipeline's shortcut, beside the figure above: decompress handed the Compressed object it came from takes the
+            # integer CDF compress built instead of evaluating the probability model again (codec.decompress(reuse_cdf=True)); the
+            # host-to-host window below never does (its decompress starts from bytes, as decompress.py:88-92)
+            def step_reuse(i):
+                c_ = cd.compress(clouds, starts)
+                keep["rr"] = cd.decompress(c_, S=S, reuse_cdf=True)
+            step_reuse(0)
+            r["dt_res_reuse"] = timed(rk, step_reuse, args.steps, sync)
+            r["reuse_equals_recompute"] = bool(torch.equal(keep.pop("rr"), out))
 
         # ---- host-to-host leg (the reference's window): two streams, pinned double buffers ---------------------
         copy_stream = torch.cuda.Stream(device=dev)
@@ -727,6 +737,10 @@ def bench_ipdae(args, rk):
             "window": "host-to-host: cloud in HBM -> .s/.p/.c bytes on the host (compress.py:85-154) -> XYZ on the host "
                       "(decompress.py:77-118); kernels on one stream, copies overlapped on a copy stream",
             "value_resident": rk.world * pts / main["dt_res"], "ms_per_step_resident": 1e3 * main["dt_res"] / args.steps,
+            "resident_cdf_reuse": {"value": rk.world * pts / main["dt_res_reuse"], "ms_per_step": 1e3 * main["dt_res_reuse"] / args.steps,
+                                   "decoded_equals_recompute": main["reuse_equals_recompute"],
+                                   "note": "resident pipeline only: decompress takes the integer CDF of the Compressed object it is handed instead "
+                                           "of running the probability model a second time; `value` (from bytes) always recomputes"} if "dt_res_reuse" in main else None,
             "host_window_checks": {k: main[k] for k in ("host_equals_resident", "host_bytes_equal_resident", "d2h_bytes_per_step")},
             "config": {"workload": "IPDAE K=256 d=16 L=7, 8192-pt CAD-like synthetic clouds (configs[1])",
                        "clouds_per_gpu_per_step": B, "distinct_clouds_per_gpu": B, "base_shapes_per_gpu": int(base.shape[0]), "points_per_cloud": N_POINTS,

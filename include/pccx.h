@@ -88,7 +88,7 @@ PCCX_API int pccx_gather(const float *points, int B, int N, int C, const int64_t
 
 /* pytorch3d knn_points(p1=q, p2=ref, K, return_nn) (compress.py:71, pn_kit.py:190, eval.py:132):
  * squared L2, K smallest ascending, ties by lower index.  q: (B,M,3); ref: (B,N,3);
- * dists: (B,M,K) f32; idx: (B,M,K) int64; nn: (B,M,K,3) or NULL.  K <= 1024, K <= N <= 32768.
+ * dists: (B,M,K) f32 or NULL; idx: (B,M,K) int64 or NULL; nn: (B,M,K,3) or NULL (at least one of the three).  K <= 1024, K <= N <= 32768.
  * If patch_scale != 0, nn instead receives (ref[idx]-q)*patch_scale: the fused form of
  * compress.py:72 (subtract centre) and compress.py:108 (scale by (N/N0)^(1/3)). */
 PCCX_API int pccx_knn(const float *q, int B, int M, const float *ref, int N, int K, float *dists,

@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
     for (int k = tid; k < K; k += 256) {
         unsigned long long e = sel[k];
         int i = (int)(e & 0xffffffffu);
-        dists[ob + k] = __uint_as_float((unsigned)(e >> 32));
-        idx[ob + k] = i;
+        if (dists) dists[ob + k] = __uint_as_float((unsigned)(e >> 32));
+        if (idx) idx[ob + k] = i;
         if (nn) {
             float x = rp[3 * i], y = rp[3 * i + 1], z = rp[3 * i + 2];
             if (patch_scale != 0.f) {
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256, 4) void knn_fast_kernel(const float *__restric
     // ---- outputs
     if (tid < K) {
         const int i = (int)(v & 0xffffffffu);
-        dists[ob + tid] = __uint_as_float((unsigned)(v >> 32));
-        idx[ob + tid] = i;
+        if (dists) dists[ob + tid] = __uint_as_float((unsigned)(v >> 32));     // the codec's patching step takes the patches only:
+        if (idx) idx[ob + tid] = i;                                             // 12 of the 24 bytes per neighbour stay unwritten
         if (nn) {
             float x = rp[3 * i], y = rp[3 * i + 1], z = rp[3 * i + 2];
             if (patch_scale != 0.f) {
@@ -377,7 +377,7 @@ extern "C" int pccx_knn(const float *q, int B, int M, const float *ref, int N, i
                         float *nn, float patch_scale, void *stream)
 {
     if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(q && ref && dists && idx, "pccx_knn: null pointer");
+    PCCX_CHECK_ARG(q && ref && (dists || idx || nn), "pccx_knn: null pointer (q, ref and at least one of dists / idx / nn are needed)");
     PCCX_CHECK_ARG(B >= 0 && M >= 0 && N >= 1, "pccx_knn: bad shape B=%d M=%d N=%d", B, M, N);
     PCCX_CHECK_ARG(K >= 1 && K <= N && K <= 1024, "pccx_knn: need 1 <= K <= min(N,1024), got K=%d N=%d", K, N);
     PCCX_CHECK_ARG(N <= 32768, "pccx_knn: N=%d > 32768 unsupported", N);

@@ -210,7 +210,8 @@ class Codec:
             rec, _ = ops.octree_decode(oc["bytes"], oc["nbytes"], self.octree_mode, S)   # compress.py:100
         scale = float((N / self.N0) ** (1 / 3))
         with stage("knn_patches"):
-            nn = ops.knn_points(rec, pcn, self.K, patch_scale=scale)                 # compress.py:105-108
+            nn = ops.knn_points(rec, pcn, self.K, patch_scale=scale,                 # compress.py:105-108 (KNN_Patching keeps the
+                                return_dists=False, return_idx=keep_extras)          # patches; the indices only for diagnostics)
         patches = nn.knn.view(B * S, self.K, 3)
         raw, latent, q = self.ae.encode(patches, sa_matmul=self.sa_matmul, pn_matmul=self.pn_matmul)                                     # compress.py:113-127
         with stage("prob"):
@@ -219,19 +220,26 @@ class Codec:
             models.range_encode(cdf_int, q.view(B, S * d), L, out=comp.p_bytes, nb=comp.p_nbytes)   # compress.py:135-136
         comp.c[:, :3].copy_(center)                                                  # compress.py:149-152
         comp.c[:, 3].copy_(longest)
+        comp._cdf_int = cdf_int               # kept for decompress(reuse_cdf=True): the resident pipeline's shortcut, never part of the streams
         if keep_extras:
             comp.extras = dict(pcn=pcn, fps_idx=fps_idx, sampled=sampled, octree=oc, rec_sampled=rec, patches=patches,
                           latent_raw=raw, latent=latent, latent_q=q, cdf_int=cdf_int, knn_idx=nn.idx)
         return comp
 
-    def decompress(self, comp, S=64):
-        """Inverse pipeline (decompress.py:80-116) -> (B, S*k, 3) f32."""
+    def decompress(self, comp, S=64, reuse_cdf=False):
+        """Inverse pipeline (decompress.py:80-116) -> (B, S*k, 3) f32.
+        reuse_cdf=True (resident pipelines only): when `comp` is the very object compress() returned, the integer CDF it coded with is
+        still in HBM and the probability model is not evaluated a second time -- both sides evaluate the SAME function of the SAME
+        decoded centres (compress.py:131, decompress.py:88), so the table is identical by construction.  From bytes (files, a
+        Compressed built by from_packed / read_files) the table is always recomputed, as decompress.py does."""
         B = comp.s_bytes.shape[0]
         d, L = self.ae.d, self.ae.L
         with stage("octree_decode"):
             rec, cnt = ops.octree_decode(comp.s_bytes, comp.s_nbytes, self.octree_mode, S)    # decompress.py:80-85
-        with stage("prob"):
-            cdf_int = self.prob.run(rec, ("cdf_int",))["cdf_int"]                         # decompress.py:88-92
+        cdf_int = getattr(comp, "_cdf_int", None) if reuse_cdf else None
+        if cdf_int is None or cdf_int.shape[0] != B or cdf_int.shape[1] != S:
+            with stage("prob"):
+                cdf_int = self.prob.run(rec, ("cdf_int",))["cdf_int"]                     # decompress.py:88-92
         with stage("range_decode"):
             q = models.range_decode(cdf_int, comp.p_bytes, comp.p_nbytes, L)              # decompress.py:93
         N = S * self.k                                                                    # decompress.py:106

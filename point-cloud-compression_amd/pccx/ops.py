@@ -133,17 +133,18 @@ def knn_gather(x, idx):
     return index_points(x, idx)
 
 
-def knn_points(p1, p2, K, return_nn=True, patch_scale=0.0):
+def knn_points(p1, p2, K, return_nn=True, patch_scale=0.0, return_dists=True, return_idx=True):
     """pytorch3d.ops.knn_points (compress.py:71, pn_kit.py:190).  With patch_scale != 0 the third
-    field holds (nn - p1) * patch_scale, i.e. compress.py:72 and :108 fused."""
+    field holds (nn - p1) * patch_scale, i.e. compress.py:72 and :108 fused.  return_dists / return_idx = False leave that field None
+    and its bytes unwritten (KNN_Patching, compress.py:70-74, keeps the gathered points only)."""
     p1, p2 = _f32c(p1, "knn_points.p1"), _f32c(p2, "knn_points.p2")
     B, M, _ = p1.shape
     N = p2.shape[1]
-    dists = torch.empty(B, M, K, device=p1.device, dtype=torch.float32)
-    idx = torch.empty(B, M, K, device=p1.device, dtype=torch.int64)
+    dists = torch.empty(B, M, K, device=p1.device, dtype=torch.float32) if return_dists else None
+    idx = torch.empty(B, M, K, device=p1.device, dtype=torch.int64) if return_idx else None
     nn = torch.empty(B, M, K, 3, device=p1.device, dtype=torch.float32) if return_nn else None
-    _lib.call("pccx_knn", p1.data_ptr(), B, M, p2.data_ptr(), N, int(K), dists.data_ptr(), idx.data_ptr(),
-              nn.data_ptr() if nn is not None else None, float(patch_scale), _stream())
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    _lib.call("pccx_knn", p1.data_ptr(), B, M, p2.data_ptr(), N, int(K), ptr(dists), ptr(idx), ptr(nn), float(patch_scale), _stream())
     return KNN(dists, idx, nn)
 
 

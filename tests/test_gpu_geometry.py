@@ -116,6 +116,18 @@ def test_knn_patches_fused_centre_and_scale():
     d, i = cport.knn(c, pc, 256)
     want = (pc[i] - c[:, None, :]) * np.float32(scale)
     assert np.array_equal(r.knn[0].cpu().numpy(), want)
+    # the codec's form (KNN_Patching, compress.py:70-74, keeps the gathered points only): distances and indices not written at all
+    r2 = ops.knn_points(dev(c)[None], dev(pc)[None], 256, patch_scale=scale, return_dists=False, return_idx=False)
+    assert r2.dists is None and r2.idx is None and torch.equal(r2.knn, r.knn)
+    r3 = ops.knn_points(dev(c)[None], dev(pc)[None], 256, return_nn=False, return_dists=False)      # indices alone (estimate_normals)
+    assert r3.dists is None and r3.knn is None and torch.equal(r3.idx, r.idx)
+    # the slower general kernel (N > 8192 candidates) takes the same optional outputs
+    big = np.concatenate([pc, pc[::-1] * np.float32(0.5)])
+    a = ops.knn_points(dev(c)[None], dev(big)[None], 300, patch_scale=scale)
+    b_ = ops.knn_points(dev(c)[None], dev(big)[None], 300, patch_scale=scale, return_dists=False, return_idx=False)
+    assert torch.equal(a.knn, b_.knn)
+    with pytest.raises(ops._lib.PccxError):
+        ops.knn_points(dev(c)[None], dev(pc)[None], 256, return_nn=False, return_dists=False, return_idx=False)
 
 
 @pytest.mark.parametrize("method", ["scan", "grid"])

@@ -120,6 +120,11 @@ def test_round_trip_properties_at_batch_scale(nets):
         assert torch.equal(q.view(-1, d), comp.extras["latent_q"])
         out = cd.decompress(comp)
         assert out.shape == (B, 64 * k, 3) and torch.isfinite(out).all()
+        # the resident shortcut (no second evaluation of the probability model) decodes the same cloud, and only applies to the object
+        # compress() returned: the same streams read back from their bytes carry no table and recompute it
+        assert torch.equal(cd.decompress(comp, reuse_cdf=True), out)
+        from_bytes = codec.Compressed.from_packed(comp.packed.clone(), B, comp.s_bytes.shape[1], comp.p_bytes.shape[1], 8192)
+        assert getattr(from_bytes, "_cdf_int", None) is None and torch.equal(cd.decompress(from_bytes, reuse_cdf=True), out)
         # compress is a pure function of (cloud, start): batch composition must not matter
         comp1 = cd.compress(clouds[7:8], starts[7:8])
         assert comp.files(7) == comp1.files(0)
