@@ -438,6 +438,50 @@ PCCX_API int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t 
                                        int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
                                        const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream);
 
+/* ---- the same layers in the f16x2 arithmetic (f16x2): every fp32 product formed from TWO fp16 pieces per operand, three
+ * v_mfma_f32_16x16x32_f16 per fp32 product instead of bf16x3's six, planes of 4 bytes per value instead of 6.  fp16 has five exponent
+ * bits, so every operand travels times an exact power of two: activations entering layer l times sigma_l (chosen by the host from
+ * rigorous interval bounds of the stack, so that |sigma_l y| <= 2^15), weights times tau_l (max|W| tau <= 2^14); a layer's accumulator
+ * is sigma_l tau_l (W y + b s).  The host passes each layer's bias as sigma_l tau_l b and the power-of-two ratios the kernels need:
+ * rho = sigma for a kernel that splits fp32 rows, scale_out = sigma_next / (sigma tau) for a planes epilogue, 1 / (sigma tau) for a
+ * row / max epilogue.  The bounds assume stack inputs of magnitude <= 1: `dyn` (device, 2 floats from pccx_dyn_scale: s and 1 / s, or
+ * NULL for 1) is the stack's dynamic input normalisation -- Conv / ReLU stacks are positively homogeneous in (input, biases), so the
+ * kernels multiply gathered inputs and biases by s and the stack's final rows by 1 / s; no input can overflow whatever the data.
+ * amax8 (device, 8 floats, or NULL): the row epilogues fold the largest |value| they write into it (atomic max over 8 replicas) --
+ * the next stack's input bound.  Same shapes, epilogues and restrictions as the bf16x3 entry points above. */
+PCCX_API size_t pccx_planes_floats_h2(int64_t M, int K);
+PCCX_API size_t pccx_packed_linear_h2_floats(int N, int K);
+/* wp_dev: the f32 fragments of pccx_pack_linear (uploaded) -> the two fp16 planes [t][MT][2] of tau * W */
+PCCX_API int pccx_pack_linear_h2(const float *wp_dev, int N, int K, float tau, float *wplanes_dev, void *stream);
+PCCX_API size_t pccx_planes_gemm_weight_floats_h2(int N, int K);
+PCCX_API int pccx_pack_planes_gemm_h2(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream);
+PCCX_API int pccx_group_planes_h2(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
+                                  int64_t rows_per_batch, int64_t n_src, float rho, const float *dyn, float *planes, void *stream);
+PCCX_API int pccx_fold_planes_h2(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
+                                 float rho, const float *dyn, float *planes, void *stream);
+PCCX_API int pccx_rows_affine_planes_h2(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                        int relu, int64_t M, float rho, const float *dyn, float *planes, void *stream);
+PCCX_API int pccx_planes_gemm_h2(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                                 int epilogue, int group, float scale_out, const float *dyn, float *amax8, float *out, int ldo,
+                                 void *stream);
+PCCX_API int pccx_planes_gemm_gather_h2(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                        int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
+                                        float rho_in, float scale_out, const float *dyn, float *amax8, float *out, int ldo,
+                                        void *stream);
+/* scales5_host (HOST, 5 floats): {rho_in (gather form only), rho_1, rho_2, rho_3, 1 / (sigma_3 tau_3)}, rho_l = sigma_l / (sigma_{l-1} tau_{l-1}) */
+PCCX_API int pccx_planes_chain4_h2(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
+                                   const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group,
+                                   const float *scales5_host, const float *dyn, float *amax8, float *out, int ldo, void *stream);
+PCCX_API int pccx_planes_chain4_gather_h2(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                          int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
+                                          const float *b2, int N2, const float *b3, int N3, int group, const float *scales5_host,
+                                          const float *dyn, float *amax8, float *out, int ldo, void *stream);
+/* The dynamic input normalisation: pccx_absmax folds max |x| over n floats into amax8 (8 non-negative floats the caller cleared);
+ * pccx_dyn_scale turns one or two such maxima into dyn2 = {s, 1 / s}, s the largest power of two <= 1 with bound * s <= 1 where
+ * bound = (combine ? max(a1 m1, a2 m2) : a1 m1 + a2 m2) + add (m2_8 may be NULL). */
+PCCX_API int pccx_absmax(const float *x, int64_t n, float *amax8, void *stream);
+PCCX_API int pccx_dyn_scale(const float *m1_8, float a1, const float *m2_8, float a2, float add, int combine, float *dyn2, void *stream);
+
 /* The epilogue of pccx_prob_forward as an op of its own, for the generic (any --d / --L, compress.py:30-34) path: softmax over
  * the L levels of each row of logits (rows, L), pmf_to_cdf (pn_kit.py:452-461: cumsum, leading 0, clamp <= 1) and torchac 0.9.3's
  * integer CDF.  Any of pmf (rows, L), cdf (rows, L+1), cdf_int (rows, L+1) may be NULL. */

@@ -22,26 +22,121 @@
 #include "common.h"
 #include "mfma_chain.h"
 
-#define PG_CHUNK 12                      // ring chunk: 4 m-tiles x 3 planes (1 KiB fragments)
 #define PG_NB 4                          // ring depth (DMA three chunks ahead)
+
+// The arithmetic of a planes kernel: P = 3 -> bf16x3 (three bf16 planes per operand, six products), P = 2 -> f16x2 (two fp16 planes of the
+// operand times an exact power of two, three products; mfma_chain.h).  A ring chunk holds 4 m-tiles x P planes (1 KiB fragments), so a wave
+// issues P DMA loads per chunk and 2 P plane loads per k-step: the counted waits below are written in terms of P.
+template <int P> struct PgArith;
+template <> struct PgArith<3> {
+    typedef bf16x8 vec;
+    static constexpr int NQ = 6;
+    static __device__ __forceinline__ constexpr int pa(int q) { return q == 0 ? 2 : (q == 1 ? 0 : (q == 2 ? 1 : (q == 3 ? 1 : 0))); }   // (lo,hi) (hi,lo) (mid,mid)
+    static __device__ __forceinline__ constexpr int pb(int q) { return q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : (q == 3 ? 0 : (q == 4 ? 1 : 0)))); }   // (mid,hi) (hi,mid) (hi,hi)
+    static __device__ __forceinline__ void split(const f32x4 &a, const f32x4 &b, float, vec (&pl)[3]) { b3_split8(a, b, pl); }
+    static __device__ __forceinline__ f32x4 mfma(const vec &a, const vec &b, const f32x4 &c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct PgArith<2> {
+    typedef f16x8 vec;
+    static constexpr int NQ = 3;
+    static __device__ __forceinline__ constexpr int pa(int q) { return q == 0 ? 1 : 0; }      // smallest first: (lo,hi) (hi,lo) (hi,hi)
+    static __device__ __forceinline__ constexpr int pb(int q) { return q == 1 ? 1 : 0; }
+    static __device__ __forceinline__ void split(const f32x4 &a, const f32x4 &b, float rho, vec (&pl)[2]) { h2_split8(a, b, rho, pl); }
+    static __device__ __forceinline__ f32x4 mfma(const vec &a, const vec &b, const f32x4 &c) { return H2_MFMA(a, b, c); }
+};
+// f16x2 only: the stack's dynamic input normalisation (pccx_dyn_scale): dyn[0] = s, a power of two with |input| s <= 1, dyn[1] = 1 / s.
+// Conv / ReLU stacks are positively homogeneous in (input, biases): the kernels multiply the gathered input and every bias by s and the
+// stack's final rows by 1 / s, so the static interval bounds of the layers (for inputs of magnitude <= 1) hold whatever the data.
+__device__ __forceinline__ float pg_dyn(const float *dyn, int i) { return dyn ? dyn[i] : 1.f; }
+
+// ---- dynamic input normalisation of an f16x2 stack ---------------------------------------------------------------------------------
+// |x| maxima are collected as the bit patterns of non-negative floats (monotone as unsigned integers) with atomicMax into one of
+// PG_AMAX_REP replicas (the same-address atomics of a large grid spread over eight words); pccx_dyn_scale turns one or two such maxima
+// into the stack's power-of-two scale.  The slots are cleared by the caller once per forward pass (pccx_zero_bytes).
+#define PG_AMAX_REP 8
+__device__ __forceinline__ float pg_wave_max(float m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+__device__ __forceinline__ void pg_amax_commit(float *amax, float m)          // m: the lane's largest |value|
+{
+    m = pg_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned *)amax + (blockIdx.x & (PG_AMAX_REP - 1)), __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, float *__restrict__ amax)
+{
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    pg_amax_commit(amax, m);
+}
+// |x|max over n floats, folded into amax (PG_AMAX_REP floats, non-negative; cleared by the caller before the first contribution)
+extern "C" int pccx_absmax(const float *x, int64_t n, float *amax8, void *stream)
+{
+    if (n == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(x && amax8 && n > 0, "pccx_absmax: bad arguments");
+    long long blocks = (n + 1023) / 1024;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, amax8);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+// bound = combine(a1 max(m1), a2 max(m2)) + add  (combine: 0 = sum, 1 = max; m2 may be NULL), inflated by 2^-20 for the roundings of this
+// very expression; dyn[0] = s = the largest power of two <= 1 with bound * s <= 1 (at least 2^-60; 1 when the bound is 0), dyn[1] = 1 / s
+__global__ void dyn_scale_kernel(const float *__restrict__ m1, float a1, const float *__restrict__ m2, float a2, float add, int combine,
+                                 float *__restrict__ dyn)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float v1 = 0.f, v2 = 0.f;
+    for (int i = 0; i < PG_AMAX_REP; ++i) {
+        v1 = fmaxf(v1, m1[i]);
+        if (m2) v2 = fmaxf(v2, m2[i]);
+    }
+    float bound = (combine ? fmaxf(a1 * v1, a2 * v2) : a1 * v1 + a2 * v2) + add;
+    bound *= 1.f + 0x1p-20f;
+    float s_ = 1.f;
+    if (bound > 0.f && bound < INFINITY) {
+        int e;
+        const float f = frexpf(bound, &e);                   // bound = f 2^e, f in [0.5, 1)
+        int k = f == 0.5f ? e - 1 : e;                       // ceil(log2 bound)
+        k = k < 0 ? 0 : (k > 60 ? 60 : k);                   // s <= 1: small inputs are not blown up (the layer bounds count the biases at full size)
+        s_ = ldexpf(1.f, -k);
+    }
+    dyn[0] = s_;
+    dyn[1] = 1.f / s_;
+}
+extern "C" int pccx_dyn_scale(const float *m1_8, float a1, const float *m2_8, float a2, float add, int combine, float *dyn2, void *stream)
+{
+    PCCX_CHECK_ARG(m1_8 && dyn2 && a1 >= 0.f && a2 >= 0.f && add >= 0.f && (combine == 0 || combine == 1), "pccx_dyn_scale: bad arguments");
+    hipLaunchKernelGGL(dyn_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, m1_8, a1, m2_8, a2, add, combine, dyn2);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
 
 static inline int pg_kt32(int K) { return ((K + 15) / 16 + 1) / 2; }
 static inline int pg_mb(int N) { return (N + 15) / 16 <= 4 ? 4 : 8; }
 
-extern "C" size_t pccx_planes_floats(int64_t M, int K)
+static size_t pg_planes_floats(int64_t M, int K, int P)
 {
     const size_t ntiles = (size_t)((M > 0 ? M : 0) + 15) / 16;
-    return (size_t)pg_kt32(K > 0 ? K : 1) * ntiles * 3 * 256;
+    return (size_t)pg_kt32(K > 0 ? K : 1) * ntiles * P * 256;
 }
+extern "C" size_t pccx_planes_floats(int64_t M, int K) { return pg_planes_floats(M, K, 3); }
+extern "C" size_t pccx_planes_floats_h2(int64_t M, int K) { return pg_planes_floats(M, K, 2); }
 
 // ---- gather + concat + split ------------------------------------------------------------------------------------
 // One wave per row tile.  Row r takes source row s = idx ? (r / rows_per_batch) * n_src + max(idx[r], 0) : r; its channels are
 // f0[s][0..C0) followed by f1[s][0..C1).
+template <int P>
 __global__ __launch_bounds__(256) void group_planes_kernel(const float *__restrict__ f0, int C0, int ld0, const float *__restrict__ f1,
                                                            int C1, int ld1, const int64_t *__restrict__ idx, long long M,
                                                            long long rows_per_batch, long long n_src, int KT32, long long ntiles,
-                                                           uint4 *__restrict__ planes, long long mod0, long long div1)
+                                                           uint4 *__restrict__ planes, long long mod0, long long div1, float rho,
+                                                           const float *__restrict__ dyn)
 {
+    typedef PgArith<P> AR;
+    rho *= pg_dyn(dyn, 0);
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
@@ -72,47 +167,72 @@ __global__ __launch_bounds__(256) void group_planes_kernel(const float *__restri
                 }
             }
         }
-        bf16x8 pl[3];
-        b3_split8(v[0], v[1], pl);
-        uint4 *d = planes + (((size_t)t * ntiles + tile) * 3) * 64 + lane;
+        typename AR::vec pl[P];
+        AR::split(v[0], v[1], rho, pl);
+        uint4 *d = planes + (((size_t)t * ntiles + tile) * P) * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+        for (int p = 0; p < P; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
     }
 }
 
+template <int P>
+static int group_planes_launch(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
+                               int64_t rows_per_batch, int64_t n_src, float *planes, float rho, const float *dyn, void *stream, const char *who)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(planes && M > 0, "%s: null output or negative M", who);
+    PCCX_CHECK_ARG(C0 >= 0 && C1 >= 0 && C0 + C1 >= 1 && (C0 == 0 || (f0 && ld0 >= C0)) && (C1 == 0 || (f1 && ld1 >= C1)),
+                   "%s: bad sources C0=%d C1=%d", who, C0, C1);
+    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1), "%s: indices need rows_per_batch and n_src", who);
+    const long long ntiles = (M + 15) / 16;
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "%s: M too large", who);
+    hipLaunchKernelGGL(group_planes_kernel<P>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, C0 ? f0 : nullptr, C0,
+                       ld0, C1 ? f1 : nullptr, C1, ld1, idx, (long long)M, (long long)(idx ? rows_per_batch : 1),
+                       (long long)(idx ? n_src : 1), pg_kt32(C0 + C1), ntiles, (uint4 *)planes, 0LL, 1LL, rho, dyn);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
 extern "C" int pccx_group_planes(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
                                  int64_t rows_per_batch, int64_t n_src, float *planes, void *stream)
 {
-    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(planes && M > 0, "pccx_group_planes: null output or negative M");
-    PCCX_CHECK_ARG(C0 >= 0 && C1 >= 0 && C0 + C1 >= 1 && (C0 == 0 || (f0 && ld0 >= C0)) && (C1 == 0 || (f1 && ld1 >= C1)),
-                   "pccx_group_planes: bad sources C0=%d C1=%d", C0, C1);
-    PCCX_CHECK_ARG(!idx || (rows_per_batch >= 1 && n_src >= 1), "pccx_group_planes: indices need rows_per_batch and n_src");
-    const long long ntiles = (M + 15) / 16;
-    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_group_planes: M too large");
-    hipLaunchKernelGGL(group_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, C0 ? f0 : nullptr, C0,
-                       ld0, C1 ? f1 : nullptr, C1, ld1, idx, (long long)M, (long long)(idx ? rows_per_batch : 1),
-                       (long long)(idx ? n_src : 1), pg_kt32(C0 + C1), ntiles, (uint4 *)planes, 0LL, 1LL);
-    PCCX_CHECK_LAUNCH();
-    return PCCX_OK;
+    return group_planes_launch<3>(f0, C0, ld0, f1, C1, ld1, idx, M, rows_per_batch, n_src, planes, 1.f, nullptr, stream, "pccx_group_planes");
+}
+// f16x2: planes of (rho * dyn[0]) * value, two fp16 pieces (pccx_planes_floats_h2(M, C0 + C1) floats); dyn = NULL: no dynamic factor
+extern "C" int pccx_group_planes_h2(const float *f0, int C0, int ld0, const float *f1, int C1, int ld1, const int64_t *idx, int64_t M,
+                                    int64_t rows_per_batch, int64_t n_src, float rho, const float *dyn, float *planes, void *stream)
+{
+    PCCX_CHECK_ARG(rho > 0.f, "pccx_group_planes_h2: rho must be a positive power of two");
+    return group_planes_launch<2>(f0, C0, ld0, f1, C1, ld1, idx, M, rows_per_batch, n_src, planes, rho, dyn, stream, "pccx_group_planes_h2");
 }
 
 // torch.cat([a, b.unsqueeze(1).repeat(1, P, 1)], -1) as planes (the inputs of FoldingNet's two stacks, PPPF_AE.py:99-106): row r has
 // the C0 channels of f0 row (mod0 > 0 ? r % mod0 : r) followed by the C1 channels of f1 row r / div1.  Nothing is concatenated or
 // repeated in memory.
+template <int P>
+static int fold_planes_launch(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
+                              float *planes, float rho, const float *dyn, void *stream, const char *who)
+{
+    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
+    PCCX_CHECK_ARG(planes && f0 && f1 && M > 0, "%s: null pointer or negative M", who);
+    PCCX_CHECK_ARG(C0 >= 1 && C1 >= 1 && ld0 >= C0 && ld1 >= C1 && mod0 >= 0 && div1 >= 1, "%s: bad arguments", who);
+    const long long ntiles = (M + 15) / 16;
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "%s: M too large", who);
+    hipLaunchKernelGGL(group_planes_kernel<P>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f0, C0, ld0, f1, C1, ld1,
+                       (const int64_t *)nullptr, (long long)M, 1LL, 1LL, pg_kt32(C0 + C1), ntiles, (uint4 *)planes, (long long)mod0,
+                       (long long)div1, rho, dyn);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
 extern "C" int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
                                 float *planes, void *stream)
 {
-    if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(planes && f0 && f1 && M > 0, "pccx_fold_planes: null pointer or negative M");
-    PCCX_CHECK_ARG(C0 >= 1 && C1 >= 1 && ld0 >= C0 && ld1 >= C1 && mod0 >= 0 && div1 >= 1, "pccx_fold_planes: bad arguments");
-    const long long ntiles = (M + 15) / 16;
-    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_fold_planes: M too large");
-    hipLaunchKernelGGL(group_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, f0, C0, ld0, f1, C1, ld1,
-                       (const int64_t *)nullptr, (long long)M, 1LL, 1LL, pg_kt32(C0 + C1), ntiles, (uint4 *)planes, (long long)mod0,
-                       (long long)div1);
-    PCCX_CHECK_LAUNCH();
-    return PCCX_OK;
+    return fold_planes_launch<3>(f0, C0, ld0, mod0, f1, C1, ld1, div1, M, planes, 1.f, nullptr, stream, "pccx_fold_planes");
+}
+extern "C" int pccx_fold_planes_h2(const float *f0, int C0, int ld0, int64_t mod0, const float *f1, int C1, int ld1, int64_t div1, int64_t M,
+                                   float rho, const float *dyn, float *planes, void *stream)
+{
+    PCCX_CHECK_ARG(rho > 0.f, "pccx_fold_planes_h2: rho must be a positive power of two");
+    return fold_planes_launch<2>(f0, C0, ld0, mod0, f1, C1, ld1, div1, M, planes, rho, dyn, stream, "pccx_fold_planes_h2");
 }
 
 // ---- the per-point part of FoldingNet's first layers straight into operand planes -------------------------------------------------
@@ -120,10 +240,14 @@ extern "C" int pccx_fold_planes(const float *f0, int C0, int ld0, int64_t mod0, 
 // ascending on top of base, so the values are bit-identical) written as the planes of the NEXT layer's operand instead of fp32 rows:
 // round 3 wrote the rows (1.07 GB for the 512-wide MLP of 2048 patches), read them back in group_planes_kernel and wrote the planes.
 // One wave per row tile, as group_planes_kernel; lane (g, n) forms channels 32 t + 16 h + 4 g .. + 3 of row 16 tile + n.
+template <int P>
 __global__ __launch_bounds__(256) void rows_affine_planes_kernel(const float *__restrict__ base, int C, unsigned div, const float *__restrict__ x,
                                                                  int ldx, int Ks, unsigned mod, const float *__restrict__ w, int relu,
-                                                                 long long M, int KT32, long long ntiles, uint4 *__restrict__ planes)
+                                                                 long long M, int KT32, long long ntiles, uint4 *__restrict__ planes,
+                                                                 float rho, const float *__restrict__ dyn)
 {
+    typedef PgArith<P> AR;
+    rho *= pg_dyn(dyn, 0);
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
@@ -153,59 +277,114 @@ __global__ __launch_bounds__(256) void rows_affine_planes_kernel(const float *__
                 v[h] = f32x4{0.f, 0.f, 0.f, 0.f};             // C % 4 == 0: a block is inside the layer or beyond it
             }
         }
-        bf16x8 pl[3];
-        b3_split8(v[0], v[1], pl);
-        uint4 *d = planes + (((size_t)t * ntiles + tile) * 3) * 64 + lane;
+        typename AR::vec pl[P];
+        AR::split(v[0], v[1], rho, pl);
+        uint4 *d = planes + (((size_t)t * ntiles + tile) * P) * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+        for (int p = 0; p < P; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
     }
 }
 
-extern "C" int pccx_rows_affine_planes(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
-                                       int relu, int64_t M, float *planes, void *stream)
+template <int P>
+static int rows_affine_planes_launch(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                     int relu, int64_t M, float *planes, float rho, const float *dyn, void *stream, const char *who)
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
-    PCCX_CHECK_ARG(base && x && w && planes, "pccx_rows_affine_planes: null pointer");
+    PCCX_CHECK_ARG(base && x && w && planes, "%s: null pointer", who);
     PCCX_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0 && Ks >= 1 && Ks <= 4 && ldx >= Ks && div >= 1 && div < 0x7fffffffLL && mod >= 0 && mod < 0x7fffffffLL &&
                        ((uintptr_t)base & 15) == 0,
-                   "pccx_rows_affine_planes: bad arguments (C=%d a multiple of 4, Ks=%d in 1..4, base 16-byte aligned)", C, Ks);
+                   "%s: bad arguments (C=%d a multiple of 4, Ks=%d in 1..4, base 16-byte aligned)", who, C, Ks);
     const long long ntiles = (M + 15) / 16;
-    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "pccx_rows_affine_planes: M too large");
-    hipLaunchKernelGGL(rows_affine_planes_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, base, C, (unsigned)div, x, ldx, Ks,
-                       (unsigned)mod, w, relu, (long long)M, pg_kt32(C), ntiles, (uint4 *)planes);
+    PCCX_CHECK_ARG((ntiles + 3) / 4 <= 0x7fffffffLL, "%s: M too large", who);
+    hipLaunchKernelGGL(rows_affine_planes_kernel<P>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, base, C, (unsigned)div, x, ldx, Ks,
+                       (unsigned)mod, w, relu, (long long)M, pg_kt32(C), ntiles, (uint4 *)planes, rho, dyn);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
-
-// ---- weight stream: [m-block][t][MB m-tiles][plane] fragments out of pccx_pack_linear_b3's [t][MT][plane] ------------
-extern "C" size_t pccx_planes_gemm_weight_floats(int N, int K)
+extern "C" int pccx_rows_affine_planes(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                       int relu, int64_t M, float *planes, void *stream)
 {
-    const int MT = ((N > 0 ? N : 1) + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB;
-    return (size_t)MBS * pg_kt32(K > 0 ? K : 1) * MB * 3 * 256;
+    return rows_affine_planes_launch<3>(base, C, div, x, ldx, Ks, mod, w, relu, M, planes, 1.f, nullptr, stream, "pccx_rows_affine_planes");
+}
+extern "C" int pccx_rows_affine_planes_h2(const float *base, int C, int64_t div, const float *x, int ldx, int Ks, int64_t mod, const float *w,
+                                          int relu, int64_t M, float rho, const float *dyn, float *planes, void *stream)
+{
+    PCCX_CHECK_ARG(rho > 0.f, "pccx_rows_affine_planes_h2: rho must be a positive power of two");
+    return rows_affine_planes_launch<2>(base, C, div, x, ldx, Ks, mod, w, relu, M, planes, rho, dyn, stream, "pccx_rows_affine_planes_h2");
 }
 
-__global__ void planes_weight_kernel(const uint4 *__restrict__ wpl, int KT32, int MT, int MB, int MBS, uint4 *__restrict__ ws)
+// ---- weight stream: [m-block][t][MB m-tiles][plane] fragments out of pccx_pack_linear_b3's (pccx_pack_linear_h2's) [t][MT][plane] ----
+static size_t pg_weight_floats(int N, int K, int P)
 {
-    const size_t total = (size_t)MBS * KT32 * MB * 3 * 64;
+    const int MT = ((N > 0 ? N : 1) + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB;
+    return (size_t)MBS * pg_kt32(K > 0 ? K : 1) * MB * P * 256;
+}
+extern "C" size_t pccx_planes_gemm_weight_floats(int N, int K) { return pg_weight_floats(N, K, 3); }
+extern "C" size_t pccx_planes_gemm_weight_floats_h2(int N, int K) { return pg_weight_floats(N, K, 2); }
+
+__global__ void planes_weight_kernel(const uint4 *__restrict__ wpl, int KT32, int MT, int MB, int MBS, uint4 *__restrict__ ws, int P)
+{
+    const size_t total = (size_t)MBS * KT32 * MB * P * 64;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(e & 63);
         size_t f = e >> 6;
-        const int p = (int)(f % 3); f /= 3;
+        const int p = (int)(f % P); f /= P;
         const int m = (int)(f % MB); f /= MB;
         const int t = (int)(f % KT32);
         const int mb = (int)(f / KT32);
         const int mt = mb * MB + m;
-        ws[e] = mt < MT ? wpl[(((size_t)t * MT + mt) * 3 + p) * 64 + lane] : make_uint4(0, 0, 0, 0);
+        ws[e] = mt < MT ? wpl[(((size_t)t * MT + mt) * P + p) * 64 + lane] : make_uint4(0, 0, 0, 0);
     }
 }
 
+static int pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, int P, void *stream, const char *who)
+{
+    PCCX_CHECK_ARG(wplanes_dev && wstream_dev && N >= 1 && K >= 1, "%s: bad argument", who);
+    const int MT = (N + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB, KT32 = pg_kt32(K);
+    const size_t total = (size_t)MBS * KT32 * MB * P * 64;
+    hipLaunchKernelGGL(planes_weight_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4 *)wplanes_dev, KT32, MT, MB, MBS, (uint4 *)wstream_dev, P);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
 extern "C" int pccx_pack_planes_gemm(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream)
 {
-    PCCX_CHECK_ARG(wplanes_dev && wstream_dev && N >= 1 && K >= 1, "pccx_pack_planes_gemm: bad argument");
-    const int MT = (N + 15) / 16, MB = pg_mb(N), MBS = (MT + MB - 1) / MB, KT32 = pg_kt32(K);
-    const size_t total = (size_t)MBS * KT32 * MB * 3 * 64;
-    hipLaunchKernelGGL(planes_weight_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const uint4 *)wplanes_dev, KT32, MT, MB, MBS, (uint4 *)wstream_dev);
+    return pack_planes_gemm(wplanes_dev, N, K, wstream_dev, 3, stream, "pccx_pack_planes_gemm");
+}
+extern "C" int pccx_pack_planes_gemm_h2(const float *wplanes_dev, int N, int K, float *wstream_dev, void *stream)
+{
+    return pack_planes_gemm(wplanes_dev, N, K, wstream_dev, 2, stream, "pccx_pack_planes_gemm_h2");
+}
+
+// f16x2 weight planes [t][MT][2] of tau * W out of the packed f32 fragments (pccx_pack_linear / pccx_pack_linear_device): the fp16 pair
+// (hi, lo) of every weight times tau, a power of two the caller picks with max|W| tau <= 2^14 (pack_h2.hip: the lo piece of all but
+// negligible weights stays a normal fp16 number)
+extern "C" size_t pccx_packed_linear_h2_floats(int N, int K)
+{
+    if (N < 1 || K < 1) return 0;
+    return (size_t)pg_kt32(K) * (size_t)((N + 15) / 16) * 2 * 256;
+}
+__global__ __launch_bounds__(256) void linear_h2_pack_kernel(const f32x4 *__restrict__ wp, int KT16, int MT, float tau, uint4 *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, T = (KT16 + 1) / 2;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)T * MT) return;
+    const int mt = (int)(item % MT), t = (int)(item / MT);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v0 = wp[((size_t)(2 * t) * MT + mt) * 64 + lane];
+    const f32x4 v1 = 2 * t + 1 < KT16 ? wp[((size_t)(2 * t + 1) * MT + mt) * 64 + lane] : zero;   // an odd last k-tile pairs with zeros
+    f16x8 pl[2];
+    h2_split8(v0, v1, tau, pl);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) out[(((size_t)t * MT + mt) * 2 + p) * 64 + lane] = __builtin_bit_cast(uint4, pl[p]);
+}
+extern "C" int pccx_pack_linear_h2(const float *wp_dev, int N, int K, float tau, float *out_dev, void *stream)
+{
+    PCCX_CHECK_ARG(wp_dev && out_dev && N >= 1 && K >= 1 && tau > 0.f, "pccx_pack_linear_h2: bad arguments");
+    const int KT16 = (K + 15) / 16, MT = (N + 15) / 16;
+    const long items = (long)((KT16 + 1) / 2) * MT;
+    hipLaunchKernelGGL(linear_h2_pack_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)wp_dev,
+                       KT16, MT, tau, (uint4 *)out_dev);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
@@ -220,14 +399,21 @@ __device__ __forceinline__ uint4 pg_load_async(const uint4 *p)    // placed exac
 
 enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
 
-template <int MB, int EPI, bool GATHER>
+// P = 2 (f16x2): the accumulators are sigma_in tau (W y + b s); `bias` holds sigma_in tau b, rho_in = sigma_in scales gathered rows,
+// scale_out = sigma_next / (sigma_in tau) for the planes epilogue, 1 / (sigma_in tau) for the row / max epilogues (times 1 / s there).
+template <int P, int MB, int EPI, bool GATHER>
 __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__restrict__ bin, const int64_t *__restrict__ idx,
                                                              long long rows_per_batch, long long n_src, int ldp, long long M,
                                                              long long ntiles, int KT32,
                                                              const float *__restrict__ wstream, int MBS, const float *__restrict__ bias,
-                                                             int N, int relu, int group, float *__restrict__ out, int ldo)
+                                                             int N, int relu, int group, float *__restrict__ out, int ldo, float rho_in,
+                                                             float scale_out, const float *__restrict__ dyn, float *__restrict__ amax)
 {
+    typedef PgArith<P> AR;
+    typedef typename AR::vec avec;
+    constexpr int PG_CHUNK = 4 * P;                            // ring chunk: 4 m-tiles x P planes (1 KiB fragments)
     constexpr int HALVES = MB / 4;                             // ring chunks per k-step
+    const float dyn_s = P == 2 ? pg_dyn(dyn, 0) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
     // Block order: XCD-aware.  Consecutive workgroup ids go round the 8 XCDs, so the MBS m-blocks of one 128-row block are
@@ -256,18 +442,19 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 16 * (mb * MB + mt) + 4 * g + r;
-            b[r] = (bias && c < N) ? bias[c] : 0.f;
+            b[r] = (bias && c < N) ? (P == 2 ? bias[c] * dyn_s : bias[c]) : 0.f;
         }
         acc[0][mt] = b; acc[1][mt] = b;
     }
     const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
     {
-        // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [3], B(t+2) [6];  boundary(2t+1): DMA(2t+4) [3]
-        //                                          HALVES = 1:  boundary(t):  DMA(t+3) [3],  B(t+2) [6]
+        // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [P], B(t+2) [2 P];  boundary(2t+1): DMA(2t+4) [P]
+        //                                          HALVES = 1:  boundary(t):  DMA(t+3) [P],  B(t+2) [2 P]
         // loads complete in order, so boundary(c) may leave in flight everything issued after the youngest load it needs.
         // GATHER: bin = fp32 source rows (n_src per batch, ldp = 32 * KT32 floats, zero padded); row r reads source row
         // (r / rows_per_batch) * n_src + max(idx[r], 0) and is split in registers at use (4 loads per k-step instead of 6).
-        constexpr int NBL = GATHER ? 4 : 6, NBV = GATHER ? 2 : 3;
+        constexpr int NBL = GATHER ? 4 : 2 * P, NBV = GATHER ? 2 : P;
+        const float rho_g = rho_in * dyn_s;
         uint4 bs[3][2][NBV];
         const uint4 *gsrc[2] = {nullptr, nullptr};
         if constexpr (GATHER) {
@@ -286,50 +473,48 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 #pragma unroll
                 for (int pl = 0; pl < NBV; ++pl)
                     dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
-                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * P + pl) * 64 + lane);
         };
         auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
-            bf16x8 bc[2][3];
+            avec bc[2][P];
 #pragma unroll
             for (int half = 0; half < HALVES; ++half) {
                 const int c = HALVES * t + half;
                 if (half == 0) {
                     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NBL) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NBL) : "memory");
+                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NBL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         if constexpr (GATHER)
-                            b3_split8(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), bc[nt]);
+                            AR::split(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), rho_g, bc[nt]);
                         else
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) bc[nt][pl] = __builtin_bit_cast(bf16x8, braw[nt][pl < NBV ? pl : 0]);
+                            for (int pl = 0; pl < P; ++pl) bc[nt][pl] = __builtin_bit_cast(avec, braw[nt][pl < NBV ? pl : 0]);
                     }
                 } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NBL) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + 2 * NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
-                bf16x8 a[4][3];
+                avec a[4][P];
 #pragma unroll
                 for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                    for (int pl = 0; pl < P; ++pl) a[mq][pl] = __builtin_bit_cast(avec, buf[(mq * P + pl) * 64]);
                 __builtin_amdgcn_sched_barrier(0);
-                // six products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                // the products, smallest first (bf16x3: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); f16x2: (lo,hi) (hi,lo) (hi,hi))
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < AR::NQ; ++q)
 #pragma unroll
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc[nt][4 * half + mq] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], bc[nt][PB[q]], acc[nt][4 * half + mq], 0, 0, 0);
+                            acc[nt][4 * half + mq] = AR::mfma(a[mq][AR::pa(q)], bc[nt][AR::pb(q)], acc[nt][4 * half + mq]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -357,15 +542,17 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
             for (int j = 0; j < MB / 2; ++j) {
                 const int to = mb * (MB / 2) + j;
                 if (to >= KTo) continue;
-                bf16x8 pl[3];
-                if (relu) b3_split8(relu4(acc[nt][2 * j]), relu4(acc[nt][2 * j + 1]), pl);
-                else b3_split8(acc[nt][2 * j], acc[nt][2 * j + 1], pl);
-                uint4 *d = o + (((size_t)to * ntiles + tile0 + nt) * 3) * 64 + lane;
+                avec pl[P];
+                if (relu) AR::split(relu4(acc[nt][2 * j]), relu4(acc[nt][2 * j + 1]), scale_out, pl);
+                else AR::split(acc[nt][2 * j], acc[nt][2 * j + 1], scale_out, pl);
+                uint4 *d = o + (((size_t)to * ntiles + tile0 + nt) * P) * 64 + lane;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
+                for (int p = 0; p < P; ++p) d[p * 64] = __builtin_bit_cast(uint4, pl[p]);
             }
         }
     } else if constexpr (EPI == PG_EPI_ROWS) {
+        const float unscale = P == 2 ? scale_out * pg_dyn(dyn, 1) : 1.f;
+        float vmax = 0.f;                                             // f16x2: the largest |value| written (the next stack's input bound)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const long long row = (tile0 + nt) * 16 + n;
@@ -374,6 +561,11 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
             for (int mt = 0; mt < MB; ++mt) {
                 const int c = 16 * (mb * MB + mt) + 4 * g;
                 f32x4 v = relu ? relu4(acc[nt][mt]) : acc[nt][mt];
+                if constexpr (P == 2) {
+                    v = v * unscale;                                  // powers of two: exact
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, fabsf(v[r]));      // channels past N are exact zeros
+                }
                 float *po = out + (size_t)row * ldo + c;
                 if (c + 3 < N && ldo % 4 == 0) {
                     *(f32x4 *)po = v;
@@ -383,6 +575,9 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                         if (c + r < N) po[r] = v[r];
                 }
             }
+        }
+        if constexpr (P == 2) {
+            if (amax) pg_amax_commit(amax, vmax);                     // whole waves reach this (no divergent exit above)
         }
     } else {
         // max over groups of `group` rows (32, 64 or 128; M is a multiple of it, so no group holds padded rows).  In the wave:
@@ -405,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
             float v = smax[(gi * wpg) * (16 * MB) + c];
             for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * (16 * MB) + c]);
             if (relu) v = fmaxf(v, 0.f);                   // max(relu(x)) = relu(max(x))
+            if constexpr (P == 2) v *= scale_out * pg_dyn(dyn, 1);       // a positive power of two commutes with max and relu
             const long long grp = blk * gpb + gi;
             const int ch = mb * 16 * MB + c;
             if (grp < G && ch < N) out[(size_t)grp * ldo + ch] = v;
@@ -414,9 +610,11 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 
 // out: epilogue 0 -> planes of the N output channels (pccx_planes_floats(M, N) floats); 1 -> fp32 rows (M, ldo);
 // 2 -> fp32 (M / group, ldo), the max over each `group` consecutive rows (group in {32, 64, 128}, M % group == 0).
+template <int P>
 static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K,
                               const float *wstream, const float *bias, int N, int relu, int epilogue, int group, float *out, int ldo,
-                              void *stream, const char *who)
+                              void *stream, const char *who, float rho_in = 1.f, float scale_out = 1.f, const float *dyn = nullptr,
+                              float *amax = nullptr)
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
@@ -434,9 +632,9 @@ static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_p
     hipStream_t st = (hipStream_t)stream;
     relu &= 1;
 #define PG_LAUNCH(MB_, E_, G_)                                                                                                  \
-    hipLaunchKernelGGL((planes_gemm_kernel<MB_, E_, G_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx,       \
+    hipLaunchKernelGGL((planes_gemm_kernel<P, MB_, E_, G_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx,    \
                        (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, \
-                       group, out, ldo)
+                       group, out, ldo, rho_in, scale_out, dyn, amax)
 #define PG_LAUNCH_E(MB_, G_)                                                                                                    \
     do {                                                                                                                        \
         if (epilogue == PG_EPI_PLANES) PG_LAUNCH(MB_, PG_EPI_PLANES, G_);                                                       \
@@ -454,8 +652,20 @@ static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_p
 extern "C" int pccx_planes_gemm(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
                                 int epilogue, int group, float *out, int ldo, void *stream)
 {
-    return planes_gemm_launch(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
-                              "pccx_planes_gemm");
+    return planes_gemm_launch<3>(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                                 "pccx_planes_gemm");
+}
+// The f16x2 form (two fp16 planes per operand, three products per fp32 product: mfma_chain.h): planes_in = pccx_planes_floats_h2 planes of
+// sigma_in * input, wstream = pccx_pack_planes_gemm_h2 of the planes of tau * W, bias = sigma_in tau b (the kernel multiplies it by
+// dyn[0]).  scale_out: epilogue 0 -> sigma_next / (sigma_in tau), the planes written are those of sigma_next * output; epilogues 1, 2 ->
+// 1 / (sigma_in tau), the rows are multiplied by it and by dyn[1].  Every scale is a power of two (exact).
+extern "C" int pccx_planes_gemm_h2(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                                   int epilogue, int group, float scale_out, const float *dyn, float *amax8, float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(scale_out > 0.f, "pccx_planes_gemm_h2: scale_out must be a positive power of two");
+    PCCX_CHECK_ARG(!amax8 || epilogue == PG_EPI_ROWS, "pccx_planes_gemm_h2: the |value| maximum is collected by the row epilogue only");
+    return planes_gemm_launch<2>(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                                 "pccx_planes_gemm_h2", 1.f, scale_out, dyn, amax8);
 }
 
 // The same layer with its input gathered in the kernel (see pccx_planes_chain4_gather): src = fp32 rows of ldp = 32 * ceil(K / 32)
@@ -465,8 +675,19 @@ extern "C" int pccx_planes_gemm_gather(const float *src, int ldp, const int64_t 
                                        float *out, int ldo, void *stream)
 {
     PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_gemm_gather: null indices");
-    return planes_gemm_launch(src, idx, rows_per_batch, n_src, ldp, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
-                              "pccx_planes_gemm_gather");
+    return planes_gemm_launch<3>(src, idx, rows_per_batch, n_src, ldp, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                                 "pccx_planes_gemm_gather");
+}
+// f16x2: the gathered fp32 rows are multiplied by rho_in * dyn[0] (= sigma_in s) as they are split in registers
+extern "C" int pccx_planes_gemm_gather_h2(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                          int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
+                                          float rho_in, float scale_out, const float *dyn, float *amax8, float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_gemm_gather_h2: null indices");
+    PCCX_CHECK_ARG(rho_in > 0.f && scale_out > 0.f, "pccx_planes_gemm_gather_h2: scales must be positive powers of two");
+    PCCX_CHECK_ARG(!amax8 || epilogue == PG_EPI_ROWS, "pccx_planes_gemm_gather_h2: the |value| maximum is collected by the row epilogue only");
+    return planes_gemm_launch<2>(src, idx, rows_per_batch, n_src, ldp, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
+                                 "pccx_planes_gemm_gather_h2", rho_in, scale_out, dyn, amax8);
 }
 
 // ---- four-layer stack in one kernel ------------------------------------------------------------------------------
@@ -478,43 +699,43 @@ extern "C" int pccx_planes_gemm_gather(const float *src, int ldp, const int64_t 
 // of the stack exists in HBM.
 //   MQ0 / MQ1 / MQ2 : output m-quads (4 m-tiles) of layers 0..2 (1 or 2);  KT1..KT3 : K/32 blocks of the inputs of layers 1..3;
 //   NP : passes (of 8 m-tiles) of the last layer.
-template <int KT, int MQ, class WS>
-__device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, const bf16x8 (&in)[2][KT][3], f32x4 (&acc)[2][4 * MQ])
+template <int P, int KT, int MQ, class WS>
+__device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, const typename PgArith<P>::vec (&in)[2][KT][P], f32x4 (&acc)[2][4 * MQ])
 {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    typedef PgArith<P> AR;
+    typedef typename AR::vec avec;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int mqq = 0; mqq < MQ; ++mqq) {
-            // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (6 loads) may stay in flight
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (2 P loads) may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
             __syncthreads();
             {
                 const int nx = c + PG_NB - 1;
                 ws.issue(nx < nch ? nx : 0, nx % PG_NB);
             }
             const f32x4 *buf = ws.chunk(c);
-            bf16x8 a[4][3];
+            avec a[4][P];
 #pragma unroll
             for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                for (int pl = 0; pl < P; ++pl) a[mq][pl] = __builtin_bit_cast(avec, buf[(mq * P + pl) * 64]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < AR::NQ; ++q)
 #pragma unroll
                 for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[nt][4 * mqq + mq] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], in[nt][kt][PB[q]], acc[nt][4 * mqq + mq], 0, 0, 0);
+                        acc[nt][4 * mqq + mq] = AR::mfma(a[mq][AR::pa(q)], in[nt][kt][AR::pb(q)], acc[nt][4 * mqq + mq]);
             __builtin_amdgcn_sched_barrier(0);
             ++c;
         }
 }
 
 template <int NTILES>
-__device__ __forceinline__ void pg_bias_init(f32x4 (&acc)[2][NTILES], const float *__restrict__ bias, int N, int m0, int g)
+__device__ __forceinline__ void pg_bias_init(f32x4 (&acc)[2][NTILES], const float *__restrict__ bias, int N, int m0, int g, float mul = 1.f, bool scaled = false)
 {
 #pragma unroll
     for (int mt = 0; mt < NTILES; ++mt) {
@@ -522,33 +743,41 @@ __device__ __forceinline__ void pg_bias_init(f32x4 (&acc)[2][NTILES], const floa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ch = 16 * (m0 + mt) + 4 * g + r;
-            b[r] = (bias && ch < N) ? bias[ch] : 0.f;
+            b[r] = (bias && ch < N) ? (scaled ? bias[ch] * mul : bias[ch]) : 0.f;
         }
         acc[0][mt] = b; acc[1][mt] = b;
     }
 }
 
 // relu + split of a layer's accumulators into the next layer's planes (k-tile j = C tiles 2j, 2j+1; a missing odd tile is zero)
-template <int NTILES, int KT>
-__device__ __forceinline__ void pg_to_planes(const f32x4 (&acc)[2][NTILES], bf16x8 (&pl)[2][KT][3])
+template <int P, int NTILES, int KT>
+__device__ __forceinline__ void pg_to_planes(const f32x4 (&acc)[2][NTILES], typename PgArith<P>::vec (&pl)[2][KT][P], float rho)
 {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int j = 0; j < KT; ++j)
-            b3_split8(relu4(acc[nt][2 * j]), 2 * j + 1 < NTILES ? relu4(acc[nt][2 * j + 1]) : zero, pl[nt][j]);
+            PgArith<P>::split(relu4(acc[nt][2 * j]), 2 * j + 1 < NTILES ? relu4(acc[nt][2 * j + 1]) : zero, rho, pl[nt][j]);
 }
 
-template <int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP, bool GATHER>
+// P = 2 (f16x2): b0..b3 hold sigma_l tau_l b_l (multiplied by dyn[0] here), sc = {rho_in, rho_1, rho_2, rho_3, 1 / (sigma_3 tau_3)}:
+// rho_in scales the gathered rows, rho_l = sigma_l / (sigma_{l-1} tau_{l-1}) the split in front of layer l, the last the output rows.
+struct PgChainScales { float rho_in, rho1, rho2, rho3, inv3; };
+template <int P, int MQ0, int KT1, int MQ1, int KT2, int MQ2, int KT3, int NP, bool GATHER>
 __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__restrict__ bin, const int64_t *__restrict__ idx,
                                                                long long rows_per_batch, long long n_src, int ldp, long long M,
                                                                long long ntiles, int KT0,
                                                                const float *__restrict__ wstream, const float *__restrict__ b0, int N0,
                                                                const float *__restrict__ b1, int N1, const float *__restrict__ b2, int N2,
                                                                const float *__restrict__ b3, int N3, int group, float *__restrict__ out,
-                                                               int ldo)
+                                                               int ldo, PgChainScales sc, const float *__restrict__ dyn, float *__restrict__ amax)
 {
+    typedef PgArith<P> AR;
+    typedef typename AR::vec avec;
+    constexpr int PG_CHUNK = 4 * P;
+    constexpr bool H2 = P == 2;
+    const float dyn_s = H2 ? pg_dyn(dyn, 0) : 1.f;
     static_assert(2 * KT1 <= 4 * MQ0 + 1 && 2 * KT2 <= 4 * MQ1 + 1 && 2 * KT3 <= 4 * MQ2 + 1, "a layer's K blocks come from the previous layer's tiles");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
@@ -568,10 +797,11 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
     // bin = fp32 source rows (n_src per batch, ldp = 32 * KT0 floats each, zero padded), row r reads source row
     // (r / rows_per_batch) * n_src + max(idx[r], 0) (pointnet_sa_module.py:27,73-83) -- and split in registers at use.
     f32x4 acc0[2][4 * MQ0];
-    pg_bias_init<4 * MQ0>(acc0, b0, N0, 0, g);
+    pg_bias_init<4 * MQ0>(acc0, b0, N0, 0, g, dyn_s, H2);
     {
-        constexpr int NBL = GATHER ? 4 : 6;                  // B loads per k-step
-        constexpr int NBV = GATHER ? 2 : 3;
+        constexpr int NBL = GATHER ? 4 : 2 * P;              // B loads per k-step
+        constexpr int NBV = GATHER ? 2 : P;
+        const float rho_g = sc.rho_in * dyn_s;
         uint4 bs[3][2][NBV];
         const uint4 *gsrc[2] = {nullptr, nullptr};
         if constexpr (GATHER) {
@@ -590,49 +820,47 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
 #pragma unroll
                 for (int pl = 0; pl < NBV; ++pl)
                     dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
-                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * 3 + pl) * 64 + lane);
+                                         : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * P + pl) * 64 + lane);
         };
         auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
-            bf16x8 bc[2][3];
+            avec bc[2][P];
 #pragma unroll
             for (int half = 0; half < MQ0; ++half) {
                 const int c = MQ0 * t + half;
                 if (half == 0) {
                     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NBL) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NBL) : "memory");
+                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NBL) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         if constexpr (GATHER)
-                            b3_split8(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), bc[nt]);
+                            AR::split(__builtin_bit_cast(f32x4, braw[nt][0]), __builtin_bit_cast(f32x4, braw[nt][1]), rho_g, bc[nt]);
                         else
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) bc[nt][pl] = __builtin_bit_cast(bf16x8, braw[nt][pl < NBV ? pl : 0]);
+                            for (int pl = 0; pl < P; ++pl) bc[nt][pl] = __builtin_bit_cast(avec, braw[nt][pl < NBV ? pl : 0]);
                     }
                 } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + 2 * NBL) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + 2 * NBL) : "memory");
                     __syncthreads();
                     dma(c + PG_NB - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
-                bf16x8 a[4][3];
+                avec a[4][P];
 #pragma unroll
                 for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[mq][pl] = __builtin_bit_cast(bf16x8, buf[(mq * 3 + pl) * 64]);
+                    for (int pl = 0; pl < P; ++pl) a[mq][pl] = __builtin_bit_cast(avec, buf[(mq * P + pl) * 64]);
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < AR::NQ; ++q)
 #pragma unroll
                     for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc0[nt][4 * half + mq] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mq][PA[q]], bc[nt][PB[q]], acc0[nt][4 * half + mq], 0, 0, 0);
+                            acc0[nt][4 * half + mq] = AR::mfma(a[mq][AR::pa(q)], bc[nt][AR::pb(q)], acc0[nt][4 * half + mq]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -650,26 +878,28 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
     }                                                                     // registers are reused; the ring's DMAs with them
     int c = MQ0 * KT0;
     // ---- layers 1, 2: registers to registers
-    bf16x8 i1[2][KT1][3];
-    pg_to_planes<4 * MQ0, KT1>(acc0, i1);
+    avec i1[2][KT1][P];
+    pg_to_planes<P, 4 * MQ0, KT1>(acc0, i1, sc.rho1);
     f32x4 acc1[2][4 * MQ1];
-    pg_bias_init<4 * MQ1>(acc1, b1, N1, 0, g);
-    pg_chain_layer<KT1, MQ1>(ws, c, nch, i1, acc1);
-    bf16x8 i2[2][KT2][3];
-    pg_to_planes<4 * MQ1, KT2>(acc1, i2);
+    pg_bias_init<4 * MQ1>(acc1, b1, N1, 0, g, dyn_s, H2);
+    pg_chain_layer<P, KT1, MQ1>(ws, c, nch, i1, acc1);
+    avec i2[2][KT2][P];
+    pg_to_planes<P, 4 * MQ1, KT2>(acc1, i2, sc.rho2);
     f32x4 acc2[2][4 * MQ2];
-    pg_bias_init<4 * MQ2>(acc2, b2, N2, 0, g);
-    pg_chain_layer<KT2, MQ2>(ws, c, nch, i2, acc2);
-    bf16x8 i3[2][KT3][3];
-    pg_to_planes<4 * MQ2, KT3>(acc2, i3);
+    pg_bias_init<4 * MQ2>(acc2, b2, N2, 0, g, dyn_s, H2);
+    pg_chain_layer<P, KT2, MQ2>(ws, c, nch, i2, acc2);
+    avec i3[2][KT3][P];
+    pg_to_planes<P, 4 * MQ2, KT3>(acc2, i3, sc.rho3);
+    const float unscale = H2 ? sc.inv3 * pg_dyn(dyn, 1) : 1.f;
+    float vmax = 0.f;                                         // f16x2, group == 1: the largest value written (the next stack's input bound)
     // ---- last layer in passes of 8 m-tiles, each reduced over the row groups (group == 1: no reduction, the rows themselves)
     const int gpb = 128 / group, wpg = group / 32;
     const long long G = M / group;
 #pragma unroll 1
     for (int ps = 0; ps < NP; ++ps) {
         f32x4 acc3[2][8];
-        pg_bias_init<8>(acc3, b3, N3, 8 * ps, g);
-        pg_chain_layer<KT3, 2>(ws, c, nch, i3, acc3);
+        pg_bias_init<8>(acc3, b3, N3, 8 * ps, g, dyn_s, H2);
+        pg_chain_layer<P, KT3, 2>(ws, c, nch, i3, acc3);
         if (group == 1) {
             // relu(L3(...)) as fp32 rows (M, ldo): lane (g, n) holds channels 128 ps + 16 mt + 4 g .. + 3 of row 16 (tile0 + nt) + n
 #pragma unroll
@@ -679,7 +909,12 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
 #pragma unroll
                     for (int mt = 0; mt < 8; ++mt) {
                         const int co = 128 * ps + 16 * mt + 4 * g;
-                        const f32x4 v = relu4(acc3[nt][mt]);
+                        f32x4 v = relu4(acc3[nt][mt]);
+                        if constexpr (H2) {
+                            v = v * unscale;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, v[r]);
+                        }
                         if (co + 3 < N3 && (ldo & 3) == 0) {
                             *(f32x4 *)(out + (size_t)row * ldo + co) = v;
                         } else {
@@ -706,6 +941,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
             float v = smax[(gi * wpg) * 128 + ch];
             for (int q = 1; q < wpg; ++q) v = fmaxf(v, smax[(gi * wpg + q) * 128 + ch]);
             v = fmaxf(v, 0.f);                               // max(relu(x)) = relu(max(x))
+            if constexpr (H2) v *= unscale;
             const long long grp = blk * gpb + gi;
             const int co = 128 * ps + ch;
             if (grp < G && co < N3) out[(size_t)grp * ldo + co] = v;
@@ -713,6 +949,9 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
         // the next pass writes smax only after its first ring boundary (a barrier every thread reaches after these reads)
     }
     ws.drain();
+    if constexpr (H2) {
+        if (amax && group == 1) pg_amax_commit(amax, vmax);
+    }
 }
 
 // out (M / group, ldo) = max over each `group` consecutive rows of relu(L3(relu(L2(relu(L1(relu(L0(x)))))))).
@@ -723,9 +962,11 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
 //   pccx_planes_chain4_gather : x gathered in the kernel from fp32 rows src (n_src rows per batch of ldp = 32 * ceil(K0 / 32) floats,
 //                               the K0 channels zero padded) by idx (M entries, -1 -> row 0): the grouped tensor of
 //                               pointnet_sa_module.py:73-83 never exists in memory in any form.
+template <int P>
 static int planes_chain4_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K0,
                                 const float *wstream, const float *b0, int N0, const float *b1, int N1, const float *b2, int N2,
-                                const float *b3, int N3, int group, float *out, int ldo, void *stream, const char *who)
+                                const float *b3, int N3, int group, float *out, int ldo, void *stream, const char *who,
+                                PgChainScales sc = PgChainScales{1.f, 1.f, 1.f, 1.f, 1.f}, const float *dyn = nullptr, float *amax = nullptr)
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
@@ -740,9 +981,9 @@ static int planes_chain4_launch(const float *x, const int64_t *idx, int64_t rows
     hipStream_t st = (hipStream_t)stream;
     auto kt = [](int N) { return pg_kt32(N); };
 #define PG_CHAIN(G_, MQ0, KT1, MQ1, KT2, MQ2, KT3, NP)                                                                           \
-    hipLaunchKernelGGL((planes_chain4_kernel<MQ0, KT1, MQ1, KT2, MQ2, KT3, NP, G_>), dim3((unsigned)nblk), dim3(256), 0, st,       \
+    hipLaunchKernelGGL((planes_chain4_kernel<P, MQ0, KT1, MQ1, KT2, MQ2, KT3, NP, G_>), dim3((unsigned)nblk), dim3(256), 0, st,    \
                        (const uint4 *)x, idx, (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT0, wstream, b0, \
-                       N0, b1, N1, b2, N2, b3, N3, group, out, ldo)
+                       N0, b1, N1, b2, N2, b3, N3, group, out, ldo, sc, dyn, amax)
     if (N0 <= 32 && N1 > 32 && N1 <= 64 && N2 > 32 && N2 <= 64 && N3 > 64 && N3 <= 128) {
         // (3, 64, 64, 128): layer 1 reads one K block, layers 2 and 3 two
         PCCX_CHECK_ARG(kt(N0) == 1 && kt(N1) == 2 && kt(N2) == 2, "%s: unsupported widths %d %d %d %d", who, N0, N1, N2, N3);
@@ -763,8 +1004,21 @@ extern "C" int pccx_planes_chain4(const float *planes_in, int64_t M, int K0, con
                                   const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group, float *out,
                                   int ldo, void *stream)
 {
-    return planes_chain4_launch(planes_in, nullptr, 1, 1, 0, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo, stream,
-                                "pccx_planes_chain4");
+    return planes_chain4_launch<3>(planes_in, nullptr, 1, 1, 0, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo, stream,
+                                   "pccx_planes_chain4");
+}
+// f16x2: planes_in / wstream / b0..b3 in the f16x2 forms (pccx_planes_gemm_h2); scales = {rho_in (gather only), rho_1, rho_2, rho_3,
+// 1 / (sigma_3 tau_3)} with rho_l = sigma_l / (sigma_{l-1} tau_{l-1}); the output rows are also multiplied by dyn[1], the biases by dyn[0]
+extern "C" int pccx_planes_chain4_h2(const float *planes_in, int64_t M, int K0, const float *wstream, const float *b0, int N0,
+                                     const float *b1, int N1, const float *b2, int N2, const float *b3, int N3, int group,
+                                     const float *scales5_host, const float *dyn, float *amax8, float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(scales5_host, "pccx_planes_chain4_h2: null scales");
+    PCCX_CHECK_ARG(!amax8 || group == 1, "pccx_planes_chain4_h2: the value maximum is collected with group == 1 (rows) only");
+    const PgChainScales sc{scales5_host[0], scales5_host[1], scales5_host[2], scales5_host[3], scales5_host[4]};
+    PCCX_CHECK_ARG(sc.rho_in > 0.f && sc.rho1 > 0.f && sc.rho2 > 0.f && sc.rho3 > 0.f && sc.inv3 > 0.f, "pccx_planes_chain4_h2: scales must be positive");
+    return planes_chain4_launch<2>(planes_in, nullptr, 1, 1, 0, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo, stream,
+                                   "pccx_planes_chain4_h2", sc, dyn, amax8);
 }
 
 extern "C" int pccx_planes_chain4_gather(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
@@ -772,8 +1026,21 @@ extern "C" int pccx_planes_chain4_gather(const float *src, int ldp, const int64_
                                          const float *b2, int N2, const float *b3, int N3, int group, float *out, int ldo, void *stream)
 {
     PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_chain4_gather: null indices");
-    return planes_chain4_launch(src, idx, rows_per_batch, n_src, ldp, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo,
-                                stream, "pccx_planes_chain4_gather");
+    return planes_chain4_launch<3>(src, idx, rows_per_batch, n_src, ldp, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo,
+                                   stream, "pccx_planes_chain4_gather");
+}
+extern "C" int pccx_planes_chain4_gather_h2(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
+                                            int K0, const float *wstream, const float *b0, int N0, const float *b1, int N1,
+                                            const float *b2, int N2, const float *b3, int N3, int group, const float *scales5_host,
+                                            const float *dyn, float *amax8, float *out, int ldo, void *stream)
+{
+    PCCX_CHECK_ARG(idx || M == 0, "pccx_planes_chain4_gather_h2: null indices");
+    PCCX_CHECK_ARG(!amax8 || group == 1, "pccx_planes_chain4_gather_h2: the value maximum is collected with group == 1 (rows) only");
+    PCCX_CHECK_ARG(scales5_host, "pccx_planes_chain4_gather_h2: null scales");
+    const PgChainScales sc{scales5_host[0], scales5_host[1], scales5_host[2], scales5_host[3], scales5_host[4]};
+    PCCX_CHECK_ARG(sc.rho_in > 0.f && sc.rho1 > 0.f && sc.rho2 > 0.f && sc.rho3 > 0.f && sc.inv3 > 0.f, "pccx_planes_chain4_gather_h2: scales must be positive");
+    return planes_chain4_launch<2>(src, idx, rows_per_batch, n_src, ldp, M, K0, wstream, b0, N0, b1, N1, b2, N2, b3, N3, group, out, ldo,
+                                   stream, "pccx_planes_chain4_gather_h2", sc, dyn, amax8);
 }
 
 // ---- three wide layers in one kernel -----------------------------------------------------------------------------
@@ -889,7 +1156,7 @@ extern "C" int pccx_pack_planes_chain_wide(const float *wp3_l0, const float *wp3
     PCCX_CHECK_HIP(hipMemcpyAsync(wstream_dev + n0, wp3_l1, sizeof(float) * n1, hipMemcpyDeviceToDevice, st));
     const size_t total = (size_t)2 * 8 * 16 * 3 * 64;
     hipLaunchKernelGGL(planes_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4 *)wp3_l2, 8, 32, 16, 2,
-                       (uint4 *)(wstream_dev + n0 + n1));                                                           // [pass][t][16][3]
+                       (uint4 *)(wstream_dev + n0 + n1), 3);                                                           // [pass][t][16][3]
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

@@ -114,6 +114,22 @@ _SIGNATURES = {
     "pccx_planes_chain4": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "pccx_planes_chain4_gather": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
                                   C.c_int, _P, C.c_int, _P],
+    "pccx_planes_floats_h2": [C.c_int64, C.c_int],
+    "pccx_packed_linear_h2_floats": [C.c_int, C.c_int],
+    "pccx_pack_linear_h2": [_P, C.c_int, C.c_int, C.c_float, _P, _P],
+    "pccx_planes_gemm_weight_floats_h2": [C.c_int, C.c_int],
+    "pccx_pack_planes_gemm_h2": [_P, C.c_int, C.c_int, _P, _P],
+    "pccx_group_planes_h2": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_float, _P, _P, _P],
+    "pccx_fold_planes_h2": [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_float, _P, _P, _P],
+    "pccx_rows_affine_planes_h2": [_P, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int64, C.c_float, _P, _P, _P],
+    "pccx_planes_gemm_h2": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_int, _P],
+    "pccx_planes_gemm_gather_h2": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, C.c_float, _P, _P, _P, C.c_int, _P],
+    "pccx_planes_chain4_h2": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P],
+    "pccx_planes_chain4_gather_h2": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int,
+                                     C.c_int, _P, _P, _P, _P, C.c_int, _P],
+    "pccx_absmax": [_P, C.c_int64, _P, _P],
+    "pccx_dyn_scale": [_P, C.c_float, _P, C.c_float, C.c_float, C.c_int, _P, _P],
     "pccx_sigmoid_spread": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_round": [_P, C.c_int64, _P, _P],
     "pccx_pack_linear_device": [_P, C.c_int, C.c_int, C.c_int, _P, _P],
@@ -148,7 +164,8 @@ _SIGNATURES = {
     "pccx_adam_step_dev": [_P, _P, _P, _P, C.c_int64, _P, C.c_float, _P, C.c_float, C.c_float, C.c_float, _P],
     "pccx_quantize_st": [_P, C.c_int64, C.c_float, C.c_float, C.c_int, _P, _P, _P],
 }
-_RESTYPES = {"pccx_streams_packed_bytes": C.c_size_t, "pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_train_sums_doubles": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
+_RESTYPES = {"pccx_planes_floats_h2": C.c_size_t, "pccx_packed_linear_h2_floats": C.c_size_t, "pccx_planes_gemm_weight_floats_h2": C.c_size_t,
+             "pccx_streams_packed_bytes": C.c_size_t, "pccx_sort_keys_workspace_bytes": C.c_size_t, "pccx_train_sums_doubles": C.c_size_t, "pccx_ae_encoder_h2_blob_floats": C.c_size_t, "pccx_ae_decoder_h2_blob_floats": C.c_size_t,
              "pccx_ae_encode_h2_workspace_bytes": C.c_size_t, "pccx_ae_decode_h2_workspace_floats": C.c_size_t,
              "pccx_patch_knn16_bytes": C.c_size_t, "pccx_ae_encode_b3_workspace_bytes": C.c_size_t, "pccx_ae_encoder_blob_floats": C.c_size_t, "pccx_ae_decoder_blob_floats": C.c_size_t,
              "pccx_prob_blob_floats": C.c_size_t, "pccx_ae_decode_workspace_floats": C.c_size_t,

@@ -14,11 +14,61 @@ reference's permutes disappear; torch only concatenates and reshapes buffers.
 These families are correctness-first (layer by layer through HBM); the fused, tuned path is the
 IPDAE codec in models.py / codec.py.
 """
+import math
+
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _lib, ops
 from .ops import _stream, stage
+
+
+# ---- f16x2 scales (csrc/planes.hip, "the same layers in the f16x2 arithmetic"; the rules of csrc/pack_h2.hip) -------------------------
+def _pow2_floor(x):
+    m, e = math.frexp(x)                                    # x = m 2^e, m in [0.5, 1)
+    return math.ldexp(1.0, e - 1)
+
+
+def h2_act_scale(bound):
+    """the power of two sigma with bound * sigma <= 2^15 (half of fp16's largest number)"""
+    return _pow2_floor(32768.0 / max(float(bound), 2.0 ** -40))
+
+
+def h2_w_scale(W):
+    """the largest power of two tau with max|W| tau <= 2^14: the lo piece of all but negligible weights stays a normal fp16 number"""
+    m = float(np.abs(W).max()) if W.size else 0.0
+    return _pow2_floor(16384.0 / m) if m > 0 else 1.0
+
+
+def ibp_layer(W, b, lo, hi, relu):
+    """Interval bounds of act(W x + b s) over x in [lo, hi] (per channel) and s in (0, 1] (the stack's dynamic normalisation multiplies
+    the biases by a power of two s <= 1), in float64, inflated by 1e-3 for the fp32 evaluation of the kernels."""
+    Wp, Wn = np.maximum(W, 0.0), np.minimum(W, 0.0)
+    nhi = Wp @ hi + Wn @ lo + np.maximum(b, 0.0)
+    nlo = Wp @ lo + Wn @ hi + np.minimum(b, 0.0)
+    nhi, nlo = nhi + 1e-3 * np.abs(nhi) + 1e-30, nlo - 1e-3 * np.abs(nlo) - 1e-30
+    if relu:
+        nhi, nlo = np.maximum(nhi, 0.0), np.maximum(nlo, 0.0)
+    return nlo, nhi
+
+
+def h2_prepare_stack(stack, lo, hi):
+    """Give every layer of a Conv/Linear stack its f16x2 operands for inputs within [lo, hi] per channel (the stack's NORMALISED input:
+    magnitudes <= 1): sigma_l from the interval bound of the layer's input, tau_l from its weights, the two fp16 planes of tau W as
+    the GEMM's weight stream, the bias as sigma tau b.  Returns the bounds of the stack's output."""
+    lib = _lib.load()
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    for l in stack:
+        sig = h2_act_scale(max(float(np.abs(lo).max()), float(np.abs(hi).max())))
+        tau = h2_w_scale(l.W_host)
+        wp2 = torch.empty(lib.pccx_packed_linear_h2_floats(l.N, l.K), device=l.wp.device, dtype=torch.float32)
+        _lib.call("pccx_pack_linear_h2", l.wp.data_ptr(), l.N, l.K, float(tau), wp2.data_ptr(), _stream())
+        ws2 = torch.empty(lib.pccx_planes_gemm_weight_floats_h2(l.N, l.K), device=l.wp.device, dtype=torch.float32)
+        _lib.call("pccx_pack_planes_gemm_h2", wp2.data_ptr(), l.N, l.K, ws2.data_ptr(), _stream())
+        l.h2 = dict(sig=sig, tau=tau, ws=ws2, b=(l.b * float(sig * tau)).contiguous())
+        lo, hi = ibp_layer(l.W_host, l.b_host, lo, hi, l.relu)
+    return lo, hi
 
 
 class FoldedLinear:
@@ -35,6 +85,7 @@ class FoldedLinear:
             b = (b - bn.running_mean.detach().cpu()) * scale + bn.bias.detach().cpu()
         self.N, self.K, self.relu = W.shape[0], W.shape[1], int(bool(relu))
         W = W.contiguous()
+        self.W_host, self.b_host, self.h2 = W.numpy().astype(np.float64), b.numpy().astype(np.float64), None   # for the f16x2 bounds
         wp = torch.zeros(_lib.load().pccx_packed_linear_floats(self.N, self.K), dtype=torch.float32)
         _lib.call("pccx_pack_linear", W.data_ptr(), self.N, self.K, wp.data_ptr())
         self.wp, self.b = wp.to(device), b.contiguous().to(device)
@@ -43,7 +94,27 @@ class FoldedLinear:
     def mode(self):
         from . import DEFAULT_MATMUL
         m = self.matmul or DEFAULT_MATMUL
-        return "bf16x3" if m == "f16x2" else m              # f16x2 exists for the fused AE transforms only (pccx/__init__.py)
+        return "bf16x3" if m == "f16x2" else m              # a layer called by itself on fp32 rows has no f16x2 form: bf16x3
+
+    def planes_mode(self):
+        """the arithmetic of the layer as part of a planes stack: "f16x2" when asked for (the stacks of PPPF_AE.forward), else mode()"""
+        from . import DEFAULT_MATMUL
+        return self.matmul or DEFAULT_MATMUL
+
+    def planes_h2(self, pin, M, epilogue=0, group=0, sig_next=None, dyn=None, amax=None):
+        """planes() in the f16x2 arithmetic (h2_prepare_stack first): pin = f16x2 planes of sigma * input.  epilogue 0 -> f16x2 planes of
+        sig_next * output; 1 / 2 -> fp32 rows / group maxima, un-scaled (and times dyn[1]); amax: 8 floats the row epilogue folds the
+        largest |value| into."""
+        h = self.h2
+        scale = (float(sig_next) if epilogue == 0 else 1.0) / (h["sig"] * h["tau"])
+        if epilogue == 0:
+            out = torch.empty(_lib.load().pccx_planes_floats_h2(M, self.N), device=pin.device, dtype=torch.float32)
+        else:
+            out = torch.empty(M if epilogue == 1 else M // group, self.N, device=pin.device, dtype=torch.float32)
+        _lib.call("pccx_planes_gemm_h2", pin.data_ptr(), M, self.K, h["ws"].data_ptr(), h["b"].data_ptr(), self.N, self.relu, epilogue, group,
+                  scale, dyn.data_ptr() if dyn is not None else None, amax.data_ptr() if amax is not None else None, out.data_ptr(), self.N,
+                  _stream())
+        return out
 
     def _planes3(self):
         if self.wp3 is None:
@@ -282,6 +353,23 @@ def rows_affine_planes(base, div, x, mod, w_small, relu, M):
     return out
 
 
+def rows_affine_planes_h2(base, div, x, mod, w_small, relu, M, rho, dyn):
+    """rows_affine_planes in the f16x2 arithmetic: the planes of (rho * dyn[0]) * act(base[r // div] + x[..] @ w_small.T)"""
+    x = x.contiguous()
+    Cc, Ks = int(base.shape[-1]), int(w_small.shape[1])
+    out = torch.empty(_lib.load().pccx_planes_floats_h2(M, Cc), device=base.device, dtype=torch.float32)
+    _lib.call("pccx_rows_affine_planes_h2", base.contiguous().data_ptr(), Cc, int(div), x.data_ptr(), int(x.shape[-1]), Ks, int(mod),
+              w_small.data_ptr(), int(bool(relu)), int(M), float(rho), dyn.data_ptr(), out.data_ptr(), _stream())
+    return out
+
+
+def run_stack_planes_h2(stack, pl, M, dyn, amax=None):
+    """A Conv/Linear stack on f16x2 planes -> fp32 rows (M, N_last), un-scaled; amax: where the rows' largest |value| is recorded"""
+    for i, layer in enumerate(stack[:-1]):
+        pl = layer.planes_h2(pl, M, 0, sig_next=stack[i + 1].h2["sig"], dyn=dyn)
+    return stack[-1].planes_h2(pl, M, 1, dyn=dyn, amax=amax)
+
+
 def gather_max(y, idx):
     """max over nsample of y[b, idx.clamp(min=0)] (pointnet_sa_module.py:27-28,91): y (B,N,C) rows, idx (B,M,ns) int64 -> (B,M,C)."""
     B, N, Cc = y.shape
@@ -357,20 +445,55 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
     # 4096 -> 128 rows per patch).  dedup=False keeps the literal grouped evaluation (tests compare the two bit for bit).
     dedup = True
 
-    def run(self, stack, xyz, feats):
-        """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C'))."""
+    def run(self, stack, xyz, feats, h2=None):
+        """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C')).
+        h2 = (dyn, amax_out): evaluate the stack in the f16x2 arithmetic (h2_prepare_stack has run): dyn = the level's dynamic input
+        normalisation {s, 1 / s} on the device, amax_out = 8 floats that receive the largest value of the stack's output."""
         B = xyz.shape[0]
         with stage("fps"):
             new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)               # :66-68 (start index 0)
         with stage("ball_query"):
             idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx       # :71 (-1 padded; gather clamps, :27)
         if self.dedup and B > 0 and stack[-1].N % 4 == 0:
-            return new_xyz, self._run_dedup(stack, xyz, feats, idx, B)
+            return new_xyz, self._run_dedup(stack, xyz, feats, idx, B, h2)
+        if h2 is not None:
+            raise _lib.PccxError("PointnetSAModule: the f16x2 stacks are built for the source-row evaluation (dedup=True)")
         return self._run_grouped(stack, xyz, feats, idx, new_xyz, B)
 
-    def _run_dedup(self, stack, xyz, feats, idx, B):
+    def _run_dedup_h2(self, stack, f2, x2, rows_n, C0, h2):
+        """the stack on the source rows in the f16x2 arithmetic: rows -> planes of sigma_0 s [features, xyz], then ONE chain kernel (sa1 /
+        sa2) or the layers one by one (sa3), the last with the row epilogue that un-scales and records the output's maximum"""
+        dyn, amax_out = h2
+        lib = _lib.load()
+        pl = torch.empty(lib.pccx_planes_floats_h2(rows_n, C0 + 3), device=x2.device, dtype=torch.float32)
+        _lib.call("pccx_group_planes_h2", f2.data_ptr() if f2 is not None else None, C0, C0, x2.data_ptr(), 3, 3, None, rows_n, 1, 1,
+                  float(stack[0].h2["sig"]), dyn.data_ptr(), pl.data_ptr(), _stream())
+        ap = amax_out.data_ptr() if amax_out is not None else None
+        if chain4_fits(stack):
+            if getattr(self, "_chain2_of", None) is not stack:
+                h = [l.h2 for l in stack]
+                sc = np.array([h[0]["sig"]] + [h[i]["sig"] / (h[i - 1]["sig"] * h[i - 1]["tau"]) for i in (1, 2, 3)] +
+                              [1.0 / (h[3]["sig"] * h[3]["tau"])], dtype=np.float32)
+                self._chain2_of, self._chain2 = stack, (torch.cat([x["ws"] for x in h]), sc)
+            ws, sc = self._chain2
+            a = []
+            for l in stack:
+                a += [l.h2["b"].data_ptr(), l.N]
+            y = torch.empty(rows_n, stack[3].N, device=x2.device, dtype=torch.float32)
+            _lib.call("pccx_planes_chain4_h2", pl.data_ptr(), rows_n, stack[0].K, ws.data_ptr(), *a, 1, sc.ctypes.data, dyn.data_ptr(), ap,
+                      y.data_ptr(), stack[3].N, _stream())
+            return y
+        for i, layer in enumerate(stack[:-1]):
+            pl = layer.planes_h2(pl, rows_n, 0, sig_next=stack[i + 1].h2["sig"], dyn=dyn)
+        return stack[-1].planes_h2(pl, rows_n, 1, dyn=dyn, amax=amax_out)
+
+    def _run_dedup(self, stack, xyz, feats, idx, B, h2=None):
         with stage("sa_stack_%d" % stack[-1].N):
-            if stack[0].mode() == "bf16x3":
+            if h2 is not None:
+                f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
+                x2 = xyz.reshape(-1, 3).contiguous()
+                y = self._run_dedup_h2(stack, f2, x2, x2.shape[0], int(f2.shape[1]) if f2 is not None else 0, h2)
+            elif stack[0].mode() == "bf16x3":
                 # :83 features first, xyz last, one row per SOURCE point -- split straight into the first layer's operand planes from the
                 # two tables (pccx_group_planes without indices): the concatenated rows (two torch copies per level in round 3) never exist
                 f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
@@ -458,6 +581,27 @@ class PPPF_AE(_Packable):
         self._packed["grid"] = torch.stack([gx, gy], dim=-1).reshape(-1, 2).to(device)            # :82-88
         return self
 
+    def _ensure_h2(self, device):
+        """The f16x2 operands of the five planes stacks (three set-abstraction levels, the two FoldingNet chains), once per pack.  Every
+        stack is bounded for a NORMALISED input -- features (post-ReLU maxima) in [0, 1], coordinates in [-1, 1] -- which forward()
+        establishes per call from the data (pccx_absmax / pccx_dyn_scale: a power of two s <= 1 per stack, biases times s, outputs
+        times 1 / s; Conv / ReLU stacks are positively homogeneous), so the interval bounds are rigorous whatever the input and restart
+        at every stack: they stay within a few layers' looseness of the values (the lo pieces keep their bits)."""
+        pk = self._packed
+        if "h2" in pk:
+            return pk["h2"]
+        c_prev = 0
+        for stack in pk["sa"]:
+            h2_prepare_stack(stack, np.concatenate([np.zeros(c_prev), -np.ones(3)]), np.ones(c_prev + 3))   # :83 features first, xyz last
+            c_prev = stack[-1].N
+        for name in ("mlp1", "mlp2"):
+            first, rest = pk[name][0], pk[name][1:]
+            h2_prepare_stack(rest, np.zeros(rest[0].K) if first.relu else -np.ones(rest[0].K), np.ones(rest[0].K))
+        wsum = lambda w: float(np.abs(w.detach().cpu().numpy().astype(np.float64)).sum(axis=1).max() * 1.001)
+        pk["h2"] = dict(amax=torch.zeros(6 * 8, device=device, dtype=torch.float32), dyn=torch.ones(5 * 2, device=device, dtype=torch.float32),
+                        wsum1=wsum(pk["mlp1_small"]), wsum2=wsum(pk["mlp2_small"]))
+        return pk["h2"]
+
     def forward(self, xyz):
         """xyz (B,N,3) on the GPU -> (recon (B,d*d,3), latent (B,dim), latent_quantized (B,d))."""
         if self._packed is None:
@@ -465,15 +609,53 @@ class PPPF_AE(_Packable):
         pk = self._packed
         B = xyz.shape[0]
         pts, feats = ops._f32c(xyz, "PPPF_AE"), None
-        for mod, stack in zip((self.encoder.sa1, self.encoder.sa2, self.encoder.sa3), pk["sa"]):
-            pts, feats = mod.run(stack, pts, feats)
+        pow2x4 = lambda n: n % 4 == 0 and n <= 1024 and (n // 4) & (n // 4 - 1) == 0     # widths pccx_rows_affine_small takes
+        h2 = None
+        if (B > 0 and pk["sa"][0][0].planes_mode() == "f16x2" and PointnetSAModule.dedup and self.split_fold
+                and all(st[-1].N % 4 == 0 for st in pk["sa"]) and pow2x4(pk["mlp1"][0].N) and pow2x4(pk["mlp2"][0].N)):
+            h2 = self._ensure_h2(pts.device)
+            am, dy = (lambda i: h2["amax"][8 * i:8 * i + 8]), (lambda i: h2["dyn"][2 * i:2 * i + 2])
+            scale_of = lambda m1, a1, m2, a2, add, comb, out: _lib.call(
+                "pccx_dyn_scale", m1.data_ptr(), float(a1), m2.data_ptr() if m2 is not None else None, float(a2), float(add), int(comb),
+                out.data_ptr(), _stream())
+            absmax = lambda t, slot: _lib.call("pccx_absmax", t.data_ptr(), t.numel(), slot.data_ptr(), _stream())
+            _lib.call("pccx_zero_bytes", h2["amax"].data_ptr(), h2["amax"].numel() * 4, _stream())
+            absmax(pts, am(0))                                                      # max |coordinate|: every level's centroids are a subset
+        for lvl, (mod, stack) in enumerate(zip((self.encoder.sa1, self.encoder.sa2, self.encoder.sa3), pk["sa"])):
+            if h2 is None:
+                pts, feats = mod.run(stack, pts, feats)
+                continue
+            # the level's input = [maxima of the previous level's output rows, coordinates]: s from the larger of the two bounds
+            if lvl == 0:
+                scale_of(am(0), 1.0, None, 0.0, 0.0, 1, dy(0))
+            else:
+                scale_of(am(lvl), 1.0, am(0), 1.0, 0.0, 1, dy(lvl))
+            pts, feats = mod.run(stack, pts, feats, h2=(dy(lvl), am(lvl + 1) if lvl < 2 else None))
         with stage("latent"):
             g = group_max(feats)                                                    # :44 max over the 32 points
             latent = sigmoid_spread(g, self.L)                                      # :136-137
             q = round_(pk["enc"](latent))                                           # :139-142
             lat_dec = pk["dec"](q)                                                  # :145
         P = self.decoder.num_points
-        pow2x4 = lambda n: n % 4 == 0 and n <= 1024 and (n // 4) & (n // 4 - 1) == 0     # widths pccx_rows_affine_small takes
+        if h2 is not None:
+            # the split folding form (below) in the f16x2 arithmetic.  A chain's input relu(base + point part) is bounded from the data:
+            # max |base| (+ the per-point update's largest row sum times max |point input|: the grid lies in [-1, 1], the coarse points'
+            # maximum comes out of the first chain's row epilogue)
+            with stage("fold_mlp1"):
+                base1 = pk["mlp1_lat"](lat_dec)
+                absmax(base1, am(3))
+                scale_of(am(3), 1.0, None, 0.0, h2["wsum1"], 0, dy(3))
+                st = pk["mlp1"][1:]
+                pl = rows_affine_planes_h2(base1, P, pk["grid"], P, pk["mlp1_small"], pk["mlp1"][0].relu, B * P, st[0].h2["sig"], dy(3))
+                x = run_stack_planes_h2(st, pl, B * P, dy(3), am(4))                                         # :104 coarse
+            with stage("fold_mlp2"):
+                base2 = pk["mlp2_lat"](lat_dec)
+                absmax(base2, am(5))
+                scale_of(am(5), 1.0, am(4), h2["wsum2"], 0.0, 0, dy(4))
+                st = pk["mlp2"][1:]
+                pl = rows_affine_planes_h2(base2, P, x, 0, pk["mlp2_small"], pk["mlp2"][0].relu, B * P, st[0].h2["sig"], dy(4))
+                x = run_stack_planes_h2(st, pl, B * P, dy(4))                                                # :107 fine
+            return x.view(B, P, 3), latent, q
         if self.split_fold and B > 0 and pow2x4(pk["mlp1"][0].N) and pow2x4(pk["mlp2"][0].N):
             # The folding inputs [grid | latent] and [coarse | latent] (:99-106) are never built: their 1024-wide latent part is the
             # same for the P points of a patch, so the first layer of each MLP is W_lat latent + bias once per PATCH (a Linear on B

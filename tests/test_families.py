@@ -100,6 +100,57 @@ def test_pppf_ae_gpu_matches_reference_fixture_and_oracle(fam, oracle_nets, matm
 
 
 @pytest.mark.gpu
+def test_pppf_ae_f16x2_stacks_match_the_fixture_the_oracle_and_bf16x3(fam, oracle_nets):
+    """The planes stacks of PPPF_AE.forward in the f16x2 arithmetic (csrc/planes.hip <2>: two fp16 pieces per operand, three products per
+    fp32 product, exact power-of-two scales from per-stack interval bounds and a dynamic input normalisation from the data): the SAME
+    bars as the bf16x3 / f32 runs of test_pppf_ae_gpu_matches_reference_fixture_and_oracle (reference fixture 2e-5 on the latent, symbols
+    equal except within 1e-3 of a rounding boundary, reconstruction 5e-5), agreement with the bf16x3 run at the level of an fp32
+    summation reorder, and inputs far outside the unit cube (x 64, x 1/64): the dynamic scale keeps every operand in fp16's range
+    (no inf / nan) and the results follow the oracle at the tolerance scaled with the data."""
+    import pccx
+    from pccx import families
+    m, _ = oracle_nets
+    g = families.PPPF_AE(512, 0, 16, 7)
+    g.load_state_dict(m.state_dict())
+    x = synth.pppf_input()
+    old = pccx.DEFAULT_MATMUL
+    try:
+        pccx.DEFAULT_MATMUL = "bf16x3"
+        rec_b, lat_b, q_b = g(torch.from_numpy(x).cuda())
+        pccx.DEFAULT_MATMUL = "f16x2"
+        rec, lat, q = g(torch.from_numpy(x).cuda())
+        assert "h2" in g._packed, "the f16x2 stacks did not run"
+        with torch.no_grad():
+            orec, olat, oq, oz = m(torch.from_numpy(x))
+        np.testing.assert_allclose(lat[:, ::16].cpu().numpy(), fam["pppf_latent_sample"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(lat.cpu().numpy(), olat.numpy(), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(lat.cpu().numpy(), lat_b.cpu().numpy(), atol=1e-5, rtol=0)
+        bad = q.cpu().numpy() != fam["pppf_q"]
+        assert _near_boundary(oz.numpy()[bad], 1e-3).all()
+        if not bad.any():
+            np.testing.assert_allclose(rec.cpu().numpy(), fam["pppf_recon"], atol=5e-5, rtol=1e-4)
+            np.testing.assert_allclose(rec.cpu().numpy(), rec_b.cpu().numpy(), atol=2e-5, rtol=1e-4)
+        # the dynamic normalisation read back: s <= 1 is a power of two with max|xyz| s <= 1, and 1 / s beside it
+        dyn = g._packed["h2"]["dyn"].cpu().numpy()
+        s0 = float(dyn[0])
+        assert s0 <= 1.0 and np.log2(s0) == np.round(np.log2(s0)) and float(np.abs(x).max()) * s0 <= 1.0 + 1e-6 and dyn[1] == 1.0 / s0
+        assert float(np.abs(x).max()) * s0 > 0.5 or s0 == 1.0
+        # ragged neighbourhoods and inputs outside the unit cube
+        rng = np.random.default_rng(2)
+        for mul, tol in ((1.6, 2e-5), (64.0, 2e-3), (1.0 / 64.0, 2e-5)):
+            xs = (rng.random((3, 512, 3)) * mul).astype(np.float32)
+            rec2, lat2, q2 = g(torch.from_numpy(xs).cuda())
+            assert torch.isfinite(rec2).all() and torch.isfinite(lat2).all()
+            with torch.no_grad():
+                orec2, olat2, oq2, oz2 = m(torch.from_numpy(xs))
+            np.testing.assert_allclose(lat2.cpu().numpy(), olat2.numpy(), atol=tol, rtol=0)
+            bad2 = q2.cpu().numpy() != oq2.numpy()
+            assert _near_boundary(oz2.numpy()[bad2], 1e-3 * max(mul, 1.0)).all()
+    finally:
+        pccx.DEFAULT_MATMUL = old
+
+
+@pytest.mark.gpu
 def test_pointnet_sa_module_on_source_rows_equals_the_grouped_evaluation_bit_for_bit(oracle_nets, matmul_mode):
     """PointnetSAModule gathers features and xyz un-centred (pointnet_sa_module.py:73-85), so each grouped row is a copy of a source
     row: families.PointnetSAModule evaluates its Conv-BN-ReLU stack on the N source rows and takes every group's maximum from that
