@@ -971,11 +971,12 @@ def run_pppf(args, rk):
             except Exception as e:
                 cpu = {"error": repr(e)}
         rf = None
-        # the arithmetic that RUNS: there is no f16x2 form of the PointNet++ / FoldingNet layers, the default mode takes their bf16x3 kernels
-        eff_matmul = "bf16x3" if args.matmul == "f16x2" else args.matmul
+        # the arithmetic that RUNS: the planes stacks (set abstraction, FoldingNet chains) take the flag's arithmetic -- f16x2 since round 5 --
+        # while the four small Linears on one row per patch (latent projections, the folding MLPs' per-patch parts) stay bf16x3
+        eff_matmul = args.matmul if ("h2" in (model._packed or {}) or args.matmul != "f16x2") else "bf16x3"
         if flop:
             ach = flop * B * S * args.steps / dt / 1e12
-            peak = F32_MATRIX_PEAK_TFLOPS if eff_matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / B3_PRODUCTS
+            peak = F32_MATRIX_PEAK_TFLOPS if eff_matmul == "f32" else BF16_DENSE_PEAK_TFLOPS / (H2_PRODUCTS if eff_matmul == "f16x2" else B3_PRODUCTS)
             rf = {"kernel": "PPPF_AE forward (all layers)", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                   "frac": ach / peak, "traffic": None, "flop_per_patch": flop, "arithmetic": eff_matmul,
                   "reference_flop_per_patch": flop_ref, "reference_counted_tflops": flop_ref * B * S * args.steps / dt / 1e12,

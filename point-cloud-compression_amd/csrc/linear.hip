@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void linear_b3_kernel(const float *__restri
         }
         acc[0][m] = b; acc[1][m] = b;
     }
-    for (int t = 0; t < KT32; ++t) {
+    auto kstep = [&](int t) {
         bf16x8 pl[2][3];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void linear_b3_kernel(const float *__restri
                 }
             }
         }
-    }
+    };
+    for (int t = 0; t < KT32; ++t) kstep(t);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int row = row0 + nt * 16 + n;
@@ -296,7 +297,10 @@ extern "C" int pccx_linear_b3(const float *x, int M, int K, int ldx, const float
                    N, ldx, ldo);
     const int KT32 = ((K + 15) / 16 + 1) / 2, MT = (N + 15) / 16;
     const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
-    const int mtb = pccx_linear_col_tiles(M, MT);          // as pccx_linear: fewer re-reads of x for wide layers
+    int mtb = pccx_linear_col_tiles(M, MT);                // as pccx_linear: fewer re-reads of x for wide layers
+    // a handful of row blocks (the per-patch Linears of PPPF_AE: 2048 rows) cannot fill 256 CUs four column tiles at a time: one tile per
+    // wave then (the rows are re-read per tile, from L2)
+    if (mtb == 4 && (long)((M + 127) / 128) * ((MT + 3) / 4) < 256 && MT > 1) mtb = 1;
     dim3 grid((M + 127) / 128, (MT + mtb - 1) / mtb);
     PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear_b3: N=%d too large", N);
     relu &= 1;
@@ -305,6 +309,7 @@ extern "C" int pccx_linear_b3(const float *x, int M, int K, int ldx, const float
                        KT32, MT, bias, N, relu, out, ldo)
     if (mtb == 16) { if (vec) PCCX_LINB3_LAUNCH(16, true); else PCCX_LINB3_LAUNCH(16, false); }
     else if (mtb == 8) { if (vec) PCCX_LINB3_LAUNCH(8, true); else PCCX_LINB3_LAUNCH(8, false); }
+    else if (mtb == 1) { if (vec) PCCX_LINB3_LAUNCH(1, true); else PCCX_LINB3_LAUNCH(1, false); }
     else { if (vec) PCCX_LINB3_LAUNCH(4, true); else PCCX_LINB3_LAUNCH(4, false); }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;

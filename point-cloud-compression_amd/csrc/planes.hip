@@ -63,7 +63,13 @@ __device__ __forceinline__ float pg_wave_max(float m)
 __device__ __forceinline__ void pg_amax_commit(float *amax, float m)          // m: the lane's largest |value|
 {
     m = pg_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned *)amax + (blockIdx.x & (PG_AMAX_REP - 1)), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) {
+        // the maximum settles after the first few waves: a plain (L2) read first, the atomic only when this wave would raise the word --
+        // 32 768 waves of a million-row stack otherwise queue 4096 deep on each of the eight words (measured +0.15 ms on a 0.3 ms stack)
+        unsigned *w = (unsigned *)amax + (blockIdx.x & (PG_AMAX_REP - 1));
+        const unsigned mine = __float_as_uint(m);
+        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(w, mine);
+    }
 }
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, float *__restrict__ amax)
 {
@@ -76,8 +82,8 @@ extern "C" int pccx_absmax(const float *x, int64_t n, float *amax8, void *stream
 {
     if (n == 0) return PCCX_OK;
     PCCX_CHECK_ARG(x && amax8 && n > 0, "pccx_absmax: bad arguments");
-    long long blocks = (n + 1023) / 1024;
-    if (blocks > 1024) blocks = 1024;
+    long long blocks = (n + 16383) / 16384;                 // >= 64 values per thread: few waves, few atomics (they start together and all see 0)
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, amax8);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
@@ -397,6 +403,56 @@ __device__ __forceinline__ uint4 pg_load_async(const uint4 *p)    // placed exac
     return v;
 }
 
+// The end of a layer-0 k loop: wait for every load still in flight -- the B loads of the last two (clamped, unused) k-steps among them --
+// with the three rotating register sets named as read-write operands of the wait.  The compiler does not know that an asm load's
+// result arrives later: on paths where a set's value is dead (a layer with one or two k-steps never reads the third set) it would
+// hand the registers to something else while the load is still in flight, and the data landing afterwards would overwrite that
+// something (found by tools/asm_load_lint.py on the f16x2 chain of sa1, one k-step: the next layer's operand planes were built in
+// those registers -- results changed from call to call).  Tied to the wait, the sets stay allocated until their loads have landed.
+typedef unsigned int pg_u32x4 __attribute__((ext_vector_type(4)));
+#define PG_R(x) __builtin_bit_cast(pg_u32x4, x)
+#define PG_SETS2(bs)                                                                                                                          \
+    "v"(PG_R(bs[0][0][0])), "v"(PG_R(bs[0][0][1])), "v"(PG_R(bs[0][1][0])), "v"(PG_R(bs[0][1][1])), "v"(PG_R(bs[1][0][0])),                     \
+        "v"(PG_R(bs[1][0][1])), "v"(PG_R(bs[1][1][0])), "v"(PG_R(bs[1][1][1])), "v"(PG_R(bs[2][0][0])), "v"(PG_R(bs[2][0][1])),                 \
+        "v"(PG_R(bs[2][1][0])), "v"(PG_R(bs[2][1][1]))
+#define PG_SETS3(bs)                                                                                                                          \
+    "v"(PG_R(bs[0][0][0])), "v"(PG_R(bs[0][0][1])), "v"(PG_R(bs[0][0][2])), "v"(PG_R(bs[0][1][0])), "v"(PG_R(bs[0][1][1])),                     \
+        "v"(PG_R(bs[0][1][2])), "v"(PG_R(bs[1][0][0])), "v"(PG_R(bs[1][0][1])), "v"(PG_R(bs[1][0][2])), "v"(PG_R(bs[1][1][0])),                 \
+        "v"(PG_R(bs[1][1][1])), "v"(PG_R(bs[1][1][2])), "v"(PG_R(bs[2][0][0])), "v"(PG_R(bs[2][0][1])), "v"(PG_R(bs[2][0][2])),                 \
+        "v"(PG_R(bs[2][1][0])), "v"(PG_R(bs[2][1][1])), "v"(PG_R(bs[2][1][2]))
+// inputs only (as native vectors: a HIP_vector_type is an aggregate the constraint cannot take): the statement READS the sets, so their
+// values (as the compiler sees them) must still sit in their registers here
+template <int NBV>
+__device__ __forceinline__ void pg_drain_loads(const uint4 (&bs)[3][2][NBV])
+{
+    if constexpr (NBV == 2) asm volatile("s_waitcnt vmcnt(0)" ::PG_SETS2(bs) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::PG_SETS3(bs) : "memory");
+}
+// A counted wait that covers the register set about to be CONSUMED: the set goes through the statement as read-write operands, so no
+// instruction that uses the loaded values can be scheduled above the wait (a "memory" clobber does not order register arithmetic: the
+// compiler hoisted a conversion of gathered rows above a bare s_waitcnt once the register allocation shifted), and the registers stay
+// allocated to the set until it.  Sets still in flight are untouched until their own wait (or the final drain) names them.
+template <int N, int NBV>
+__device__ __forceinline__ void pg_wait_set(uint4 (&b)[2][NBV])
+{
+    pg_u32x4 r00 = PG_R(b[0][0]), r01 = PG_R(b[0][1]), r10 = PG_R(b[1][0]), r11 = PG_R(b[1][1]);
+    if constexpr (NBV == 2) {
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r00), "+v"(r01), "+v"(r10), "+v"(r11) : "n"(N) : "memory");
+    } else {
+        pg_u32x4 r02 = PG_R(b[0][2]), r12 = PG_R(b[1][2]);
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r00), "+v"(r01), "+v"(r02), "+v"(r10), "+v"(r11), "+v"(r12) : "n"(N) : "memory");
+        b[0][2] = __builtin_bit_cast(uint4, r02);
+        b[1][2] = __builtin_bit_cast(uint4, r12);
+    }
+    b[0][0] = __builtin_bit_cast(uint4, r00);
+    b[0][1] = __builtin_bit_cast(uint4, r01);
+    b[1][0] = __builtin_bit_cast(uint4, r10);
+    b[1][1] = __builtin_bit_cast(uint4, r11);
+}
+#undef PG_SETS2
+#undef PG_SETS3
+#undef PG_R
+
 enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
 
 // P = 2 (f16x2): the accumulators are sigma_in tau (W y + b s); `bias` holds sigma_in tau b, rho_in = sigma_in scales gathered rows,
@@ -411,8 +467,15 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 {
     typedef PgArith<P> AR;
     typedef typename AR::vec avec;
-    constexpr int PG_CHUNK = 4 * P;                            // ring chunk: 4 m-tiles x P planes (1 KiB fragments)
-    constexpr int HALVES = MB / 4;                             // ring chunks per k-step
+    // ring chunk: MQC m-tiles x P planes (1 KiB fragments).  MQC = 8 for the wide f16x2 form (all eight m-tiles of a k-step in one chunk,
+    // one barrier per k-step instead of two, three-deep ring of 16 KiB chunks) was built and measured SLOWER: the sixteen A fragments in
+    // registers take the kernel from 158 to 188 VGPRs = from three to two workgroups per CU (sa3 stack 1.52 -> 1.90 ms, FoldingNet's
+    // 512-wide chain 1.50 -> 1.61 per 2048 patches; tools/experiments/r5/README.md)
+    constexpr int MQC = 4;
+    constexpr int PG_CHUNK = MQC * P;
+    constexpr int NBUF = MQC == 8 ? 3 : PG_NB;                 // ring depth
+    constexpr int DMA = PG_CHUNK / 4;                          // LDS-DMA loads per wave and chunk
+    constexpr int HALVES = MB / MQC;                           // ring chunks per k-step
     const float dyn_s = P == 2 ? pg_dyn(dyn, 0) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, n = lane & 15;
@@ -425,15 +488,15 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
     const int mb = (int)(s % MBS);
     if (blk >= nblk) return;                                  // whole workgroup, before any barrier
     const long long tile0 = blk * 8 + 2 * w;
-    __shared__ __attribute__((aligned(16))) f32x4 swt[PG_NB * PG_CHUNK * 64];
+    __shared__ __attribute__((aligned(16))) f32x4 swt[NBUF * PG_CHUNK * 64];
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int nch = HALVES * KT32;
-    const WStreamT<PG_CHUNK, PG_NB> ws{wstream + (size_t)mb * nch * PG_CHUNK * 256, swt, nch, lane, wu, false};
+    const WStreamT<PG_CHUNK, NBUF> ws{wstream + (size_t)mb * nch * PG_CHUNK * 256, swt, nch, lane, wu, false};
     // DMA of chunk c (a chunk past the end re-reads chunk 0 into a free buffer, so every boundary issues the same loads and
     // the counted waits below hold to the last k-step)
-    auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % PG_NB); };
+    auto dma = [&](int c) { ws.issue(c < nch ? c : 0, c % NBUF); };
 #pragma unroll
-    for (int c = 0; c < PG_NB - 1; ++c) dma(c);
+    for (int c = 0; c < NBUF - 1; ++c) dma(c);
 
     f32x4 acc[2][MB];
 #pragma unroll
@@ -448,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
     }
     const long long t0 = tile0 < ntiles ? tile0 : ntiles - 1, t1 = tile0 + 1 < ntiles ? tile0 + 1 : ntiles - 1;
     {
-        // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [P], B(t+2) [2 P];  boundary(2t+1): DMA(2t+4) [P]
-        //                                          HALVES = 1:  boundary(t):  DMA(t+3) [P],  B(t+2) [2 P]
+        // VMEM issue order per wave and k-step t:  HALVES = 2:  boundary(2t): DMA(2t+3) [DMA], B(t+2) [2 P];  boundary(2t+1): DMA(2t+4) [DMA]
+        //                                          HALVES = 1:  boundary(t):  DMA(t+NBUF-1) [DMA],  B(t+2) [2 P]
         // loads complete in order, so boundary(c) may leave in flight everything issued after the youngest load it needs.
         // GATHER: bin = fp32 source rows (n_src per batch, ldp = 32 * KT32 floats, zero padded); row r reads source row
         // (r / rows_per_batch) * n_src + max(idx[r], 0) and is split in registers at use (4 loads per k-step instead of 6).
@@ -475,17 +538,17 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                     dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
                                          : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * P + pl) * 64 + lane);
         };
-        auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
+        auto kstep = [&](int t, uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
             avec bc[2][P];
 #pragma unroll
             for (int half = 0; half < HALVES; ++half) {
                 const int c = HALVES * t + half;
                 if (half == 0) {
-                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (HALVES == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NBL) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NBL) : "memory");
+                    if (first) pg_wait_set<0, NBV>(braw);
+                    else if (HALVES == 2) pg_wait_set<2 * DMA + NBL, NBV>(braw);
+                    else pg_wait_set<DMA + NBL, NBV>(braw);
                     __syncthreads();
-                    dma(c + PG_NB - 1);
+                    dma(c + NBUF - 1);
                     load_b(bload, t + 2);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
@@ -496,14 +559,14 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                             for (int pl = 0; pl < P; ++pl) bc[nt][pl] = __builtin_bit_cast(avec, braw[nt][pl < NBV ? pl : 0]);
                     }
                 } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + 2 * NBL) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA + 2 * NBL) : "memory");
                     __syncthreads();
-                    dma(c + PG_NB - 1);
+                    dma(c + NBUF - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
-                avec a[4][P];
+                avec a[MQC][P];
 #pragma unroll
-                for (int mq = 0; mq < 4; ++mq)
+                for (int mq = 0; mq < MQC; ++mq)
 #pragma unroll
                     for (int pl = 0; pl < P; ++pl) a[mq][pl] = __builtin_bit_cast(avec, buf[(mq * P + pl) * 64]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -511,10 +574,10 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 #pragma unroll
                 for (int q = 0; q < AR::NQ; ++q)
 #pragma unroll
-                    for (int mq = 0; mq < 4; ++mq)
+                    for (int mq = 0; mq < MQC; ++mq)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc[nt][4 * half + mq] = AR::mfma(a[mq][AR::pa(q)], bc[nt][AR::pb(q)], acc[nt][4 * half + mq]);
+                            acc[nt][MQC * half + mq] = AR::mfma(a[mq][AR::pa(q)], bc[nt][AR::pb(q)], acc[nt][MQC * half + mq]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -528,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
             if (t + 1 < KT32) kstep(t + 1, bs[0], bs[2], false);
             if (t + 2 < KT32) kstep(t + 2, bs[1], bs[0], false);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads and DMAs
+        pg_drain_loads<NBV>(bs);                                          // the last (clamped, unused) B loads and DMAs
     }
 
     if constexpr (EPI == PG_EPI_PLANES) {
@@ -822,15 +885,15 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
                     dst[nt][pl] = GATHER ? pg_load_async(gsrc[nt] + 8 * tc + 4 * pl)
                                          : pg_load_async(bin + (((size_t)tc * ntiles + (nt ? t1 : t0)) * P + pl) * 64 + lane);
         };
-        auto kstep = [&](int t, const uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
+        auto kstep = [&](int t, uint4 (&braw)[2][NBV], uint4 (&bload)[2][NBV], bool first) {
             avec bc[2][P];
 #pragma unroll
             for (int half = 0; half < MQ0; ++half) {
                 const int c = MQ0 * t + half;
                 if (half == 0) {
-                    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (MQ0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + NBL) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NBL) : "memory");
+                    if (first) pg_wait_set<0, NBV>(braw);
+                    else if (MQ0 == 2) pg_wait_set<2 * P + NBL, NBV>(braw);
+                    else pg_wait_set<P + NBL, NBV>(braw);
                     __syncthreads();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
@@ -874,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
             if (t + 1 < KT0) kstep(t + 1, bs[0], bs[2], false);
             if (t + 2 < KT0) kstep(t + 2, bs[1], bs[0], false);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last (clamped, unused) B loads land before their
+        pg_drain_loads<NBV>(bs);                                          // the last (clamped, unused) B loads land before their
     }                                                                     // registers are reused; the ring's DMAs with them
     int c = MQ0 * KT0;
     // ---- layers 1, 2: registers to registers

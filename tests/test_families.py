@@ -134,7 +134,17 @@ def test_pppf_ae_f16x2_stacks_match_the_fixture_the_oracle_and_bf16x3(fam, oracl
         dyn = g._packed["h2"]["dyn"].cpu().numpy()
         s0 = float(dyn[0])
         assert s0 <= 1.0 and np.log2(s0) == np.round(np.log2(s0)) and float(np.abs(x).max()) * s0 <= 1.0 + 1e-6 and dyn[1] == 1.0 / s0
-        assert float(np.abs(x).max()) * s0 > 0.5 or s0 == 1.0
+        assert float(np.abs(x).max()) * s0 >= 0.5 or s0 == 1.0          # ... and no smaller than it has to be
+        # call-to-call reproducibility on RECYCLED memory (the first call runs on fresh, zero-filled pages): the kernels take their B
+        # operand through loads issued from inline assembly into rotating register sets; a register of a load still in flight handed to
+        # something else shows up as results that change from call to call (it did: csrc/planes.hip pg_drain_loads)
+        xc = torch.from_numpy(x).cuda()
+        first = [t.clone() for t in g(xc)]
+        for _ in range(5):
+            junk = torch.full((64 << 20,), float("nan"), device="cuda")          # dirty the allocator's free blocks
+            del junk
+            again = g(xc)
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(first, again))
         # ragged neighbourhoods and inputs outside the unit cube
         rng = np.random.default_rng(2)
         for mul, tol in ((1.6, 2e-5), (64.0, 2e-3), (1.0 / 64.0, 2e-5)):
