@@ -1,15 +1,15 @@
-# Profile collection on the GPU box: PROFILE_TAG=r4p bash tools/profile_round.sh   (outputs under gpurun_out/$PROFILE_TAG, copied to profiles/
+# Profile collection on the GPU box: PROFILE_TAG=r5p bash tools/profile_round.sh   (outputs under gpurun_out/$PROFILE_TAG, copied to profiles/
 # by tools/collect_profiles.py).  Kernel statistics and counters come from SEPARATE runs (gpurun refuses --pmc together with trace domains).
 set -o pipefail
-O=$GRAFT_REPO_ROOT/gpurun_out/${PROFILE_TAG:-r4p}; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/${PROFILE_TAG:-r5p}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 if [ -z "$PROFILE_SKIP_MAIN" ]; then
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2> $O/trace.err; echo "trace rc=$?"
+timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2> $O/trace.err; echo "trace rc=$?"
 fi
 if [ -z "$PROFILE_SKIP_PMC" ]; then
-B="python3 bench.py --steps 1 --warmup 1 --batch 256 --cpu-clouds 0"
+B="python3 bench.py --steps 1 --warmup 1 --batch 256 --cpu-clouds 0 --no-secondary --no-files"
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/sq --output-format csv -- $B > $O/sq.log 2>&1; echo "sq rc=$?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- $B > $O/fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- $B > $O/write.log 2>&1; echo "write rc=$?"
