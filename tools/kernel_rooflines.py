@@ -176,6 +176,31 @@ def main():
         row(f"planes_gemm {K_}->{N_} on {M3} rows" + (" + max over 128" if epi == 2 else ""), ms, "mfma", 2.0 * M3 * K_ * N_, "TFLOP/s",
             round(MFMA_B3_PEAK, 1), "sa3 of PPPF_AE.py:32-34; 6 B per activation in" + ("" if epi == 2 else " and out"))
         del pin
+    # ---- round 5: the layers of PPPF_AE.forward in the f16x2 arithmetic, on the rows it runs them on (the N source rows per patch: 128 for
+    # sa3 = 262144 rows, 256 grid points for FoldingNet = 524288 rows); operand planes built from random rows in [0, 1]
+    lib = families._lib.load()
+    dyn1 = torch.ones(2, device=dev)
+    for K_, N_, M_, epi, what in ((259, 256, PB * 128, 0, "sa3 layer 0"), (256, 256, PB * 128, 0, "sa3 layer 1"), (256, 512, PB * 128, 0, "sa3 layer 2"),
+                                  (512, 1024, PB * 128, 1, "sa3 layer 3 (fp32 rows out)"), (512, 512, PB * 256, 0, "FoldingNet mlp1 layer 1")):
+        lyr = stack((N_,), K_)[0]
+        families.h2_prepare_stack([lyr], np.zeros(K_), np.ones(K_))
+        src = torch.rand(M_, K_, device=dev)
+        pin = torch.empty(lib.pccx_planes_floats_h2(M_, K_), device=dev, dtype=torch.float32)
+        families._lib.call("pccx_group_planes_h2", src.data_ptr(), K_, K_, None, 0, 0, None, M_, 1, 1, float(lyr.h2["sig"]), None, pin.data_ptr(), st_)
+        del src
+        ms = timed(lambda: lyr.planes_h2(pin, M_, epi, 0, sig_next=lyr.h2["sig"], dyn=dyn1), args.iters)
+        row(f"planes_gemm f16x2 {K_}->{N_} on {M_} rows ({what})", ms, "mfma", 2.0 * M_ * K_ * N_, "TFLOP/s", round(MFMA_H2_PEAK, 1),
+            "csrc/planes.hip <2>: three fp16 MFMA products per fp32 product; 4 B per activation in" + (" and out" if epi == 0 else ", fp32 rows out"))
+        del pin
+    for name, k0, widths, nsrc in (("sa1 3-3-64-64-128", 3, (3, 64, 64, 128), 512), ("sa2 131-128-128-128-256", 131, (128, 128, 128, 256), 512)):
+        st = stack(widths, k0)
+        families.h2_prepare_stack(st, np.concatenate([np.zeros(k0 - 3), -np.ones(3)]), np.ones(k0))
+        mod = families.PointnetSAModule(nsrc, 0.2, 32, list(widths), True, k0 - 3)
+        f2 = torch.rand(PB * nsrc, k0 - 3, device=dev) if k0 > 3 else None
+        x2 = torch.rand(PB * nsrc, 3, device=dev)
+        ms = timed(lambda: mod._run_dedup_h2(st, f2, x2, PB * nsrc, k0 - 3, (dyn1, None)), args.iters)
+        row(f"rows -> planes + planes_chain4 f16x2 {name} on {PB * nsrc} source rows", ms, "mfma", 2.0 * PB * nsrc * sum(l.N * l.K for l in st), "TFLOP/s",
+            round(MFMA_H2_PEAK, 1), "the stack once per SOURCE row (PointnetSAModule.dedup), fp32 rows out; algorithmic flops of the unpadded layers")
     # ---- round 3: PointnetSAModule on source rows (families.PointnetSAModule.dedup): the group maxima and FoldingNet's per-point update
     for name, nsrc, Cc, npoint, ns in (("sa1", 512, 128, 512, 32), ("sa2", 512, 256, 128, 64), ("sa3", 128, 1024, 32, 128)):
         y = torch.randn(PB, nsrc, Cc, device=dev)
