@@ -112,15 +112,21 @@ def main():
     # 2. the captured step: two graphs around the all-reduce (warmup=0: the first replay starts from the same state)
     m2 = copy.deepcopy(base)
     opt2 = train.Adam(m2.parameters(), lr=1e-4)
-    gs = train.GraphedTrainStep(m2, opt2, x, starts, lam=1e-3, warmup=0, data_parallel=True)
+    # ... in the form bench.py runs at N > 1: selection tables of the next batch prefetched on a side stream (prefetch=True)
+    gs = train.GraphedTrainStep(m2, opt2, x, starts, lam=1e-3, warmup=0, data_parallel=True, prefetch=True)
     RECORD.clear()
-    gs(sync=False)
+    gs.prefetch(x, starts)
+    gs(sync=False, next_batch=(x, starts))
     torch.cuda.synchronize()
     res["graph_avg_err"], res["graph_input_spread"], res["graph_calls"] = check_records(world)
     res["graph_covered"] = sum(pre.numel() for pre, _ in RECORD) == sum(g.numel() for g in gs._dp_grads)
     res["graph_grads_equal_across_ranks"] = same_on_all_ranks(gs._dp_grads, world)
     res["graph_params_equal_across_ranks"] = same_on_all_ranks(list(m2.parameters()), world)
     res["two_graphs"] = gs.graph_opt is not None
+    gs(sync=False)                                           # the prefetched batch: a second replay pair around a second all-reduce
+    torch.cuda.synchronize()
+    res["second_step_params_equal_across_ranks"] = same_on_all_ranks(list(m2.parameters()), world)
+    res["second_step_finite"] = bool(all(torch.isfinite(p).all() for p in m2.parameters()))
     differ = world == 1 or (res["eager_input_spread"] > 1e-2 and res["graph_input_spread"] > 1e-2)
     if BACKEND == "nccl":                                    # the file-sharded workloads' two exchanges over RCCL as well (pccx/dist.py)
         from pccx import dist as pdist
@@ -131,7 +137,8 @@ def main():
     res["ok"] = bool(res["eager_avg_err"] <= 1e-5 and res["graph_avg_err"] <= 1e-5 and differ
                      and res["eager_covered"] and res["graph_covered"] and res["eager_grads_equal_across_ranks"]
                      and res["graph_grads_equal_across_ranks"] and res["eager_params_equal_across_ranks"]
-                     and res["graph_params_equal_across_ranks"] and res["side_stream"] and res["buckets_launched"] >= 2 and res["two_graphs"])
+                     and res["graph_params_equal_across_ranks"] and res["side_stream"] and res["buckets_launched"] >= 2 and res["two_graphs"]
+                     and res["second_step_params_equal_across_ranks"] and res["second_step_finite"])
     print(json.dumps(res), flush=True)
     print("stage: checks done", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
