@@ -102,10 +102,12 @@ def farthest_point_sample_batch(xyz, npoint, start_idx=None):
     B, N, _ = xyz.shape
     if start_idx is None:
         start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-    start = torch.as_tensor(start_idx).to(device=xyz.device, dtype=torch.int32).contiguous()
+    # start_idx == "zero": every cloud starts from its point 0 (pytorch3d's sample_farthest_points); the kernel takes a null table for
+    # that, so nothing is uploaded (a pageable upload blocks the calling thread behind everything queued on its stream)
+    start = None if isinstance(start_idx, str) and start_idx == "zero" else torch.as_tensor(start_idx).to(device=xyz.device, dtype=torch.int32).contiguous()
     out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
     work = torch.empty(B * N, device=xyz.device, dtype=torch.float32) if N > 16384 else None
-    _lib.call("pccx_fps", xyz.data_ptr(), B, N, int(npoint), start.data_ptr(), out.data_ptr(),
+    _lib.call("pccx_fps", xyz.data_ptr(), B, N, int(npoint), start.data_ptr() if start is not None else None, out.data_ptr(),
               work.data_ptr() if work is not None else None, _stream())
     return out
 
@@ -113,7 +115,7 @@ def farthest_point_sample_batch(xyz, npoint, start_idx=None):
 def sample_farthest_points(xyz, K):
     """pytorch3d.ops.sample_farthest_points as pointnet_sa_module.py:12 uses it: start index 0,
     returns (points, idx)."""
-    idx = farthest_point_sample_batch(xyz, K, start_idx=torch.zeros(xyz.shape[0], dtype=torch.int32))
+    idx = farthest_point_sample_batch(xyz, K, start_idx="zero")
     return index_points(xyz, idx), idx
 
 
