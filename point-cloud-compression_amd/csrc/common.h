@@ -7,6 +7,7 @@
 #include "../../include/pccx.h"
 
 #define PCCX_WAVE 64
+#define PCCX_SUM_REPLICAS 8       // replicas of a column-sum accumulator (train.hip: workgroup b adds into replica b % 8; the consumer adds them up)
 
 void pccx_set_error(const char *fmt, ...);
 

@@ -59,16 +59,35 @@ static int pccx_linear_col_tiles(int M, int MT)
 // BF16 = the autocast form (train_pppe_pcd_ae.py:193-217, torch.cuda.amp.autocast around the forward): both operands rounded to
 // bf16, products on the bf16 matrix cores (one v_mfma_f32_16x16x16_bf16 per k-tile: its lane map -- four consecutive k per
 // lane -- is exactly the f32 fragment's), fp32 accumulate, result rounded to bf16 (the layer's output dtype under autocast).
-template <int MTB, bool VEC, bool BF16>
+// sum over the 16 lanes of a DPP row (the n index of a C/D tile), a fixed order; every lane ends with the sum
+__device__ __forceinline__ float row16_sum(float v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true);   // row_mirror
+    v = v + __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v = v + __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x1B, 0xf, 0xf, true);    // quad_perm [3,2,1,0]
+    v = v + __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v = v + __int_as_float(t);
+    return v;
+}
+
+// MOM (the training step's Conv -> BatchNorm pairs, pppe_pcd_ae.py:556-568): the epilogue also accumulates the column moments sum z
+// and sum z^2 of what it stores -- fp32 over the workgroup's 128 rows, then one double atomic per column and sum into replica
+// blockIdx.x % nrep of `sums` ([nrep][2][N] doubles, cleared by the caller) -- so the BatchNorm that follows needs no pass of its own over
+// the activation (col_reduce4_kernel<0>: one launch per layer, 13 per step).
+template <int MTB, bool VEC, bool BF16, bool MOM = false>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict__ x, int M, int K, int ldx,
                                                      const f32x4 *__restrict__ wp, int KT, int MT,
                                                      const float *__restrict__ bias, int N, int relu,
-                                                     float *__restrict__ out, int ldo)
+                                                     float *__restrict__ out, int ldo, double *__restrict__ sums = nullptr, int nrep = 1)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int row0 = (blockIdx.x * 4 + w) * 32;
-    if (row0 >= M) return;                                        // whole wave
+    if (!MOM && row0 >= M) return;                                // whole wave (MOM: every wave reaches the barrier below; rows are clamped)
     const int mt0 = blockIdx.y * MTB;
     f32x4 acc[2][MTB];
 #pragma unroll
@@ -116,13 +135,14 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict_
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int row = row0 + nt * 16 + n;
-        if (row >= M) continue;
 #pragma unroll
         for (int m = 0; m < MTB; ++m) {
             const int c = 16 * (mt0 + m) + 4 * g;
             f32x4 v = acc[nt][m];
             if (BF16) v = round_bf16x4(v);
             if (relu) v = relu4(v);
+            if (MOM) acc[nt][m] = row < M ? v : f32x4{0.f, 0.f, 0.f, 0.f};      // what is stored, for the moments below
+            if (row >= M) continue;
             float *po = out + (size_t)row * ldo + c;
             if (VEC && c + 3 < N) {
                 *(f32x4 *)po = v;
@@ -133,6 +153,54 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict_
             }
         }
     }
+    if constexpr (MOM) {
+        __shared__ float smom[4][2][MTB * 16];
+#pragma unroll
+        for (int m = 0; m < MTB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = acc[0][m][r], b = acc[1][m][r];
+                const float s1 = row16_sum(a + b), s2 = row16_sum(a * a + b * b);
+                if (n == 0) {
+                    smom[w][0][16 * m + 4 * g + r] = s1;
+                    smom[w][1][16 * m + 4 * g + r] = s2;
+                }
+            }
+        __syncthreads();
+        double *dst = sums + (size_t)(blockIdx.x % nrep) * 2 * N;
+        for (int e = threadIdx.x; e < 2 * MTB * 16; e += 256) {
+            const int which = e / (MTB * 16), cl = e % (MTB * 16), col = 16 * mt0 + cl;
+            const float t = (smom[0][which][cl] + smom[1][which][cl]) + (smom[2][which][cl] + smom[3][which][cl]);
+            if (col < N) atomicAdd(&dst[(size_t)which * N + col], (double)t);
+        }
+    }
+}
+
+// pccx_linear (no bias, no ReLU; flags bit 1 = autocast) whose epilogue accumulates the output's column moments into `sums`
+// (pccx_train_sums_doubles(N) doubles: PCCX_SUM_REPLICAS x [sum z (N) | sum z^2 (N)]); flags bit 2 (4): `sums` was cleared by the caller.
+extern "C" int pccx_linear_moments(const float *x, int M, int K, int ldx, const float *wp, int N, int flags, float *out, int ldo,
+                                   double *sums, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(x && wp && out && sums, "pccx_linear_moments: null pointer");
+    PCCX_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && ldx >= K && ldo >= N, "pccx_linear_moments: bad shape M=%d K=%d N=%d ldx=%d ldo=%d", M, K, N, ldx, ldo);
+    const int KT = (K + 15) / 16, MT = (N + 15) / 16;
+    const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const bool bf16 = (flags & 2) != 0;
+    dim3 grid((M + 127) / 128, (MT + 3) / 4);
+    PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear_moments: N=%d too large", N);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & 4)) PCCX_CHECK_HIP(pccx_zero_async(sums, sizeof(double) * PCCX_SUM_REPLICAS * 2 * (size_t)N, st));
+#define PCCX_LINM_LAUNCH(V, B)                                                                                                   \
+    hipLaunchKernelGGL((linear_kernel<4, V, B, true>), grid, dim3(256), 0, st, x, M, K, ldx, (const f32x4 *)wp, KT, MT, (const float *)nullptr, N, \
+                       0, out, ldo, sums, PCCX_SUM_REPLICAS)
+    if (vec && bf16) PCCX_LINM_LAUNCH(true, true);
+    else if (vec) PCCX_LINM_LAUNCH(true, false);
+    else if (bf16) PCCX_LINM_LAUNCH(false, true);
+    else PCCX_LINM_LAUNCH(false, false);
+#undef PCCX_LINM_LAUNCH
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
 }
 
 extern "C" int pccx_linear(const float *x, int M, int K, int ldx, const float *wp, const float *bias, int N, int relu,

@@ -429,7 +429,6 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(const float *__restric
 }
 
 // prezeroed: the caller cleared o0 / o1 already (train.py's step arena: ONE clear per training step instead of one per reduction)
-#define PCCX_SUM_REPLICAS 8
 static int launch_col_reduce(int mode, const float *A, const float *Y, const float *Z, const float *mean, const float *rstd,
                              int64_t M, int C, double *o0, double *o1, hipStream_t st, bool prezeroed = false, int nrep = 1)
 {
@@ -639,8 +638,10 @@ extern "C" int pccx_bn_relu_train_forward(const float *Z, int64_t M, int C, floa
     if (M == 0) return PCCX_OK;
     PCCX_CHECK_ARG(Z && sums && gamma && beta && mean && rstd && Y && C >= 1 && C <= 4096, "pccx_bn_relu_train_forward: bad arguments (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_col_reduce(0, Z, nullptr, nullptr, nullptr, nullptr, M, C, sums, sums + C, st, (flags & 4) != 0, PCCX_SUM_REPLICAS);
-    if (rc) return rc;
+    if (!(flags & 8)) {                                    // flags & 8: `sums` already holds the moments (pccx_linear_moments produced Z)
+        int rc = launch_col_reduce(0, Z, nullptr, nullptr, nullptr, nullptr, M, C, sums, sums + C, st, (flags & 4) != 0, PCCX_SUM_REPLICAS);
+        if (rc) return rc;
+    }
     long blocks = ((long)M * C + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_relu_fwd_fused_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 2 * C, st, Z, (long)M * C, C, (long)M, sums,

@@ -113,11 +113,17 @@ def _linear_raw(x, wp, bias, N, K, flags=0):
     return out
 
 
+_MOMENTS = {}              # address of a LinearFn output produced WITH its column moments -> (shape, sums); consumed by the BnReluFn that
+                           # takes that tensor next, emptied at the start of every forward
+_FOLD_MOMENTS = os.environ.get("PCCX_NO_MOMENT_FOLD") != "1"      # experiment knob: 0 = every BatchNorm reduces its input itself
+
+
 class LinearFn(torch.autograd.Function):
-    """z = x W^T (+ b): nn.Linear / 1x1 Conv on channels-last rows."""
+    """z = x W^T (+ b): nn.Linear / 1x1 Conv on channels-last rows.  want_moments (a Conv that feeds a train-mode BatchNorm): the GEMM's
+    epilogue also accumulates the output's column moments (pccx_linear_moments) and BnReluFn takes them instead of reducing z again."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, want_moments=False):
         x = x.contiguous()
         W2 = W.reshape(W.shape[0], -1).contiguous()
         ctx.save_for_backward(x, W2)
@@ -133,6 +139,13 @@ class LinearFn(torch.autograd.Function):
             out = torch.empty(x.shape[0], N, device=x.device, dtype=torch.float32)
             _lib.call("pccx_linear_skinny", x.data_ptr(), x.shape[0], K, ldx, W2.data_ptr(), b.data_ptr() if b is not None else None,
                       N, ctx.flags, out.data_ptr(), N, _stream())
+            return out
+        if want_moments and b is None and _FOLD_MOMENTS and x.is_cuda:
+            sums, pre = _sums(N, x.device)
+            out = torch.empty(x.shape[0], N, device=x.device, dtype=torch.float32)
+            _lib.call("pccx_linear_moments", x.data_ptr(), x.shape[0], K, x.stride(0), _packed(W2, False).data_ptr(), N, ctx.flags | pre,
+                      out.data_ptr(), N, sums.data_ptr(), _stream())
+            _MOMENTS[out.data_ptr()] = (tuple(out.shape), sums)
             return out
         return _linear_raw(x, _packed(W2, False), b, N, K, ctx.flags)
 
@@ -157,7 +170,7 @@ class LinearFn(torch.autograd.Function):
             db = torch.empty(N, device=dz.device, dtype=torch.float32)                                             # written, not accumulated
             sums, pre = _sums(N, dz.device)
             _lib.call("pccx_col_sum_w", dz.data_ptr(), M, N, sums.data_ptr(), db.data_ptr(), pre, _stream())
-        return dx, dW.view(ctx.wshape), db
+        return dx, dW.view(ctx.wshape), db, None
 
 
 class BnReluFn(torch.autograd.Function):
@@ -170,7 +183,11 @@ class BnReluFn(torch.autograd.Function):
         mean = torch.empty(Cc, device=z.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         y = torch.empty_like(z)
-        sums, pre = _sums(Cc, z.device)
+        mom = _MOMENTS.pop(z.data_ptr(), None)
+        if mom is not None and mom[0] == tuple(z.shape):
+            sums, pre = mom[1], 4 | 8                # the producing GEMM's epilogue accumulated the moments: no reduction pass here
+        else:
+            sums, pre = _sums(Cc, z.device)
         # moments, then ONE kernel that finalises them (mean, rstd, running statistics) and applies the layer (csrc/train.hip)
         _lib.call("pccx_bn_relu_train_forward", z.data_ptr(), M, Cc, float(bn.eps), float(bn.momentum), sums.data_ptr(), gamma.data_ptr(),
                   beta.data_ptr(), 1, mean.data_ptr(), rstd.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), y.data_ptr(),
@@ -339,7 +356,7 @@ def _sa_train(mod, table, feats):
         grouped = torch.cat([grouped, GatherFn.apply(feats, idx)], dim=-1)
     x = grouped.reshape(-1, grouped.shape[-1])
     for layer in mod.mlp_stack:                                             # conv (no bias) -> BN -> ReLU
-        x = BnReluFn.apply(LinearFn.apply(x, layer[0].weight, None), layer[1].weight, layer[1].bias, layer[1])
+        x = BnReluFn.apply(LinearFn.apply(x, layer[0].weight, None, True), layer[1].weight, layer[1].bias, layer[1])
     return new_xyz, GroupMaxFn.apply(x.view(B * S, mod.K, -1)).view(B, S, -1)
 
 
@@ -352,6 +369,7 @@ def forward_train(model, x, starts, tables=None):
     B = x.shape[0]
     sa = enc.sa_modules
     outs, new_xyz = [], None
+    _MOMENTS.clear()
     _BN_COUNTED = _advance_bn_counters(model, x.device)    # every BatchNorm's num_batches_tracked += 1, one launch
     try:
         with ops.stage("selection"):

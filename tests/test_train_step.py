@@ -319,6 +319,45 @@ def test_autocast_training_step_stays_close_to_the_fp32_step():
 
 
 @pytest.mark.gpu
+def test_linear_with_moments_feeds_batchnorm_the_sums_it_would_have_reduced():
+    """pccx_linear_moments (the Conv of a Conv -> BatchNorm pair with the column moments accumulated in its epilogue) against pccx_linear
+    followed by the BatchNorm's own reduction: identical rows (same kernel body), moments equal to the double-precision sums of those rows
+    to 2e-5 of (|sum| + 1e-3 M) (fp32 partial sums over a workgroup's 128 rows -- at worst 128 roundings of 6e-8 -- then doubles; the
+    reduction they replace adds every element as a double), and BnReluFn's outputs / saved statistics equal to the unfused
+    pair's to 1e-6 -- in fp32 and in the autocast form, on shapes with ragged rows and channel counts."""
+    from pccx import _lib, train
+    from pccx.ops import _stream
+    rng = np.random.default_rng(4)
+    for M, K, N, flags in ((1000, 35, 64, 0), (4096, 259, 256, 2), (131, 3, 32, 0), (65536, 64, 128, 2)):
+        x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+        W = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).cuda()
+        wp = train._packed(W, False)
+        ref = train._linear_raw(x, wp, None, N, K, flags)
+        out = torch.empty(M, N, device="cuda")
+        sums = torch.full((_lib.load().pccx_train_sums_doubles(N),), 7.0, device="cuda", dtype=torch.float64)       # not cleared: the entry point clears
+        _lib.call("pccx_linear_moments", x.data_ptr(), M, K, x.stride(0), wp.data_ptr(), N, flags, out.data_ptr(), N, sums.data_ptr(), _stream())
+        assert torch.equal(out, ref)
+        got = sums.view(8, 2, N).sum(dim=0)
+        want = torch.stack([ref.double().sum(dim=0), (ref.double() ** 2).sum(dim=0)])
+        assert float(((got - want).abs() / (want.abs() + 1e-3 * M)).max()) <= 2e-5, (M, K, N)
+    # through the autograd functions: the folded pair against the unfused pair (experiment knob off / on)
+    bn_a, bn_b = torch.nn.BatchNorm2d(128).cuda(), torch.nn.BatchNorm2d(128).cuda()
+    x = torch.from_numpy(rng.standard_normal((8192, 64)).astype(np.float32)).cuda()
+    W = torch.from_numpy((rng.standard_normal((128, 64, 1, 1)) / 8).astype(np.float32)).cuda().requires_grad_(True)
+    ya = train.BnReluFn.apply(train.LinearFn.apply(x, W, None, True), bn_a.weight, bn_a.bias, bn_a)
+    assert not train._MOMENTS, "the BatchNorm did not take the GEMM's moments"
+    old = train._FOLD_MOMENTS
+    try:
+        train._FOLD_MOMENTS = False
+        yb = train.BnReluFn.apply(train.LinearFn.apply(x, W, None, True), bn_b.weight, bn_b.bias, bn_b)
+    finally:
+        train._FOLD_MOMENTS = old
+    assert float((ya - yb).abs().max()) <= 1e-5 and float((bn_a.running_var - bn_b.running_var).abs().max()) <= 1e-6
+    (ga,) = torch.autograd.grad(ya.sum(), W, retain_graph=False)
+    assert torch.isfinite(ga).all()
+
+
+@pytest.mark.gpu
 def test_graphed_training_step_replays_the_eager_step():
     """train.GraphedTrainStep (the iteration captured once as a hipGraph; Adam's lr / bias corrections, the batch, the FPS starts
     and lambda read from device memory) against the eager train_step from the SAME state: the first replay is iteration 1 of
