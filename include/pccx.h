@@ -542,7 +542,7 @@ PCCX_API int pccx_col_sum(const float *dY, int64_t M, int C, double *sums, float
 /* The training step's forms of the four entry points above (train_pppe_pcd_ae.py:184-226; round 4): the same arithmetic in fewer launches.
  * flags bit 2 (value 4): the accumulation target (`sums`, dF, gX / gY) was CLEARED BY THE CALLER -- pccx/train.py clears one arena per
  * step with pccx_zero_bytes instead of one launch per reduction; pccx_bn_relu_train_forward flags bit 3 (value 8): `sums` already HOLDS the
- * column moments of Z (pccx_linear_moments produced Z), no reduction is launched.  pccx_bn_relu_train_forward = pccx_bn_train_stats + pccx_bn_relu_forward
+ * column moments of Z (pccx_linear_moments produced Z), no reduction is launched; likewise pccx_bn_relu_train_backward after pccx_linear_bnback.  pccx_bn_relu_train_forward = pccx_bn_train_stats + pccx_bn_relu_forward
  * (moments, then one kernel that finalises them and applies the layer; mean / rstd / running stats / Y bit-identical);
  * pccx_bn_relu_train_backward = pccx_bn_relu_backward with g_gamma / g_beta WRITTEN (not accumulated); pccx_col_sum_w writes g_bias. */
 PCCX_API int pccx_bn_relu_train_forward(const float *Z, int64_t M, int C, float eps, float momentum, double *sums, const float *gamma,
@@ -562,6 +562,11 @@ PCCX_API size_t pccx_train_sums_doubles(int C);
  * (bf16 operands and result; the moments are those of the rounded result), bit 2 (4) = `sums` was cleared by the caller. */
 PCCX_API int pccx_linear_moments(const float *x, int M, int K, int ldx, const float *wp, int N, int flags, float *out, int ldo,
                                  double *sums, void *stream);
+/* The dX GEMM behind such a pair in the backward pass: out = x . W^T is the BatchNorm's dY, and the epilogue accumulates the two column
+ * sums its backward needs (sum d xhat | sum d, d = (Y > 0 ? dY : 0), xhat = (Z - mean) rstd) from the rows it has just produced;
+ * pccx_bn_relu_train_backward with flags bit 3 (8) takes `sums` as filled.  Y, Z: the BatchNorm's output and input rows (M, ldo). */
+PCCX_API int pccx_linear_bnback(const float *x, int M, int K, int ldx, const float *wp, int N, int flags, float *out, int ldo,
+                                const float *Y, const float *Z, const float *mean, const float *rstd, double *sums, void *stream);
 /* clear `bytes` (a multiple of 4) with a kernel (as a hipGraph node it is ordered like every other kernel: DESIGN.md section 7) */
 PCCX_API int pccx_zero_bytes(void *p, size_t bytes, void *stream);
 /* dst[0 .. bytes) = src[0 .. bytes) by a kernel (both 16-byte aligned, bytes % 16 == 0): how a training loop hands the next batch and its

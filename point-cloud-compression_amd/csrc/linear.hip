@@ -78,16 +78,23 @@ __device__ __forceinline__ float row16_sum(float v)
 // and sum z^2 of what it stores -- fp32 over the workgroup's 128 rows, then one double atomic per column and sum into replica
 // blockIdx.x % nrep of `sums` ([nrep][2][N] doubles, cleared by the caller) -- so the BatchNorm that follows needs no pass of its own over
 // the activation (col_reduce4_kernel<0>: one launch per layer, 13 per step).
-template <int MTB, bool VEC, bool BF16, bool MOM = false>
+// MOM = 2 (the backward of the same pairs: this GEMM is the dX of the layer BEHIND a BatchNorm-ReLU, its output is that BatchNorm's dY):
+// the epilogue accumulates sum d xhat and sum d with d = (Y > 0 ? dY : 0), xhat = (Z - mean) rstd -- the two sums of
+// col_reduce4_kernel<1> -- reading Y and Z of the rows it has just produced.
+struct LinBn {
+    const float *Y, *Z, *mean, *rstd;                            // (M, N) rows of the BatchNorm's output and input, (N) statistics
+};
+template <int MTB, bool VEC, bool BF16, int MOM = 0>
 __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict__ x, int M, int K, int ldx,
                                                      const f32x4 *__restrict__ wp, int KT, int MT,
                                                      const float *__restrict__ bias, int N, int relu,
-                                                     float *__restrict__ out, int ldo, double *__restrict__ sums = nullptr, int nrep = 1)
+                                                     float *__restrict__ out, int ldo, double *__restrict__ sums = nullptr, int nrep = 1,
+                                                     LinBn bn = LinBn{nullptr, nullptr, nullptr, nullptr})
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int row0 = (blockIdx.x * 4 + w) * 32;
-    if (!MOM && row0 >= M) return;                                // whole wave (MOM: every wave reaches the barrier below; rows are clamped)
+    if (MOM == 0 && row0 >= M) return;                            // whole wave (MOM: every wave reaches the barrier below; rows are clamped)
     const int mt0 = blockIdx.y * MTB;
     f32x4 acc[2][MTB];
 #pragma unroll
@@ -132,6 +139,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict_
             }
         }
     }
+    f32x4 dsum[MOM == 2 ? 2 : 1][MOM == 2 ? MTB : 1];
+    (void)dsum;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int row = row0 + nt * 16 + n;
@@ -141,7 +150,34 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict_
             f32x4 v = acc[nt][m];
             if (BF16) v = round_bf16x4(v);
             if (relu) v = relu4(v);
-            if (MOM) acc[nt][m] = row < M ? v : f32x4{0.f, 0.f, 0.f, 0.f};      // what is stored, for the moments below
+            if (MOM == 1) acc[nt][m] = row < M ? v : f32x4{0.f, 0.f, 0.f, 0.f};  // what is stored, for the moments below
+            if (MOM == 2) {
+                // d = relu'(y) dY and d xhat in place of the accumulators (acc[nt][m] <- d xhat; the d's go to a second array)
+                f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dx_ = {0.f, 0.f, 0.f, 0.f};
+                if (row < M) {
+                    const size_t e = (size_t)row * ldo + c;
+                    if (VEC && c + 3 < N) {
+                        const f32x4 y4 = *(const f32x4 *)(bn.Y + e), z4 = *(const f32x4 *)(bn.Z + e);
+                        const f32x4 mu = *(const f32x4 *)(bn.mean + c), rs = *(const f32x4 *)(bn.rstd + c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = y4[r] > 0.f ? v[r] : 0.f;
+                            dd[r] = d;
+                            dx_[r] = d * ((z4[r] - mu[r]) * rs[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c + r < N) {
+                                const float d = bn.Y[e + r] > 0.f ? v[r] : 0.f;
+                                dd[r] = d;
+                                dx_[r] = d * ((bn.Z[e + r] - bn.mean[c + r]) * bn.rstd[c + r]);
+                            }
+                    }
+                }
+                acc[nt][m] = dx_;
+                dsum[nt][m] = dd;
+            }
             if (row >= M) continue;
             float *po = out + (size_t)row * ldo + c;
             if (VEC && c + 3 < N) {
@@ -153,14 +189,14 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const float *__restrict_
             }
         }
     }
-    if constexpr (MOM) {
+    if constexpr (MOM != 0) {
         __shared__ float smom[4][2][MTB * 16];
 #pragma unroll
         for (int m = 0; m < MTB; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = acc[0][m][r], b = acc[1][m][r];
-                const float s1 = row16_sum(a + b), s2 = row16_sum(a * a + b * b);
+                const float s1 = row16_sum(a + b), s2 = MOM == 1 ? row16_sum(a * a + b * b) : row16_sum(dsum[0][m][r] + dsum[1][m][r]);
                 if (n == 0) {
                     smom[w][0][16 * m + 4 * g + r] = s1;
                     smom[w][1][16 * m + 4 * g + r] = s2;
@@ -192,13 +228,42 @@ extern "C" int pccx_linear_moments(const float *x, int M, int K, int ldx, const 
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & 4)) PCCX_CHECK_HIP(pccx_zero_async(sums, sizeof(double) * PCCX_SUM_REPLICAS * 2 * (size_t)N, st));
 #define PCCX_LINM_LAUNCH(V, B)                                                                                                   \
-    hipLaunchKernelGGL((linear_kernel<4, V, B, true>), grid, dim3(256), 0, st, x, M, K, ldx, (const f32x4 *)wp, KT, MT, (const float *)nullptr, N, \
+    hipLaunchKernelGGL((linear_kernel<4, V, B, 1>), grid, dim3(256), 0, st, x, M, K, ldx, (const f32x4 *)wp, KT, MT, (const float *)nullptr, N, \
                        0, out, ldo, sums, PCCX_SUM_REPLICAS)
     if (vec && bf16) PCCX_LINM_LAUNCH(true, true);
     else if (vec) PCCX_LINM_LAUNCH(true, false);
     else if (bf16) PCCX_LINM_LAUNCH(false, true);
     else PCCX_LINM_LAUNCH(false, false);
 #undef PCCX_LINM_LAUNCH
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
+}
+
+// pccx_linear as the dX GEMM behind a train-mode BatchNorm-ReLU: out = x . W^T (no bias; flags as pccx_linear_moments) is that
+// BatchNorm's dY, and the epilogue accumulates its two column sums -- sum d xhat into sums[r][0][N], sum d into sums[r][1][N], d = (Y > 0 ?
+// dY : 0), xhat = (Z - mean) rstd -- so pccx_bn_relu_train_backward (flags bit 3) needs no reduction pass.  Y, Z: (M, ldo-strided) rows.
+extern "C" int pccx_linear_bnback(const float *x, int M, int K, int ldx, const float *wp, int N, int flags, float *out, int ldo,
+                                  const float *Y, const float *Z, const float *mean, const float *rstd, double *sums, void *stream)
+{
+    if (M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(x && wp && out && sums && Y && Z && mean && rstd, "pccx_linear_bnback: null pointer");
+    PCCX_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && ldx >= K && ldo >= N, "pccx_linear_bnback: bad shape M=%d K=%d N=%d ldx=%d ldo=%d", M, K, N, ldx, ldo);
+    const int KT = (K + 15) / 16, MT = (N + 15) / 16;
+    const bool vec = ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const bool bf16 = (flags & 2) != 0;
+    dim3 grid((M + 127) / 128, (MT + 3) / 4);
+    PCCX_CHECK_ARG(grid.y <= 65535, "pccx_linear_bnback: N=%d too large", N);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & 4)) PCCX_CHECK_HIP(pccx_zero_async(sums, sizeof(double) * PCCX_SUM_REPLICAS * 2 * (size_t)N, st));
+    const LinBn bn{Y, Z, mean, rstd};
+#define PCCX_LINB_LAUNCH(V, B)                                                                                                   \
+    hipLaunchKernelGGL((linear_kernel<4, V, B, 2>), grid, dim3(256), 0, st, x, M, K, ldx, (const f32x4 *)wp, KT, MT, (const float *)nullptr, N, \
+                       0, out, ldo, sums, PCCX_SUM_REPLICAS, bn)
+    if (vec && bf16) PCCX_LINB_LAUNCH(true, true);
+    else if (vec) PCCX_LINB_LAUNCH(true, false);
+    else if (bf16) PCCX_LINB_LAUNCH(false, true);
+    else PCCX_LINB_LAUNCH(false, false);
+#undef PCCX_LINB_LAUNCH
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }

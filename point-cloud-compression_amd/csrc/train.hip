@@ -686,8 +686,10 @@ extern "C" int pccx_bn_relu_train_backward(const float *dY, const float *Y, cons
     if (M == 0) return PCCX_OK;
     PCCX_CHECK_ARG(dY && Y && Z && mean && rstd && gamma && sums && dZ && g_gamma && g_beta, "pccx_bn_relu_train_backward: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_col_reduce(1, dY, Y, Z, mean, rstd, M, C, sums, sums + C, st, (flags & 4) != 0, PCCX_SUM_REPLICAS);
-    if (rc) return rc;
+    if (!(flags & 8)) {                                    // flags & 8: `sums` already holds the two sums (pccx_linear_bnback produced dY)
+        int rc = launch_col_reduce(1, dY, Y, Z, mean, rstd, M, C, sums, sums + C, st, (flags & 4) != 0, PCCX_SUM_REPLICAS);
+        if (rc) return rc;
+    }
     long blocks = ((long)M * C + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_relu_bwd_apply_w_kernel, dim3((unsigned)blocks), dim3(256), sizeof(double) * 2 * C, st, dY, Y, Z, (long)M * C, C, (long)M, mean, rstd,

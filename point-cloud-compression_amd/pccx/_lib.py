@@ -145,6 +145,7 @@ _SIGNATURES = {
     "pccx_col_sum_w": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P],
     "pccx_train_sums_doubles": [C.c_int],
     "pccx_linear_moments": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P],
+    "pccx_linear_bnback": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P],
     "pccx_zero_bytes": [_P, C.c_size_t, _P],
     "pccx_copy_bytes": [_P, _P, C.c_size_t, _P],
     "pccx_add_i64_table": [_P, C.c_int, C.c_int64, _P],

@@ -115,6 +115,9 @@ def _linear_raw(x, wp, bias, N, K, flags=0):
 
 _MOMENTS = {}              # address of a LinearFn output produced WITH its column moments -> (shape, sums); consumed by the BnReluFn that
                            # takes that tensor next, emptied at the start of every forward
+_BN_OF = {}                # address of a BnReluFn output y -> (shape, y, z, mean, rstd): the LinearFn that consumes y keeps it, and its
+                           # backward produces dY together with the BatchNorm backward's two column sums (pccx_linear_bnback)
+_BWD_SUMS = {}             # address of such a dY -> (shape, sums); consumed by that BnReluFn's backward
 _FOLD_MOMENTS = os.environ.get("PCCX_NO_MOMENT_FOLD") != "1"      # experiment knob: 0 = every BatchNorm reduces its input itself
 
 
@@ -129,6 +132,8 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, W2)
         ctx.has_bias, ctx.wshape = b is not None, W.shape
         ctx.flags = 2 if _AUTOCAST else 0
+        bn_in = _BN_OF.get(x.data_ptr()) if _FOLD_MOMENTS else None
+        ctx.bn_in = bn_in if (bn_in is not None and bn_in[0] == tuple(x.shape)) else None
         N, K = W2.shape
         # a few rows: a weight stream, not matrix work (csrc/train.hip).  The kernels take 16-byte loads of x rows and W rows: row stride and
         # base addresses are checked HERE (a (1, K) view keeps an arbitrary stride(0), a tensor with a storage offset can be misaligned) and
@@ -161,6 +166,15 @@ class LinearFn(torch.autograd.Function):
             # generic path rounds its result to bf16 as well; the per-layer pin of tests/test_train_step.py holds either to one bf16 ulp)
             dx, _ = _zeros((M, K), torch.float32, dz.device)
             _lib.call("pccx_linear_skinny_dx", dz.data_ptr(), M, N, dz.stride(0), W2.data_ptr(), K, ctx.flags, dx.data_ptr(), K, _stream())
+        elif ctx.needs_input_grad[0] and ctx.bn_in is not None and K % 4 == 0:
+            # x is the output of a train-mode BatchNorm-ReLU: dX is that layer's dY, and the GEMM's epilogue accumulates the two column
+            # sums its backward needs from the rows it has just produced (13 col_reduce4<1> launches per step otherwise)
+            _, y_, z_, mean_, rstd_ = ctx.bn_in
+            sums, pre = _sums(K, dz.device)
+            dx = torch.empty(M, K, device=dz.device, dtype=torch.float32)
+            _lib.call("pccx_linear_bnback", dz.data_ptr(), M, N, dz.stride(0), _packed(W2, True).data_ptr(), K, ctx.flags | pre, dx.data_ptr(), K,
+                      y_.data_ptr(), z_.data_ptr(), mean_.data_ptr(), rstd_.data_ptr(), sums.data_ptr(), _stream())
+            _BWD_SUMS[dx.data_ptr()] = (tuple(dx.shape), sums)
         elif ctx.needs_input_grad[0]:
             dx = _linear_raw(dz, _packed(W2, True), None, K, N, ctx.flags)                                       # dX = dZ . W
         dW, _ = _zeros(tuple(W2.shape), torch.float32, dz.device)
@@ -195,6 +209,8 @@ class BnReluFn(torch.autograd.Function):
         if _BN_COUNTED is None:
             bn.num_batches_tracked += 1             # outside forward_train (which advances every counter of the model in one launch)
         ctx.save_for_backward(z, y, mean, rstd, gamma)
+        if _FOLD_MOMENTS:
+            _BN_OF[y.data_ptr()] = (tuple(y.shape), y, z, mean, rstd)
         return y
 
     @staticmethod
@@ -204,7 +220,11 @@ class BnReluFn(torch.autograd.Function):
         M, Cc = z.shape
         dz = torch.empty_like(z)
         gg, gb = torch.empty_like(gamma), torch.empty_like(gamma)                    # written by the apply kernel's first workgroup
-        sums, pre = _sums(Cc, z.device)
+        bs = _BWD_SUMS.pop(dy.data_ptr(), None)
+        if bs is not None and bs[0] == tuple(dy.shape):
+            sums, pre = bs[1], 4 | 8                 # the GEMM that produced dY accumulated the two sums in its epilogue
+        else:
+            sums, pre = _sums(Cc, z.device)
         _lib.call("pccx_bn_relu_train_backward", dy.data_ptr(), y.data_ptr(), z.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
                   gamma.data_ptr(), sums.data_ptr(), dz.data_ptr(), gg.data_ptr(), gb.data_ptr(), pre, _stream())
         return dz, gg, gb, None
@@ -370,6 +390,8 @@ def forward_train(model, x, starts, tables=None):
     sa = enc.sa_modules
     outs, new_xyz = [], None
     _MOMENTS.clear()
+    _BN_OF.clear()
+    _BWD_SUMS.clear()
     _BN_COUNTED = _advance_bn_counters(model, x.device)    # every BatchNorm's num_batches_tracked += 1, one launch
     try:
         with ops.stage("selection"):

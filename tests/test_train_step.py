@@ -355,6 +355,34 @@ def test_linear_with_moments_feeds_batchnorm_the_sums_it_would_have_reduced():
     assert float((ya - yb).abs().max()) <= 1e-5 and float((bn_a.running_var - bn_b.running_var).abs().max()) <= 1e-6
     (ga,) = torch.autograd.grad(ya.sum(), W, retain_graph=False)
     assert torch.isfinite(ga).all()
+    # the backward of a two-layer stack: the second layer's dX GEMM produces the first BatchNorm's dY together with its two column sums
+    # (pccx_linear_bnback); gradients of both weights, both BatchNorm parameter pairs and the input against the unfused evaluation
+    def two_layers(fold, autocast):
+        train._FOLD_MOMENTS, train._AUTOCAST = fold, autocast
+        train._MOMENTS.clear(), train._BN_OF.clear(), train._BWD_SUMS.clear()
+        r2 = np.random.default_rng(11)
+        xin = torch.from_numpy(r2.standard_normal((5000, 32)).astype(np.float32)).cuda().requires_grad_(True)
+        W1 = torch.from_numpy((r2.standard_normal((64, 32)) / 6).astype(np.float32)).cuda().requires_grad_(True)
+        W2 = torch.from_numpy((r2.standard_normal((128, 64)) / 8).astype(np.float32)).cuda().requires_grad_(True)
+        b1, b2 = torch.nn.BatchNorm2d(64).cuda(), torch.nn.BatchNorm2d(128).cuda()
+        h = train.BnReluFn.apply(train.LinearFn.apply(xin, W1, None, True), b1.weight, b1.bias, b1)
+        o = train.BnReluFn.apply(train.LinearFn.apply(h, W2, None, True), b2.weight, b2.bias, b2)
+        wgt = torch.from_numpy(r2.standard_normal((5000, 128)).astype(np.float32)).cuda()
+        train._AUTOCAST = False
+        grads = torch.autograd.grad((o * wgt).sum(), [xin, W1, W2, b1.weight, b1.bias, b2.weight, b2.bias])
+        return [g.clone() for g in grads], (len(train._BWD_SUMS), fold)
+    try:
+        for autocast in (False, True):
+            g_f, info = two_layers(True, autocast)
+            assert info[0] == 0, "the BatchNorm backward did not take the GEMM's sums"
+            g_u, _ = two_layers(False, autocast)
+            # autocast rounds every GEMM result to bf16: sums that differ in their last fp32 bits move a few of those roundings by one
+            # bf16 ulp (2^-8 relative), nothing more
+            tol = 2.0 ** -8 if autocast else 2e-5
+            for a_, b_ in zip(g_f, g_u):
+                assert float((a_ - b_).abs().max()) <= tol * float(b_.abs().max()) + 1e-7, (autocast, tuple(a_.shape))
+    finally:
+        train._FOLD_MOMENTS, train._AUTOCAST = old, False
 
 
 @pytest.mark.gpu
