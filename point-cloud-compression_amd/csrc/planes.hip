@@ -453,6 +453,20 @@ __device__ __forceinline__ void pg_wait_set(uint4 (&b)[2][NBV])
 #undef PG_SETS3
 #undef PG_R
 
+// The barrier of a ring boundary WITHOUT __syncthreads()' fences.  The release fence in __syncthreads() makes the compiler wait for
+// EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)) in front of the s_barrier -- LDS-DMA fills are tracked by vmcnt and
+// write LDS, so it cannot tell them from the plane loads -- which throws away the counted waits above it: the plane loads of k-step
+// t + 2 and the ring fills of the next chunks, issued to stay in flight across the boundary, were all drained at every boundary
+// (matrix pipe 0.43 busy in the 512 -> 1024 layer).  What the protocol needs is already explicit: each wave's counted wait covers its own
+// pieces of chunk c (in-order completion), the barrier then says everyone's have landed and everyone has finished reading chunk c - 1
+// (those reads feed MFMAs issued before the barrier; the compiler's own lgkmcnt wait for them precedes their use).
+__device__ __forceinline__ void pg_ring_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
 
 // P = 2 (f16x2): the accumulators are sigma_in tau (W y + b s); `bias` holds sigma_in tau b, rho_in = sigma_in scales gathered rows,
@@ -467,11 +481,11 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
 {
     typedef PgArith<P> AR;
     typedef typename AR::vec avec;
-    // ring chunk: MQC m-tiles x P planes (1 KiB fragments).  MQC = 8 for the wide f16x2 form (all eight m-tiles of a k-step in one chunk,
-    // one barrier per k-step instead of two, three-deep ring of 16 KiB chunks) was built and measured SLOWER: the sixteen A fragments in
-    // registers take the kernel from 158 to 188 VGPRs = from three to two workgroups per CU (sa3 stack 1.52 -> 1.90 ms, FoldingNet's
-    // 512-wide chain 1.50 -> 1.61 per 2048 patches; tools/experiments/r5/README.md)
-    constexpr int MQC = 4;
+    // ring chunk: MQC m-tiles x P planes (1 KiB fragments).  The wide f16x2 form takes all eight m-tiles of a k-step in ONE chunk -- one
+    // barrier per k-step instead of two: f16x2 issues half the MFMAs of bf16x3 between barriers -- through a three-deep ring of 16 KiB
+    // chunks (48 KiB per workgroup: three workgroups per CU as before), reading the chunk's A fragments four m-tiles at a time (with all
+    // sixteen in registers the kernel needs 188 VGPRs = two workgroups per CU, and was slower: tools/experiments/r5/README.md)
+    constexpr int MQC = (P == 2 && MB == 8) ? 8 : 4;
     constexpr int PG_CHUNK = MQC * P;
     constexpr int NBUF = MQC == 8 ? 3 : PG_NB;                 // ring depth
     constexpr int DMA = PG_CHUNK / 4;                          // LDS-DMA loads per wave and chunk
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                     if (first) pg_wait_set<0, NBV>(braw);
                     else if (HALVES == 2) pg_wait_set<2 * DMA + NBL, NBV>(braw);
                     else pg_wait_set<DMA + NBL, NBV>(braw);
-                    __syncthreads();
+                    pg_ring_barrier();
                     dma(c + NBUF - 1);
                     load_b(bload, t + 2);
 #pragma unroll
@@ -560,25 +574,28 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                     }
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA + 2 * NBL) : "memory");
-                    __syncthreads();
+                    pg_ring_barrier();
                     dma(c + NBUF - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
-                avec a[MQC][P];
 #pragma unroll
-                for (int mq = 0; mq < MQC; ++mq)
+                for (int sub = 0; sub < MQC / 4; ++sub) {
+                    avec a[4][P];
 #pragma unroll
-                    for (int pl = 0; pl < P; ++pl) a[mq][pl] = __builtin_bit_cast(avec, buf[(mq * P + pl) * 64]);
-                __builtin_amdgcn_sched_barrier(0);
-                // the products, smallest first (bf16x3: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); f16x2: (lo,hi) (hi,lo) (hi,hi))
+                    for (int mq = 0; mq < 4; ++mq)
 #pragma unroll
-                for (int q = 0; q < AR::NQ; ++q)
+                        for (int pl = 0; pl < P; ++pl) a[mq][pl] = __builtin_bit_cast(avec, buf[((4 * sub + mq) * P + pl) * 64]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the products, smallest first (bf16x3: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); f16x2: (lo,hi) (hi,lo) (hi,hi))
 #pragma unroll
-                    for (int mq = 0; mq < MQC; ++mq)
+                    for (int q = 0; q < AR::NQ; ++q)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[nt][MQC * half + mq] = AR::mfma(a[mq][AR::pa(q)], bc[nt][AR::pb(q)], acc[nt][MQC * half + mq]);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int mq = 0; mq < 4; ++mq)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[nt][MQC * half + 4 * sub + mq] = AR::mfma(a[mq][AR::pa(q)], bc[nt][AR::pb(q)], acc[nt][MQC * half + 4 * sub + mq]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
         load_b(bs[0], 0);
@@ -773,7 +790,7 @@ __device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, co
         for (int mqq = 0; mqq < MQ; ++mqq) {
             // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (2 P loads) may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-            __syncthreads();
+            pg_ring_barrier();
             {
                 const int nx = c + PG_NB - 1;
                 ws.issue(nx < nch ? nx : 0, nx % PG_NB);
@@ -894,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
                     if (first) pg_wait_set<0, NBV>(braw);
                     else if (MQ0 == 2) pg_wait_set<2 * P + NBL, NBV>(braw);
                     else pg_wait_set<P + NBL, NBV>(braw);
-                    __syncthreads();
+                    pg_ring_barrier();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
 #pragma unroll
@@ -907,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
                     }
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + 2 * NBL) : "memory");
-                    __syncthreads();
+                    pg_ring_barrier();
                     dma(c + PG_NB - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
