@@ -241,7 +241,14 @@ struct WStreamT {
     __device__ __forceinline__ void boundary_keep(int c) const
     {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-        __syncthreads();
+        // a bare s_barrier, not __syncthreads(): the release fence in __syncthreads() makes the compiler put s_waitcnt vmcnt(0) in front of
+        // the barrier (LDS-DMA fills are vmcnt-tracked LDS writes, it cannot tell them from the loads meant to stay in flight), which
+        // discarded the counted wait above it in 64 of the f16x2 decoder's 65 barriers.  The wait above is what the protocol needs
+        // (in-order completion covers this wave's pieces of chunk c; reads of chunk c - 1 fed MFMAs issued before this point).
+        // Same-box A/B: decoder stage 6.01 / 6.07 -> 5.92 / 5.99 ms per 1024 clouds (tools/experiments/r5/README.md).
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         issue_ahead(c);
     }
     __device__ __forceinline__ const f32x4 *chunk(int c) const { return lds + (c % NB) * CH * 64 + lane; }

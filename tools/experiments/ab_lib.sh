@@ -7,7 +7,7 @@ L=$GRAFT_REPO_ROOT/point-cloud-compression_amd/pccx/lib
 cp $L/libpccx.so /tmp/base.so
 for v in base $V base $V; do
   if [ $v = base ]; then cp /tmp/base.so $L/libpccx.so; else cp $L/libpccx_$v.so $L/libpccx.so; fi
-  timeout -k 10 200 python3 bench.py --one-mode --cpu-clouds 0 --steps 5 --warmup 2 > $O/$v.json 2> $O/$v.err || { cp /tmp/base.so $L/libpccx.so; exit 1; }
+  timeout -k 10 200 python3 bench.py --one-mode --cpu-clouds 0 --no-secondary --no-files --steps 5 --warmup 2 > $O/$v.json 2> $O/$v.err || { cp /tmp/base.so $L/libpccx.so; exit 1; }
   python3 - <<PY
 import json
 d=json.loads([l for l in open("$O/$v.json") if l.startswith("{")][-1])
