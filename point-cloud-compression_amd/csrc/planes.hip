@@ -460,11 +460,18 @@ __device__ __forceinline__ void pg_wait_set(uint4 (&b)[2][NBV])
 // (matrix pipe 0.43 busy in the 512 -> 1024 layer).  What the protocol needs is already explicit: each wave's counted wait covers its own
 // pieces of chunk c (in-order completion), the barrier then says everyone's have landed and everyone has finished reading chunk c - 1
 // (those reads feed MFMAs issued before the barrier; the compiler's own lgkmcnt wait for them precedes their use).
+// BARE = false keeps __syncthreads(): the bf16x3 forms, the one-chunk forms and the chains gain nothing measurable from the bare barrier,
+// and with the compiler's drain in place tools/asm_load_lint.py can check them.
+template <bool BARE>
 __device__ __forceinline__ void pg_ring_barrier()
 {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if constexpr (BARE) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
 }
 
 enum { PG_EPI_PLANES = 0, PG_EPI_ROWS = 1, PG_EPI_MAX = 2 };
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                     if (first) pg_wait_set<0, NBV>(braw);
                     else if (HALVES == 2) pg_wait_set<2 * DMA + NBL, NBV>(braw);
                     else pg_wait_set<DMA + NBL, NBV>(braw);
-                    pg_ring_barrier();
+                    pg_ring_barrier<P == 2 && MB == 8>();
                     dma(c + NBUF - 1);
                     load_b(bload, t + 2);
 #pragma unroll
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                     }
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA + 2 * NBL) : "memory");
-                    pg_ring_barrier();
+                    pg_ring_barrier<P == 2 && MB == 8>();
                     dma(c + NBUF - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
@@ -790,7 +797,7 @@ __device__ __forceinline__ void pg_chain_layer(const WS &ws, int &c, int nch, co
         for (int mqq = 0; mqq < MQ; ++mqq) {
             // only DMAs are in flight here: chunk c's was issued three boundaries ago, two chunks (2 P loads) may stay in flight
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-            pg_ring_barrier();
+            pg_ring_barrier<false>();
             {
                 const int nx = c + PG_NB - 1;
                 ws.issue(nx < nch ? nx : 0, nx % PG_NB);
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
                     if (first) pg_wait_set<0, NBV>(braw);
                     else if (MQ0 == 2) pg_wait_set<2 * P + NBL, NBV>(braw);
                     else pg_wait_set<P + NBL, NBV>(braw);
-                    pg_ring_barrier();
+                    pg_ring_barrier<false>();
                     dma(c + PG_NB - 1);
                     load_b(bload, t + 2);
 #pragma unroll
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void planes_chain4_kernel(const uint4 *__re
                     }
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P + 2 * NBL) : "memory");
-                    pg_ring_barrier();
+                    pg_ring_barrier<false>();
                     dma(c + PG_NB - 1);
                 }
                 const f32x4 *buf = ws.chunk(c);
