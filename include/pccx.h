@@ -464,6 +464,16 @@ PCCX_API int pccx_rows_affine_planes_h2(const float *base, int C, int64_t div, c
 PCCX_API int pccx_planes_gemm_h2(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
                                  int epilogue, int group, float scale_out, const float *dyn, float *amax8, float *out, int ldo,
                                  void *stream);
+/* The last layer of a set-abstraction stack whose groups are only reduced together (PPPF_AE.py:44 over pointnet_sa_module.py:91: the maximum
+ * over the centroids of the maxima over their samples = the maximum over every source row that is a sample of any centroid, because the stack
+ * acts on each un-centred row by itself): member = 1 byte per row from pccx_group_members, group = the source rows of one batch element
+ * (32, 64 or 128, M % group == 0) -> out (M / group, ldo).  The layer's fp32 rows are never written. */
+PCCX_API int pccx_planes_gemm_h2_member_max(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                                            int group, const unsigned char *member, float scale_out, const float *dyn, float *out, int ldo,
+                                            void *stream);
+/* member (n_idx / per_batch, n_src) bytes: 1 where the row is named by an entry of idx (per_batch entries per batch element; -1 -> row 0, the
+ * clamp of pointnet_sa_module.py:27), else 0 */
+PCCX_API int pccx_group_members(const int64_t *idx, int64_t n_idx, int64_t per_batch, int64_t n_src, unsigned char *member, void *stream);
 PCCX_API int pccx_planes_gemm_gather_h2(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
                                         int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,
                                         float rho_in, float scale_out, const float *dyn, float *amax8, float *out, int ldo,

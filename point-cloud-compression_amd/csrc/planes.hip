@@ -484,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
                                                              long long ntiles, int KT32,
                                                              const float *__restrict__ wstream, int MBS, const float *__restrict__ bias,
                                                              int N, int relu, int group, float *__restrict__ out, int ldo, float rho_in,
-                                                             float scale_out, const float *__restrict__ dyn, float *__restrict__ amax)
+                                                             float scale_out, const float *__restrict__ dyn, float *__restrict__ amax,
+                                                             const unsigned char *__restrict__ member)
 {
     typedef PgArith<P> AR;
     typedef typename AR::vec avec;
@@ -671,6 +672,15 @@ __global__ __launch_bounds__(256, 2) void planes_gemm_kernel(const uint4 *__rest
         // the two tiles elementwise, then the 16 rows of the tile by DPP; across the waves of a group through LDS.
         __syncthreads();                                   // every wave is done with the ring
         float *smax = (float *)swt;                        // [4 waves][16 * MB channels]
+        if (member) {                                      // the maximum over the MEMBER rows of each group only (pccx_group_members)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const long long row = (tile0 + nt) * 16 + n;
+                if (tile0 + nt < ntiles && row < M && member[row]) continue;
+#pragma unroll
+                for (int mt = 0; mt < MB; ++mt) acc[nt][mt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MB; ++mt)
 #pragma unroll
@@ -701,7 +711,7 @@ template <int P>
 static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int ldp, int64_t M, int K,
                               const float *wstream, const float *bias, int N, int relu, int epilogue, int group, float *out, int ldo,
                               void *stream, const char *who, float rho_in = 1.f, float scale_out = 1.f, const float *dyn = nullptr,
-                              float *amax = nullptr)
+                              float *amax = nullptr, const unsigned char *member = nullptr)
 {
     if (M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(x && wstream && out, "%s: null pointer", who);
@@ -721,7 +731,7 @@ static int planes_gemm_launch(const float *x, const int64_t *idx, int64_t rows_p
 #define PG_LAUNCH(MB_, E_, G_)                                                                                                  \
     hipLaunchKernelGGL((planes_gemm_kernel<P, MB_, E_, G_>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)x, idx,    \
                        (long long)rows_per_batch, (long long)n_src, ldp, (long long)M, ntiles, KT32, wstream, MBS, bias, N, relu, \
-                       group, out, ldo, rho_in, scale_out, dyn, amax)
+                       group, out, ldo, rho_in, scale_out, dyn, amax, member)
 #define PG_LAUNCH_E(MB_, G_)                                                                                                    \
     do {                                                                                                                        \
         if (epilogue == PG_EPI_PLANES) PG_LAUNCH(MB_, PG_EPI_PLANES, G_);                                                       \
@@ -753,6 +763,50 @@ extern "C" int pccx_planes_gemm_h2(const float *planes_in, int64_t M, int K, con
     PCCX_CHECK_ARG(!amax8 || epilogue == PG_EPI_ROWS, "pccx_planes_gemm_h2: the |value| maximum is collected by the row epilogue only");
     return planes_gemm_launch<2>(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, epilogue, group, out, ldo, stream,
                                  "pccx_planes_gemm_h2", 1.f, scale_out, dyn, amax8);
+}
+
+// The last layer of a set-abstraction stack whose groups are only ever reduced TOGETHER (PPPF_AE's third level: PPPF_AE.py:44 takes the
+// maximum over the 32 centroids of the maxima over their 128 samples, pointnet_sa_module.py:91 -- and the stack acts on each un-centred
+// source row by itself, so that double maximum is the maximum over the rows that are a sample of ANY centroid).  member = one byte per
+// row (pccx_group_members), group = the source rows of one batch element (32, 64 or 128): out (M / group, ldo) = the maximum over the
+// member rows of each group.  The layer's fp32 rows (1 GB per 2048 patches for 512 -> 1024) are never written, nor gathered per centroid.
+// A group without a member gives 0 with relu, -inf without.
+extern "C" int pccx_planes_gemm_h2_member_max(const float *planes_in, int64_t M, int K, const float *wstream, const float *bias, int N, int relu,
+                                              int group, const unsigned char *member, float scale_out, const float *dyn, float *out, int ldo,
+                                              void *stream)
+{
+    PCCX_CHECK_ARG(scale_out > 0.f, "pccx_planes_gemm_h2_member_max: scale_out must be a positive power of two");
+    PCCX_CHECK_ARG(member || M == 0, "pccx_planes_gemm_h2_member_max: null member table");
+    return planes_gemm_launch<2>(planes_in, nullptr, 1, 1, 0, M, K, wstream, bias, N, relu, PG_EPI_MAX, group, out, ldo, stream,
+                                 "pccx_planes_gemm_h2_member_max", 1.f, scale_out, dyn, nullptr, member);
+}
+
+// member[(e / per_batch) * n_src + max(idx[e], 0)] = 1 for every entry e of idx (n_idx entries, per_batch = centroids * nsample per
+// batch element; -1 = the ball query's padding, which the reference's gather clamps to row 0: pointnet_sa_module.py:27); all other
+// bytes of member (n_batches * n_src) are cleared.
+__global__ __launch_bounds__(256) void group_members_kernel(const int64_t *__restrict__ idx, long long n_idx, long long per_batch, long long n_src,
+                                                            unsigned char *__restrict__ member)
+{
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < n_idx; e += gridDim.x * 256ll) {
+        long long j = idx[e];
+        j = j < 0 ? 0 : (j < n_src ? j : n_src - 1);
+        member[(e / per_batch) * n_src + j] = 1;
+    }
+}
+
+extern "C" int pccx_group_members(const int64_t *idx, int64_t n_idx, int64_t per_batch, int64_t n_src, unsigned char *member, void *stream)
+{
+    if (n_idx == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(idx && member, "pccx_group_members: null pointer");
+    PCCX_CHECK_ARG(n_idx > 0 && per_batch >= 1 && n_src >= 1 && n_idx % per_batch == 0, "pccx_group_members: bad shape n_idx=%lld per_batch=%lld n_src=%lld",
+                   (long long)n_idx, (long long)per_batch, (long long)n_src);
+    hipStream_t st = (hipStream_t)stream;
+    PCCX_CHECK_HIP(hipMemsetAsync(member, 0, (size_t)(n_idx / per_batch * n_src), st));
+    const long long blocks = (n_idx + 255) / 256;
+    hipLaunchKernelGGL(group_members_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, idx, (long long)n_idx,
+                       (long long)per_batch, (long long)n_src, member);
+    PCCX_CHECK_LAUNCH();
+    return PCCX_OK;
 }
 
 // The same layer with its input gathered in the kernel (see pccx_planes_chain4_gather): src = fp32 rows of ldp = 32 * ceil(K / 32)

@@ -123,6 +123,8 @@ _SIGNATURES = {
     "pccx_fold_planes_h2": [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_float, _P, _P, _P],
     "pccx_rows_affine_planes_h2": [_P, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int64, C.c_float, _P, _P, _P],
     "pccx_planes_gemm_h2": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_int, _P],
+    "pccx_planes_gemm_h2_member_max": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, C.c_int, _P],
+    "pccx_group_members": [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P],
     "pccx_planes_gemm_gather_h2": [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.c_float, _P, _P, _P, C.c_int, _P],
     "pccx_planes_chain4_h2": [_P, C.c_int64, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P],

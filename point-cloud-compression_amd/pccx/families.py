@@ -101,12 +101,17 @@ class FoldedLinear:
         from . import DEFAULT_MATMUL
         return self.matmul or DEFAULT_MATMUL
 
-    def planes_h2(self, pin, M, epilogue=0, group=0, sig_next=None, dyn=None, amax=None):
+    def planes_h2(self, pin, M, epilogue=0, group=0, sig_next=None, dyn=None, amax=None, member=None):
         """planes() in the f16x2 arithmetic (h2_prepare_stack first): pin = f16x2 planes of sigma * input.  epilogue 0 -> f16x2 planes of
         sig_next * output; 1 / 2 -> fp32 rows / group maxima, un-scaled (and times dyn[1]); amax: 8 floats the row epilogue folds the
-        largest |value| into."""
+        largest |value| into.  member (M bytes, with epilogue 2): the maxima run over the rows marked 1 only."""
         h = self.h2
         scale = (float(sig_next) if epilogue == 0 else 1.0) / (h["sig"] * h["tau"])
+        if member is not None:
+            out = torch.empty(M // group, self.N, device=pin.device, dtype=torch.float32)
+            _lib.call("pccx_planes_gemm_h2_member_max", pin.data_ptr(), M, self.K, h["ws"].data_ptr(), h["b"].data_ptr(), self.N, self.relu, group,
+                      member.data_ptr(), scale, dyn.data_ptr() if dyn is not None else None, out.data_ptr(), self.N, _stream())
+            return out
         if epilogue == 0:
             out = torch.empty(_lib.load().pccx_planes_floats_h2(M, self.N), device=pin.device, dtype=torch.float32)
         else:
@@ -444,6 +449,32 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
     # per row, hence bit-identical outputs, for 1 / (npoint * nsample / N) of the matrix work (PPPF_AE: 16384 -> 512, 8192 -> 512,
     # 4096 -> 128 rows per patch).  dedup=False keeps the literal grouped evaluation (tests compare the two bit for bit).
     dedup = True
+    # A level whose output is only ever reduced over ALL its centroids (PPPF_AE's third: PPPF_AE.py:44) needs no per-centroid maxima: the
+    # maximum over the centroids of the maxima over their samples is the maximum over the source rows that are a sample of any centroid.
+    # run_union_max() marks those rows (pccx_group_members) and takes that maximum in the last layer's epilogue -- neither the layer's
+    # fp32 rows (1 GB per 2048 patches) nor the per-centroid table exist.  union_max=False keeps gather_max + group_max (tests compare).
+    union_max = True
+
+    def run_union_max(self, stack, xyz, feats, h2):
+        """max over the npoint centroids of the level's output (B, C'), f16x2 arithmetic; needs N in {32, 64, 128} source rows per element"""
+        B, N = xyz.shape[0], xyz.shape[1]
+        with stage("fps"):
+            new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)               # :66-68 (start index 0)
+        with stage("ball_query"):
+            idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx       # :71 (-1 padded; gather clamps, :27)
+            member = torch.empty(B * N, device=xyz.device, dtype=torch.uint8)
+            _lib.call("pccx_group_members", idx.data_ptr(), idx.numel(), self.npoint * self.nsample, N, member.data_ptr(), _stream())
+        with stage("sa_stack_%d" % stack[-1].N):
+            dyn, _ = h2
+            f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
+            x2 = xyz.reshape(-1, 3).contiguous()
+            C0 = int(f2.shape[1]) if f2 is not None else 0
+            pl = torch.empty(_lib.load().pccx_planes_floats_h2(B * N, C0 + 3), device=x2.device, dtype=torch.float32)
+            _lib.call("pccx_group_planes_h2", f2.data_ptr() if f2 is not None else None, C0, C0, x2.data_ptr(), 3, 3, None, B * N, 1, 1,
+                      float(stack[0].h2["sig"]), dyn.data_ptr(), pl.data_ptr(), _stream())
+            for i, layer in enumerate(stack[:-1]):
+                pl = layer.planes_h2(pl, B * N, 0, sig_next=stack[i + 1].h2["sig"], dyn=dyn)
+            return stack[-1].planes_h2(pl, B * N, 2, group=N, dyn=dyn, member=member)
 
     def run(self, stack, xyz, feats, h2=None):
         """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C')).
@@ -630,9 +661,12 @@ class PPPF_AE(_Packable):
                 scale_of(am(0), 1.0, None, 0.0, 0.0, 1, dy(0))
             else:
                 scale_of(am(lvl), 1.0, am(0), 1.0, 0.0, 1, dy(lvl))
+            if (lvl == 2 and mod.union_max and pts.shape[1] in (32, 64, 128) and stack[-1].relu and not chain4_fits(stack)):
+                feats = mod.run_union_max(stack, pts, feats, (dy(lvl), None))       # (B, dim): :44 and :91 of the level in one epilogue
+                continue
             pts, feats = mod.run(stack, pts, feats, h2=(dy(lvl), am(lvl + 1) if lvl < 2 else None))
         with stage("latent"):
-            g = group_max(feats)                                                    # :44 max over the 32 points
+            g = group_max(feats) if feats.dim() == 3 else feats                     # :44 max over the 32 points
             latent = sigmoid_spread(g, self.L)                                      # :136-137
             q = round_(pk["enc"](latent))                                           # :139-142
             lat_dec = pk["dec"](q)                                                  # :145

@@ -161,6 +161,65 @@ def test_pppf_ae_f16x2_stacks_match_the_fixture_the_oracle_and_bf16x3(fam, oracl
 
 
 @pytest.mark.gpu
+def test_third_level_union_maximum_equals_gather_max_then_group_max_bit_for_bit(oracle_nets):
+    """PPPF_AE's third set-abstraction level feeds only the maximum over its 32 centroids (PPPF_AE.py:44), and its stack acts on each
+    un-centred source row by itself (pointnet_sa_module.py:73-91): max over centroids of max over samples = max over the rows that are a
+    sample of any centroid.  The f16x2 path marks those rows (pccx_group_members; -1 -> row 0 as the gather's clamp does) and takes the
+    maximum in the last layer's epilogue (pccx_planes_gemm_h2_member_max).  Against the per-centroid table (union_max=False: row epilogue,
+    pccx_gather_max, pccx_group_max): IDENTICAL latents, symbols and reconstructions -- dense balls (every row a member), sparse clouds
+    whose balls are padded, and a cloud where most rows are outside every ball.  The two entry points against torch as well."""
+    import pccx
+    from pccx import _lib, families
+    m, _ = oracle_nets
+    g = families.PPPF_AE(512, 0, 16, 7)
+    g.load_state_dict(m.state_dict())
+    rng = np.random.default_rng(11)
+    far = (rng.random((4, 512, 3)) * 0.05).astype(np.float32)
+    far[:, ::2] += rng.integers(0, 2, (4, 256, 3)).astype(np.float32) * 40.0         # clusters 40 apart: most rows outside most balls
+    old = pccx.DEFAULT_MATMUL
+    try:
+        pccx.DEFAULT_MATMUL = "f16x2"
+        for x in (synth.pppf_input(), (rng.random((5, 512, 3)) * 1.6).astype(np.float32), (rng.random((3, 512, 3)) * 30).astype(np.float32), far):
+            xc = torch.from_numpy(x).cuda()
+            assert families.PointnetSAModule.union_max
+            a = g(xc)
+            try:
+                families.PointnetSAModule.union_max = False
+                b = g(xc)
+            finally:
+                families.PointnetSAModule.union_max = True
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
+    finally:
+        pccx.DEFAULT_MATMUL = old
+    # pccx_group_members: the rows named by idx (with the clamp), per batch element
+    B, G, ns, N = 7, 5, 16, 128
+    idx = torch.from_numpy(rng.integers(-1, N, (B, G, ns))).cuda()
+    idx[3] = -1                                                                       # an element whose balls are all padding: row 0 only
+    member = torch.full((B * N,), 7, device="cuda", dtype=torch.uint8)
+    _lib.call("pccx_group_members", idx.data_ptr(), idx.numel(), G * ns, N, member.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    want = torch.zeros(B, N, dtype=torch.uint8, device="cuda")
+    want.scatter_(1, idx.clamp(min=0).view(B, -1), 1)
+    assert torch.equal(member.view(B, N), want) and int(want[3].sum()) == 1
+    with pytest.raises(_lib.PccxError):
+        _lib.call("pccx_group_members", idx.data_ptr(), idx.numel(), G * ns + 1, N, member.data_ptr(), None)
+    # pccx_planes_gemm_h2_member_max against the row epilogue of the same layer reduced by torch
+    stack = g._packed["sa"][2]
+    layer, M = stack[-1], B * N
+    rows_in = (rng.random((M, layer.K)) * (16384.0 / layer.h2["sig"])).astype(np.float32)   # sigma * input within fp16's range
+    pl = torch.empty(_lib.load().pccx_planes_floats_h2(M, layer.K), device="cuda", dtype=torch.float32)
+    xin = torch.from_numpy(rows_in).cuda()
+    _lib.call("pccx_group_planes_h2", xin.data_ptr(), layer.K, layer.K, None, 0, 0, None, M, 1, 1, float(layer.h2["sig"]), None, pl.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    rows = layer.planes_h2(pl, M, 1)
+    got = layer.planes_h2(pl, M, 2, group=N, member=member)
+    ref = torch.where(want.view(B, N, 1).bool(), rows.view(B, N, -1), torch.full_like(rows.view(B, N, -1), float("-inf"))).amax(dim=1)
+    assert torch.equal(got, ref)
+    none = layer.planes_h2(pl, M, 2, group=N, member=torch.zeros_like(member))
+    assert torch.equal(none, torch.zeros_like(none))                                  # no member: relu(-inf) = 0
+
+
+@pytest.mark.gpu
 def test_pointnet_sa_module_on_source_rows_equals_the_grouped_evaluation_bit_for_bit(oracle_nets, matmul_mode):
     """PointnetSAModule gathers features and xyz un-centred (pointnet_sa_module.py:73-85), so each grouped row is a copy of a source
     row: families.PointnetSAModule evaluates its Conv-BN-ReLU stack on the N source rows and takes every group's maximum from that
