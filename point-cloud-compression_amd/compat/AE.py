@@ -9,8 +9,9 @@ from pccx.models import AE, ConditionalProbabilityModel  # noqa: F401
 
 class get_loss(torch.nn.Module):                                  # AE.py:57-70
     """Rate-distortion loss d + lambda * r.  The Chamfer term is differentiable w.r.t. both clouds
-    (ops.chamfer_distance: HIP forward + pccx_chamfer_grad backward); the models of this module are
-    inference-only (their forwards do not record a graph), so training goes through pccx.train."""
+    (ops.chamfer_distance: HIP forward + pccx_chamfer_grad backward).  The forwards of this module's models are
+    the codec's inference kernels (they record no graph); the training step of train.py:156-245 evaluates the SAME
+    parameters layer by layer through autograd Functions in pccx.train_ipdae (cli/train.py keeps train.py's flags)."""
 
     def forward(self, pc_pred, pc_target, fbpp, λ):
         d, _ = ops.chamfer_distance(pc_pred, pc_target)

@@ -553,6 +553,38 @@ class Adam:
                   float(self.betas[0]), float(self.betas[1]), float(self.eps), _stream())
         return acc
 
+    def state_dict(self):
+        """torch.optim.Adam.state_dict()'s layout (what train.py:107 saves as optimizer_step{N}.pkl): per-parameter step / exp_avg /
+        exp_avg_sq keyed by the parameter's position, one param_group with the hyper-parameters -- a checkpoint written here loads into
+        torch.optim.Adam over the same parameter list, and the other way round."""
+        state = {i: {"step": torch.tensor(float(self.t)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+                 for i, (m, v) in enumerate(zip(self.m, self.v))} if self.t > 0 else {}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        if len(g["params"]) != len(self.params):
+            raise _lib.PccxError(f"Adam.load_state_dict: {len(g['params'])} parameters in the checkpoint, {len(self.params)} here")
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise _lib.PccxError("Adam.load_state_dict: weight_decay / amsgrad / maximize are not built (train.py:131-134 uses none of them)")
+        self.betas, self.eps = tuple(g["betas"]), float(g["eps"])
+        steps = {int(float(st["step"])) for st in sd["state"].values()}
+        if len(steps) > 1:
+            raise _lib.PccxError(f"Adam.load_state_dict: parameters at different steps {sorted(steps)} (one counter here)")
+        self.t = steps.pop() if steps else 0
+        for i, (m, v) in enumerate(zip(self.m, self.v)):
+            st = sd["state"].get(i)
+            if st is None:
+                m.zero_(), v.zero_()
+            else:
+                m.copy_(st["exp_avg"]), v.copy_(st["exp_avg_sq"])
+        if self.hyper is not None:
+            self.hyper = None
+            self.make_capturable(self.params[0].device)
+        self.set_lr(float(g["lr"]))
+
     def flush_table(self):
         """Upload the tensor table recorded during a capture (step() could not copy from the host there)."""
         if self._pending is not None:

@@ -14,6 +14,8 @@ What is executed from the reference, unmodified, imported from /root/reference:
   * eval.calc_uc (uniformity coefficient, eval.py:127-151)            (eval.py, imported with an argv that matches no file)
   * train_pppe_pcd_ae.set_model_and_loss / train_one_epoch (two iterations on CPU, scaler=None) with
     pppe_pcd_ae.RateDistortionLoss / estimate_bits_per_point_conditional (train_pppe_pcd_ae.py:171-252)
+  * train.prepare_model_and_optimizer / train_one_epoch for --model AE (two iterations on CPU, scaler=None) with AE.get_loss
+    (train.py:125-256, AE.py:57-70)
 
 pn_kit.py and AE.py import pytorch3d, pyntcloud and plyfile at module import; none
 of the three is installed in the image (no network).  Their NAMES are bound here
@@ -73,6 +75,63 @@ def _bind_absent_third_party():
         sys.modules[m.__name__] = m
 
 
+IPDAE_TRAIN_CFG = dict(N=2048, N0=1024, ALPHA=2, K=64, d=16, L=7, B=2, lr=5e-4, lamda=1000.0, rate_loss_enable_step=1, lr_decay=0.1,
+                       lr_decay_steps=2)
+
+
+def make_ipdae_train(ref_AE):
+    """ipdae_train_step.npz: two iterations of the reference's OWN loop body for ``--model AE`` -- train.train_one_epoch (train.py:156-256)
+    called once per iteration with a one-batch loader on CPU (scaler=None: the contextlib.nullcontext branch of :175, fp32), the models and
+    the optimizer built as train.py:125-135 builds them, the criterion the reference's AE.get_loss behind a recorder that keeps the exact
+    scalars it is handed.  Iteration 0 runs with lambda = 0 (global_step < rate_loss_enable_step, :218-219), iteration 1 with the rate term
+    on (lambda chosen large enough that the probability model's gradients are comparable with the distortion's), and the learning rate
+    decays after it (:250-254).  pytorch3d's knn_points and chamfer_distance are the oracle's definitions (module docstring)."""
+    import argparse
+    import tempfile
+    import train as ref_script
+    c = IPDAE_TRAIN_CFG
+    targs = argparse.Namespace(device="cpu", model="AE", N=c["N"], N0=c["N0"], ALPHA=c["ALPHA"], K=c["K"], d=c["d"], L=c["L"],
+                               S=c["N"] * c["ALPHA"] // c["K"], k=c["K"] // c["ALPHA"], lr=c["lr"], lamda=c["lamda"],
+                               rate_loss_enable_step=c["rate_loss_enable_step"], lr_decay=c["lr_decay"], lr_decay_steps=c["lr_decay_steps"],
+                               max_steps=100, step_window=10 ** 9, batch_size=c["B"], model_save_folder=tempfile.mkdtemp())
+    ae, prob, crit, opt = ref_script.prepare_model_and_optimizer(targs)               # train.py:125-135
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, synth.AE_SEED, last_gain=synth.AE_LAST_GAIN))
+    prob.load_state_dict(ref_model.seeded_state_dict(prob, synth.PROB_SEED, gain=synth.PROB_GAIN))
+    xt = torch.from_numpy(synth.train_input(c["B"], c["N"]))
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.log = inner, []
+
+        def forward(self, pc_pred, pc_target, fbpp, λ):
+            out = self.inner(pc_pred, pc_target, fbpp, λ)
+            self.log.append((float(out), float(fbpp), float(λ), float(pc_pred.shape[1])))
+            return out
+
+    class Bar:
+        def set_postfix(self, *a, **k): pass
+        def update(self, *a): pass
+
+    rec = Recorder(crit)
+    named = [("ae." + k, v) for k, v in ae.named_parameters()] + [("prob." + k, v) for k, v in prob.named_parameters()]
+    tr = {"param_names": np.array([k for k, _ in named])}
+    gstep, starts = 0, []
+    for it in range(2):
+        torch.manual_seed(900 + it)                  # the one torch.randint draw of pn_kit.py:321 in this iteration (train.py:178)
+        starts.append(torch.randint(0, c["N"], (c["B"],), dtype=torch.long).numpy())
+        torch.manual_seed(900 + it)
+        gstep = ref_script.train_one_epoch([(xt, 0)], ae, prob, rec, opt, None, targs, it, gstep, Bar())
+        tr[f"params_{it}"] = np.concatenate([synth.sample64(v.detach().numpy()) for _, v in named])
+        tr[f"grads_{it}"] = np.concatenate([synth.sample64(v.grad.numpy()) if v.grad is not None
+                                             else np.full(synth.sample64(v.detach().numpy()).shape, np.nan, np.float32) for _, v in named])
+        tr[f"grad_norms_{it}"] = np.array([float(v.grad.double().norm()) if v.grad is not None else np.nan for _, v in named])
+        tr[f"lr_{it}"] = np.float64(opt.param_groups[0]["lr"])
+    tr["scalars"] = np.array(rec.log, dtype=np.float64)          # per iteration: loss, fbpp, lambda, points in pc_pred
+    tr["starts"] = np.stack(starts)
+    np.savez_compressed(os.path.join(HERE, "ipdae_train_step.npz"), **tr)
+
+
 def make_eval_uc():
     """7. eval.calc_uc (eval.py:127-151), the reference's own function: eval.py is a script (argparse + the evaluation
     loop run at import), so it is imported with an argv whose glob matches nothing and an output file in a scratch
@@ -103,6 +162,13 @@ def main():
     if "--only-eval-uc" in sys.argv:
         sys.argv.remove("--only-eval-uc")
         return make_eval_uc()
+    if "--only-ipdae-train" in sys.argv:
+        sys.argv.remove("--only-ipdae-train")
+        _bind_absent_third_party()
+        sys.path.insert(0, REF)
+        import AE as ref_AE_
+        torch.set_num_threads(1)
+        return make_ipdae_train(ref_AE_)
     _bind_absent_third_party()
     sys.path.insert(0, REF)
     import octree_np as ref_octree
@@ -293,8 +359,9 @@ def main():
     tr["bn_running_var_sample"] = np.concatenate([synth.sample64(v.numpy()) for k, v in ae.named_buffers() if k.endswith("running_var")])
     np.savez_compressed(os.path.join(HERE, "train_step.npz"), **tr)
 
+    make_ipdae_train(ref_AE)
     make_eval_uc()
-    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz", "train_step.npz", "eval_uc.npz"):
+    for f in ("octree.npz", "depth_search_pack.npz", "pnkit_float.npz", "model.npz", "families.npz", "train_step.npz", "ipdae_train_step.npz", "eval_uc.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
