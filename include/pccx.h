@@ -472,7 +472,7 @@ PCCX_API int pccx_planes_gemm_h2_member_max(const float *planes_in, int64_t M, i
                                             int group, const unsigned char *member, float scale_out, const float *dyn, float *out, int ldo,
                                             void *stream);
 /* member (n_idx / per_batch, n_src) bytes: 1 where the row is named by an entry of idx (per_batch entries per batch element; -1 -> row 0, the
- * clamp of pointnet_sa_module.py:27), else 0 */
+ * clamp of pointnet_sa_module.py:27), else 0.  The table's size and address must be multiples of 4 (cleared in words by a kernel). */
 PCCX_API int pccx_group_members(const int64_t *idx, int64_t n_idx, int64_t per_batch, int64_t n_src, unsigned char *member, void *stream);
 PCCX_API int pccx_planes_gemm_gather_h2(const float *src, int ldp, const int64_t *idx, int64_t rows_per_batch, int64_t n_src, int64_t M,
                                         int K, const float *wstream, const float *bias, int N, int relu, int epilogue, int group,

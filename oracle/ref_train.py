@@ -52,3 +52,41 @@ def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, chamfer_chun
     torch.nn.utils.clip_grad_norm_(list(model.parameters()), grad_clip)
     opt.step()
     return float(loss), float(dist), float(rate)
+
+
+# ------------------------------------------------------------------------------------------------
+def ipdae_train_step(ae, prob, opt, batch_x, starts, lam, N0=1024, ALPHA=2, K=256, chamfer=None):
+    """One iteration of train.train_one_epoch for --model AE (train.py:162-236) on CPU, fp32 (the contextlib.nullcontext branch of
+    :175): ae / prob are oracle.ref_model's restatements of AE.AE / AE.ConditionalProbabilityModel, opt a torch.optim.Adam over both
+    (train.py:131-134).  -> dict(loss, fbpp, bpp).  TEST INFRASTRUCTURE ONLY.  Pinned by tests/golden/ipdae_train_step.npz (two
+    iterations of the reference's own train_one_epoch; tests/test_train_ipdae.py checks this function against it on CPU).
+    chamfer: a callable (pred, target) -> scalar with autograd, default the brute-force definition above."""
+    import numpy as np
+    from . import cport, ref_model
+    B, N, _ = batch_x.shape
+    S = N * ALPHA // K
+    ae.train(), prob.train()
+    # pn_kit.normalize reads centre / longest side from pc[0] only (pn_kit.py:50-53) and applies them to the whole batch
+    x, _, _ = ref_model.normalize(batch_x, margin=0.01)                                            # :171
+    opt.zero_grad()                                                                                # :173
+    sampled = ref_model.index_points(x, ref_model.farthest_point_sample(x, S, list(starts)))       # :178
+    codes, sampled_bits = cport.encode_sampled_np(sampled.numpy(), 1, N, ref_model.OCTREE_BPP_DICT[K])   # :183
+    rec = torch.from_numpy(np.asarray(cport.decode_sampled_np(codes, 1, "reference"), dtype=np.float32))   # :184
+    _, _, grouped = ref_model.knn_points(rec, x, K=K, return_nn=True)                               # :192-194
+    grouped = grouped - rec.view(B, S, 1, 3)                                                       # :195
+    scale = (N / N0) ** (1 / 3)
+    x_patches = grouped.view(B * S, K, 3) * scale                                                  # :196-199
+    latent = ae.encode(x_patches)                                                                  # AE.py:37-44
+    q = latent + (latent.round() - latent).detach()                                                # AE.py:45, STEQuantize (:72-85)
+    patches_pred = ae.decode(q) / scale                                                            # AE.py:48-53, train.py:201
+    pmf = prob(rec)                                                                                # :204
+    sym = (q.detach().view(B, S, ae.d) + ae.L // 2).long().clamp(0, ae.L - 1)                      # :205-206
+    feature_bits = ref_model.estimate_bits_from_pmf(pmf, sym) / (B * N)                            # :208
+    bpp = (sampled_bits + feature_bits) / (B * N)                                                  # :211
+    fbpp = feature_bits / (B * N)                                                                  # :212
+    pc_pred = (patches_pred.reshape(B, S, -1, 3) + rec.view(B, S, 1, 3)).reshape(B, -1, 3)         # :214-216
+    d = (chamfer or chamfer_autograd)(pc_pred, x)                                                  # AE.py:67
+    loss = d + lam * fbpp                                                                          # AE.py:68-70
+    loss.backward()                                                                                # :229
+    opt.step()                                                                                     # :230
+    return dict(loss=float(loss.detach()), fbpp=float(fbpp.detach()), bpp=float(bpp.detach()))

@@ -800,8 +800,11 @@ extern "C" int pccx_group_members(const int64_t *idx, int64_t n_idx, int64_t per
     PCCX_CHECK_ARG(idx && member, "pccx_group_members: null pointer");
     PCCX_CHECK_ARG(n_idx > 0 && per_batch >= 1 && n_src >= 1 && n_idx % per_batch == 0, "pccx_group_members: bad shape n_idx=%lld per_batch=%lld n_src=%lld",
                    (long long)n_idx, (long long)per_batch, (long long)n_src);
+    PCCX_CHECK_ARG((n_idx / per_batch * n_src) % 4 == 0 && (uintptr_t)member % 4 == 0,
+                   "pccx_group_members: the member table (%lld bytes) is cleared in 4-byte words: size and address must be multiples of 4",
+                   (long long)(n_idx / per_batch * n_src));
     hipStream_t st = (hipStream_t)stream;
-    PCCX_CHECK_HIP(hipMemsetAsync(member, 0, (size_t)(n_idx / per_batch * n_src), st));
+    PCCX_CHECK_HIP(pccx_zero_async(member, (size_t)(n_idx / per_batch * n_src), st));       // a kernel, never a memset node (common.h)
     const long long blocks = (n_idx + 255) / 256;
     hipLaunchKernelGGL(group_members_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, idx, (long long)n_idx,
                        (long long)per_batch, (long long)n_src, member);

@@ -88,7 +88,8 @@ def estimate_bits_from_pmf(pmf, sym):
 
 def select_patches(batch_x, S, K, N, N0, starts):
     """train.py:171-199 -- everything in front of the networks: depends on the data and the FPS start indices only.
-    -> (batch_x normalised (B,N,3), rec_sampled_xyz (B,S,3), x_patches (B*S,K,3) scaled, sampled_bits (python int), scale)"""
+    -> (batch_x normalised (B,N,3), rec_sampled_xyz (B,S,3), x_patches (B*S,K,3) scaled, sampled_bits (device scalar), scale)
+    Nothing here reads a result on the host: the whole step can be captured into a hipGraph (GraphedIpdaeStep)."""
     B = batch_x.shape[0]
     if S != 64:
         raise _lib.PccxError(f"train_ipdae: octree_np.decode returns 64 centres whatever it is given (octree_np.py:100-111); S = N * ALPHA / K "
@@ -104,7 +105,7 @@ def select_patches(batch_x, S, K, N, N0, starts):
     sampled = ops.index_points(x, ops.farthest_point_sample_batch(x, S, starts))      # :178
     enc = ops.octree_encode(sampled, N, OCTREE_BPP_DICT[K])                           # :183
     rec, _ = ops.octree_decode(enc["bytes"], enc["nbytes"], "reference", S)           # :184
-    sampled_bits = int(enc["nbits"].sum())                                            # codebits: the streams' lengths in bits
+    sampled_bits = enc["nbits"].sum()                                                 # codebits: the streams' lengths in bits (device scalar)
     scale = float((N / N0) ** (1 / 3))
     patches = ops.knn_points(rec, x, K, patch_scale=scale).knn.view(B * S, K, 3)      # :192-199
     return x, rec, patches, sampled_bits, scale
@@ -167,3 +168,82 @@ class IpdaeTrainer:
             self.lr *= self.lr_decay
             self.opt.set_lr(self.lr)
         return dict(loss=float(loss.detach()), fbpp=float(fbpp.detach()), bpp=float(bpp.detach()))
+
+    def graphed(self, batch_x, starts, warmup=2):
+        """-> GraphedIpdaeStep over this trainer's models and optimizer (the warm-up iterations are real steps on batch_x)"""
+        return GraphedIpdaeStep(self, batch_x, starts, warmup)
+
+
+class GraphedIpdaeStep:
+    """IpdaeTrainer.step captured ONCE as a hipGraph and replayed: the iteration is ~400 small launches at the reference's batch size of 1
+    (64 patches), bound by launch latency, not by arithmetic.  Selection included: FPS, the octree depth search / encode / decode and
+    both kNN searches are stream-ordered kernels that read the batch and the start indices from device memory.  What changes from step to
+    step lives in buffers the graph reads: the batch, the start indices, lambda (0 until rate_loss_enable_step) and Adam's lr / bias
+    corrections (Adam.make_capturable).  Shapes are fixed at construction."""
+
+    def __init__(self, trainer, batch_x, starts, warmup=2):
+        tr = self.tr = trainer
+        dev = batch_x.device
+        self.arena = train.StepArena()
+        tr.opt.make_capturable(dev)
+        self.x = batch_x.detach().to(torch.float32).clone().contiguous()
+        self.starts = torch.as_tensor(starts).to(device=dev, dtype=torch.int32).contiguous().clone()
+        self.lam = torch.zeros((), device=dev, dtype=torch.float32)
+        if warmup > 0:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._set_lam()
+                    self._body()
+                    self._advance()
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):        # see pccx.train.GraphedTrainStep on the mode
+            self.out = self._body()
+        self._grads = tr.opt._keep
+        tr.opt.flush_table()
+        for p in tr.opt.params:
+            p.grad = None
+
+    def _set_lam(self):
+        self.lam.fill_(0.0 if self.tr.global_step < self.tr.rate_loss_enable_step else self.tr.lamda)
+
+    def _advance(self):
+        tr = self.tr
+        tr.global_step += 1
+        if tr.global_step % tr.lr_decay_steps == 0:
+            tr.lr *= tr.lr_decay
+            tr.opt.set_lr(tr.lr)
+
+    def _body(self):
+        tr = self.tr
+        for p in tr.opt.params:
+            p.grad = None
+        train._AUTOCAST = tr.autocast
+        train._ARENA = self.arena
+        self.arena.begin(self.x.device)
+        try:
+            loss, fbpp, bpp = forward_loss(tr.ae, tr.prob, self.x, self.starts, self.lam, tr.S, tr.K, tr.N, tr.N0)
+            train._AUTOCAST = False
+            loss.backward()
+            tr.opt.step(max_norm=None)
+        finally:
+            train._AUTOCAST = False
+            train._ARENA = None
+            self.arena.end(self.x.device)
+        return loss.detach(), fbpp.detach(), bpp.detach()
+
+    def __call__(self, batch_x=None, starts=None, sync=True):
+        """one iteration on (batch_x, starts) (None = the buffers' current content) -> dict of floats, or of device scalars (sync=False)"""
+        if batch_x is not None:
+            self.x.copy_(batch_x)
+        if starts is not None:
+            self.starts.copy_(torch.as_tensor(starts).to(self.x.device, torch.int32))
+        self._set_lam()
+        self.graph.replay()
+        self.tr.opt.t += 1
+        self._advance()
+        keys = ("loss", "fbpp", "bpp")
+        return {k: float(v) for k, v in zip(keys, self.out)} if sync else dict(zip(keys, self.out))
