@@ -306,6 +306,33 @@ def cpu_baseline_pppe_train(state_dict, x, starts, budget_s):
                       f"train_pppe_pcd_ae.py:184-226 without autocast (torch autograd + torch.optim.Adam)", "ms_per_step": 1e3 * tot / n, "loss": loss}
 
 
+def cpu_baseline_ipdae_train(cfg, cloud, start, budget_s):
+    """The IPDAE training step beside the GPU number: oracle.ref_train.ipdae_train_step (train.py:162-236 restated on torch CPU, pinned to
+    the reference's own run by tests/test_train_ipdae.py) from the same weights on the same cloud; the brute-force Chamfer of 8192 x 8192
+    points makes one step seconds long, so the sample is a few steps (at least one after the warm-up)."""
+    from pccx import launch as _launch
+    _launch.restore_affinity()
+    import torch
+    from oracle import ref_model, ref_train
+    K, k, d, L = cfg
+    ae, prob = ref_model.AE(K=K, k=k, d=d, L=L), ref_model.ConditionalProbabilityModel(L, d)
+    ae.load_state_dict(ref_model.seeded_state_dict(ae, 3)), prob.load_state_dict(ref_model.seeded_state_dict(prob, 4, gain=2.0))
+    opt = torch.optim.Adam(list(ae.parameters()) + list(prob.parameters()), lr=5e-4)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    xb = cloud.cpu()
+    ref_train.ipdae_train_step(ae, prob, opt, xb, start, 1e-6, K=K)                    # warm-up, discarded
+    tot, n, t0 = 0.0, 0, time.time()
+    while n < 1 or time.time() - t0 < budget_s:
+        t1 = time.time()
+        out = ref_train.ipdae_train_step(ae, prob, opt, xb, start, 1e-6, K=K)
+        tot += time.time() - t1
+        n += 1
+    return {"value": n * xb.shape[0] / tot, "unit": "clouds/s", **cores_fields(), "kind": "port",
+            "sample": f"{n} optimisation step(s) on the GPU leg's first cloud ({xb.shape[1]} points, 64 patches of {K}), CPU restatement of "
+                      f"train.py:162-236 (torch autograd + torch.optim.Adam)", "ms_per_step": 1e3 * tot / n, "loss": out["loss"]}
+
+
 # =====================================================================================================================
 # distributed plumbing
 # =====================================================================================================================
@@ -1135,6 +1162,68 @@ def run_pppe_train(args, rk):
     return None
 
 
+def run_ipdae_train(args, rk):
+    """The IPDAE trainer's step (train.py:156-256, --model AE) at the reference's own shape: batch 1 (train.py:40: "must be 1"), 8192
+    points, K = 256 -> 64 patches of 256 points, d = 16, L = 7; one optimisation step per "step", captured as one hipGraph (selection
+    included) and, beside it, eager.  Not a BASELINE config (north_star names train.py's CLI); N > 1 runs independent replicas -- the
+    reference has no data-parallel form of this loop and none is invented."""
+    import numpy as np
+    import torch
+    from oracle import ref_model          # seeded weights only (the CPU leg's oracle starts from the same ones)
+    from pccx import models, synth, train_ipdae
+    K, k, d, L = 256, 128, 16, 7
+    n_clouds = 8
+    autocast = bool(args.autocast) if getattr(args, "autocast_given", False) else False    # fp32 is what the parity tests pin; --autocast = bf16
+    x = torch.from_numpy(np.stack([synth.cad_cloud(1200 + rk.rank * n_clouds + i, N_POINTS) for i in range(n_clouds)])).to(rk.dev)
+    rng = np.random.default_rng(rk.rank)
+    starts = rng.integers(0, N_POINTS, (n_clouds, 1))
+
+    def fresh():
+        ae, prob = models.AE(K=K, k=k, d=d, L=L), models.ConditionalProbabilityModel(L, d)
+        ae.load_state_dict(ref_model.seeded_state_dict(ae, 3)), prob.load_state_dict(ref_model.seeded_state_dict(prob, 4, gain=2.0))
+        return train_ipdae.IpdaeTrainer(ae.to(rk.dev), prob.to(rk.dev), N=N_POINTS, K=K, lr=5e-4, lamda=1e-6, rate_loss_enable_step=0,
+                                        autocast=autocast)
+    keep = {}
+    tr = fresh()
+    for i in range(max(args.warmup, 1)):
+        tr.step(x[i % n_clouds:i % n_clouds + 1], starts[i % n_clouds])
+    dt_e = timed(rk, lambda i: keep.__setitem__("e", tr.step(x[i % n_clouds:i % n_clouds + 1], starts[i % n_clouds])), args.steps,
+                 torch.cuda.synchronize)
+    tg = fresh()
+    gstep = tg.graphed(x[:1], starts[0], warmup=max(args.warmup, 1))
+    dstarts = torch.from_numpy(starts.astype(np.int32)).to(rk.dev)                       # the start indices live on the device, like the clouds
+    dt = timed(rk, lambda i: keep.__setitem__("g", gstep(x[i % n_clouds:i % n_clouds + 1], dstarts[i % n_clouds], sync=False)), args.steps,
+               torch.cuda.synchronize)
+    out = {k_: float(v) for k_, v in keep["g"].items()}
+    if rk.rank != 0:
+        return None
+    cpu = None
+    if cpu_leg_allowed(args, rk):
+        try:
+            cpu = cpu_baseline_ipdae_train((K, k, d, L), x[:1], starts[0], args.cpu_budget / 2)
+        except Exception as e:
+            cpu = {"error": repr(e)}
+    P, rows_sa = 64, 64 * K * 16
+    macs = (rows_sa * (3 * 32 + 32 * 64 + 64 * 128) + P * K * (131 * 128 + 128 * 256 + 256 * 512 + 512 * d)
+            + P * (d * 256 + 256 * 1024 + 1024 * k * 128) + P * k * ((128 + d) * 128 + 128 * 64 + 64 * 32 + 32 * 3)
+            + 64 * (3 * 64 + 64 * 128 + 128 * 256 + 259 * 512 + 512 * 512 + 512 * d * L))
+    flop = 3 * 2 * macs
+    ach = flop * args.steps / dt / 1e12
+    peak = BF16_DENSE_PEAK_TFLOPS if autocast else F32_MATRIX_PEAK_TFLOPS
+    return {"metric": "clouds/sec, IPDAE training step (train.py --model AE: forward+backward+Adam)", "value": rk.world * args.steps / dt,
+            "unit": "clouds/s", "patches_per_s": rk.world * 64 * args.steps / dt, "n_gpus": rk.world, **rk.info, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "ms_per_step_eager": 1e3 * dt_e / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast" if autocast else "f32", "data": "synthetic",
+            "config": {"workload": "IPDAE training step (train.py:156-256, --model AE), batch 1 x 8192 points, K=256 (64 patches), d=16, L=7",
+                       "parallelism": f"{rk.world} independent replica(s)", "weights": "seeded random",
+                       "launch": "one hipGraph replay per step, selection (normalize, FPS, octree, kNN) inside it"},
+            "roofline": {"kernel": "training step (forward + backward GEMMs)", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": None, "flop_per_step": flop,
+                         "note": "whole-step wall time over the algorithmic GEMM FLOPs (3x forward): ~400 small launches on 64 patches -- "
+                                 "latency-bound, not arithmetic-bound"},
+            "cpu_baseline": cpu, "gpu_over_cpu": (rk.world * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None, **out}
+
+
 def _printer(fn):
     def run(args, rk):
         res = fn(args, rk)
@@ -1143,7 +1232,7 @@ def _printer(fn):
     return run
 
 
-bench_s3dis, bench_pppf, bench_pppe_train = _printer(run_s3dis), _printer(run_pppf), _printer(run_pppe_train)
+bench_s3dis, bench_pppf, bench_pppe_train, bench_ipdae_train = _printer(run_s3dis), _printer(run_pppf), _printer(run_pppe_train), _printer(run_ipdae_train)
 
 
 def main():
@@ -1159,7 +1248,7 @@ def main():
     ap.add_argument("--one-mode", action="store_true", help="skip the second arithmetic mode")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="max clouds in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the baseline sample (2/3 all cores, 1/3 one thread)")
-    ap.add_argument("--workload", default="ipdae", choices=["ipdae", "s3dis", "pppf", "pppe-train", "launch-check"],
+    ap.add_argument("--workload", default="ipdae", choices=["ipdae", "s3dis", "pppf", "pppe-train", "ipdae-train", "launch-check"],
                     help="ipdae = the headline compress+decompress path (default); s3dis = configs[3] room-scale clouds in Morton "
                          "blocks; pppf = configs[2] PPPF_AE forward; pppe-train = the training step of configs[4]; "
                          "launch-check = no GPU work, exercises the N-rank launch and the summary all-gather")
@@ -1197,6 +1286,7 @@ def main():
             print("[bench] launcher parent is GPU-free (no torch import)", file=sys.stderr, flush=True)
         sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    args.autocast_given = args.autocast is not None
     args.autocast = not args.fp32 if args.autocast is None else bool(args.autocast)
     # NUMA placement of this rank's host side, from sysfs, BEFORE anything touches the GPU (pccx/launch.py)
     _, local_, _ = launch.rank_env()
@@ -1210,7 +1300,7 @@ def main():
         print(f"[bench] note: WORLD_SIZE={rk.world} from the launcher overrides --gpus {args.gpus}", file=sys.stderr)
     try:
         {"ipdae": bench_ipdae, "s3dis": bench_s3dis, "pppf": bench_pppf, "pppe-train": bench_pppe_train,
-         "launch-check": bench_launch_check}[args.workload](args, rk)
+         "ipdae-train": bench_ipdae_train, "launch-check": bench_launch_check}[args.workload](args, rk)
     finally:
         rk.close()
 

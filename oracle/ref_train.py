@@ -51,7 +51,7 @@ def train_step(model, opt, batch_x, starts, lam=1.0, grad_clip=1.0, chamfer_chun
     loss.backward()
     torch.nn.utils.clip_grad_norm_(list(model.parameters()), grad_clip)
     opt.step()
-    return float(loss), float(dist), float(rate)
+    return float(loss.detach()), float(dist.detach()), float(rate.detach())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -121,6 +121,15 @@ _BWD_SUMS = {}             # address of such a dY -> (shape, sums); consumed by 
 _FOLD_MOMENTS = os.environ.get("PCCX_NO_MOMENT_FOLD") != "1"      # experiment knob: 0 = every BatchNorm reduces its input itself
 
 
+def _is_wide(M, N, K):
+    """A handful of rows through a large weight matrix (the IPDAE decoder's Linear(1024, k * 128) on 64 patches, the pppe decoder's coarse
+    layer at batches above 8): the generic layer gives each workgroup four of the N / 16 column tiles and walks the K / 16 weight fragments
+    of those columns one dependent load after the other -- 1.5 ms for the dX of a 16384 x 1024 layer on 64 rows, a 67 MB weight read at
+    45 GB/s.  With the ROLES SWAPPED the weight matrix is the row operand the kernels stream at full rate: y^T = W x^T is pccx_linear
+    over N rows with the (few) activations packed as its weights, and dX^T = W^T dZ^T is pccx_linear_dw over the same N rows."""
+    return 8 < M <= 256 and M % 4 == 0 and N >= 1024 and N >= 8 * M and K % 4 == 0 and N * K >= (1 << 21)
+
+
 class LinearFn(torch.autograd.Function):
     """z = x W^T (+ b): nn.Linear / 1x1 Conv on channels-last rows.  want_moments (a Conv that feeds a train-mode BatchNorm): the GEMM's
     epilogue also accumulates the output's column moments (pccx_linear_moments) and BnReluFn takes them instead of reducing z again."""
@@ -139,11 +148,21 @@ class LinearFn(torch.autograd.Function):
         # base addresses are checked HERE (a (1, K) view keeps an arbitrary stride(0), a tensor with a storage offset can be misaligned) and
         # anything else takes the generic layer, as before round 3.
         ldx = K if x.shape[0] == 1 else x.stride(0)
+        ctx.wide = False
         ctx.skinny = (x.shape[0] <= 8 and K % 4 == 0 and ldx % 4 == 0 and ldx >= K and x.data_ptr() % 16 == 0 and W2.data_ptr() % 16 == 0)
         if ctx.skinny:
             out = torch.empty(x.shape[0], N, device=x.device, dtype=torch.float32)
             _lib.call("pccx_linear_skinny", x.data_ptr(), x.shape[0], K, ldx, W2.data_ptr(), b.data_ptr() if b is not None else None,
                       N, ctx.flags, out.data_ptr(), N, _stream())
+            return out
+        ctx.wide = x.is_cuda and _is_wide(x.shape[0], N, K) and x.stride(0) == K
+        if ctx.wide:
+            yT = _linear_raw(W2, _packed(x, False), None, x.shape[0], K, ctx.flags)     # (N, M) = W x^T
+            out = yT.t().contiguous()
+            if b is not None:
+                out += b
+                if ctx.flags & 2:
+                    out = out.bfloat16().float()                                        # the autocast layer rounds AFTER its bias
             return out
         if want_moments and b is None and _FOLD_MOMENTS and x.is_cuda:
             sums, pre = _sums(N, x.device)
@@ -166,6 +185,12 @@ class LinearFn(torch.autograd.Function):
             # generic path rounds its result to bf16 as well; the per-layer pin of tests/test_train_step.py holds either to one bf16 ulp)
             dx, _ = _zeros((M, K), torch.float32, dz.device)
             _lib.call("pccx_linear_skinny_dx", dz.data_ptr(), M, N, dz.stride(0), W2.data_ptr(), K, ctx.flags, dx.data_ptr(), K, _stream())
+        elif ctx.needs_input_grad[0] and ctx.wide:
+            # dX^T (K, M) = W^T dZ^T: the weight-gradient kernel with W as its "dZ" (N rows of K) and dZ^T as its "x" (N rows of M)
+            dzT = dz.t().contiguous()
+            dxT, _ = _zeros((K, M), torch.float32, dz.device)
+            _lib.call("pccx_linear_dw", W2.data_ptr(), dzT.data_ptr(), N, K, M, K, M, dxT.data_ptr(), ctx.flags, _stream())
+            dx = dxT.t().contiguous()
         elif ctx.needs_input_grad[0] and ctx.bn_in is not None and K % 4 == 0:
             # x is the output of a train-mode BatchNorm-ReLU: dX is that layer's dY, and the GEMM's epilogue accumulates the two column
             # sums its backward needs from the rows it has just produced (13 col_reduce4<1> launches per step otherwise)

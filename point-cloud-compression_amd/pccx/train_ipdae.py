@@ -26,9 +26,61 @@ from .train import GroupMaxFn, LinearFn, ReluFn
 OCTREE_BPP_DICT = {1024: 0.07, 512: 0.125, 256: 0.25, 128: 0.5, 64: 1.0}      # pn_kit.py:17-23
 
 
+class LinearReluFn(torch.autograd.Function):
+    """relu(x W^T + b) as ONE launch (pccx_linear with its ReLU epilogue) whose backward masks dY with the saved output: the separate
+    ReLU pass of pccx.train (z written, read back, y written) was a third of this step's activation traffic -- 64 patches x 256 points x
+    16 neighbours = 262 144 rows through the set-abstraction stack.  Same values as LinearFn + ReluFn."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        W2 = W.reshape(W.shape[0], -1).contiguous()
+        N, K = W2.shape
+        ctx.flags = 2 if train._AUTOCAST else 0
+        y = train._linear_raw(x, train._packed(W2, False), b, N, K, ctx.flags | 1)
+        ctx.save_for_backward(x, W2, y)
+        ctx.has_bias, ctx.wshape = b is not None, W.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2, y = ctx.saved_tensors
+        N, K = W2.shape
+        M = x.shape[0]
+        dz = torch.empty_like(y)
+        _lib.call("pccx_relu_backward", dy.contiguous().data_ptr(), y.data_ptr(), y.numel(), dz.data_ptr(), train._stream())
+        dx = train._linear_raw(dz, train._packed(W2, True), None, K, N, ctx.flags) if ctx.needs_input_grad[0] else None
+        dW, _ = train._zeros(tuple(W2.shape), torch.float32, dz.device)
+        _lib.call("pccx_linear_dw", dz.data_ptr(), x.data_ptr(), M, N, K, N, x.stride(0), dW.data_ptr(), ctx.flags, train._stream())
+        db = None
+        if ctx.has_bias:
+            db = torch.empty(N, device=dz.device, dtype=torch.float32)
+            sums, pre = train._sums(N, dz.device)
+            _lib.call("pccx_col_sum_w", dz.data_ptr(), M, N, sums.data_ptr(), db.data_ptr(), pre, train._stream())
+        return dx, dW.view(ctx.wshape), db
+
+
 def _lin(x, conv, relu):
+    N_, K_ = conv.weight.shape[0], conv.weight[0].numel()
+    if relu and x.shape[0] > 8 and not train._is_wide(x.shape[0], N_, K_):    # (a few rows: pccx.train's skinny / role-swapped layers)
+        return LinearReluFn.apply(x, conv.weight, conv.bias)
     y = LinearFn.apply(x, conv.weight, conv.bias)
     return ReluFn.apply(y) if relu else y
+
+
+def inpatch_neighbour_rows(x, nk):
+    """pn_kit.py:190-191 with S == N: for every point of every patch its nk nearest neighbours inside the patch, relative to the point ->
+    rows (P * K * nk, 3).  nk = 16 (AE.py:16) takes the codec's own selection kernel (pccx_patch_knn16: a byte per index; the SET of
+    pytorch3d's knn_points -- the order inside a group does not matter to the max-pool that follows) and a gather."""
+    P, K, _ = x.shape
+    if nk == 16 and K % 16 == 0 and 16 <= K <= 1024:
+        lib = _lib.load()
+        ib = int(lib.pccx_patch_knn16_index_bytes(K))
+        tab = torch.empty(int(lib.pccx_patch_knn16_bytes(P, K)), device=x.device, dtype=torch.uint8)
+        _lib.call("pccx_patch_knn16", x.data_ptr(), P, K, tab.data_ptr(), train._stream())
+        idx = tab.view(P, K, 16).to(torch.int64) if ib == 1 else (tab.view(torch.int16).view(P, K, 16).to(torch.int64) & 0xFFFF)
+        return (ops.index_points(x, idx) - x.view(P, K, 1, 3)).reshape(P * K * 16, 3).contiguous()
+    return ops.knn_points(x, x, nk, patch_scale=1.0).knn.reshape(P * K * nk, 3).contiguous()
 
 
 def ae_forward_train(ae, x_patches):
@@ -39,8 +91,7 @@ def ae_forward_train(ae, x_patches):
         raise _lib.PccxError(f"train_ipdae: AE was built for K={sa.npoint}, patches have {K} points")
     x = x_patches.detach().contiguous()
     with torch.no_grad():
-        # pn_kit.py:190-191: the 16 nearest neighbours of every point inside its patch, relative to the point (S == N: no sampling)
-        rows = ops.knn_points(x, x, sa.K, patch_scale=1.0).knn.reshape(P * K * sa.K, 3).contiguous()
+        rows = inpatch_neighbour_rows(x, sa.K)                                        # pn_kit.py:190-191
     h = _lin(rows, sa.conv0, True)                                                    # :198
     h = _lin(h, sa.conv1, True)                                                       # :199
     h = _lin(h, sa.conv2, sa.finalRelu)                                               # :201-205

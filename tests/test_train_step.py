@@ -22,7 +22,10 @@ def test_backward_primitives_match_autograd():
     from pccx import train
     rng = np.random.default_rng(0)
     # Linear: dX, dW, db
-    for M, K, N in [(1000, 195, 128), (37, 3, 32), (4, 512, 64), (300, 64, 1536)]:
+    # ... the last three are "wide" layers (train._is_wide: a handful of rows through a large weight matrix, evaluated with the roles of
+    # rows and weights swapped -- the IPDAE decoder's Linear(1024, 16384) on 64 patches, the pppe decoder's coarse layer at batch 16)
+    assert train._is_wide(64, 16384, 1024) and train._is_wide(16, 4096, 512) and not train._is_wide(300, 1536, 64) and not train._is_wide(4, 24576, 1024)
+    for M, K, N in [(1000, 195, 128), (37, 3, 32), (4, 512, 64), (300, 64, 1536), (64, 1024, 16384), (16, 512, 4096), (12, 1024, 2048)]:
         x = rng.standard_normal((M, K)).astype(np.float32)
         W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32)
