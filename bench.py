@@ -838,7 +838,8 @@ def bench_ipdae(args, rk):
         print(json.dumps(res), flush=True)
 
 
-SECONDARY = (("pppf", "run_pppf", {"batch": 256}), ("s3dis", "run_s3dis", {"batch": 1024}), ("pppe_train", "run_pppe_train", {"graph": True}))
+SECONDARY = (("pppf", "run_pppf", {"batch": 256}), ("s3dis", "run_s3dis", {"batch": 1024}), ("pppe_train", "run_pppe_train", {"graph": True}),
+             ("ipdae_train", "run_ipdae_train", {}))       # the last one is not a BASELINE config: train.py's step
 
 
 def run_secondaries(args, rk, headline, specs=None):
