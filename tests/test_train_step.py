@@ -772,8 +772,8 @@ def test_autocast_run_of_twenty_steps_stays_in_a_band_of_the_fp32_run():
     do not pin the optimisation; the reference trains in fp16 autocast with a GradScaler, train_pppe_pcd_ae.py:193,280, which this image
     cannot run).  Twenty clipped Adam steps from the same weights on the same 16-cloud batch with the same FPS draws, in fp32 and in bf16
     autocast: both bring the distortion below 2 % of its initial value, and the autocast run's distortion stays within 35 % of the fp32
-    run's at steps 5 and 10 (single trajectories diverge at the level of the quantiser's bin flips and of max-pool winners: measured
-    gaps of 2-22 %, in either direction)."""
+    run's at step 5 and within a factor of two at step 10 (single trajectories diverge at the level of the quantiser's bin flips and of
+    max-pool winners: measured gaps of 2-22 % at step 5, in either direction)."""
     import copy
     from pccx import families, synth as cloud_synth, train
     o = _models(2048)
@@ -794,7 +794,11 @@ def test_autocast_run_of_twenty_steps_stays_in_a_band_of_the_fp32_run():
     print("distortion bf16", ["%.5f" % v for v in hist["bf16"][::5] + hist["bf16"][-1:]])
     for name in hist:
         assert hist[name][-1] < 0.02 * hist[name][0], (name, hist[name][0], hist[name][-1])     # measured: 0.5 % of the initial distortion after 20 steps
-    for t in (4, 9):
-        a, b = hist["f32"][t], hist["bf16"][t]
-        assert abs(a - b) <= 0.35 * a, (t, a, b)
+    a, b = hist["f32"][4], hist["bf16"][4]
+    assert abs(a - b) <= 0.35 * a, (4, a, b)
+    # step 10 sits on the steep part of the curve (the distortion falls 8x between steps 5 and 10): the fp32 run ALONE lands anywhere in
+    # 0.0097 .. 0.0197 there from run to run (eight repeats, tools/experiments/r5/band_test_repeat.py: weight gradients and the few-row
+    # layers' dX are summed with fp32 atomics), so the comparison is a factor of two, not a percentage
+    a, b = hist["f32"][9], hist["bf16"][9]
+    assert 0.5 * a <= b <= 2.0 * a, (9, a, b)
     # by step 20 the fp32 run itself moves by +-20 % from run to run (0.0059 .. 0.0085 over three runs): no tighter band is meaningful there
