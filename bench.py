@@ -1170,7 +1170,6 @@ def run_ipdae_train(args, rk):
     reference has no data-parallel form of this loop and none is invented."""
     import numpy as np
     import torch
-    from oracle import ref_model          # seeded weights only (the CPU leg's oracle starts from the same ones)
     from pccx import models, synth, train_ipdae
     K, k, d, L = 256, 128, 16, 7
     n_clouds = 8
@@ -1181,7 +1180,7 @@ def run_ipdae_train(args, rk):
 
     def fresh():
         ae, prob = models.AE(K=K, k=k, d=d, L=L), models.ConditionalProbabilityModel(L, d)
-        ae.load_state_dict(ref_model.seeded_state_dict(ae, 3)), prob.load_state_dict(ref_model.seeded_state_dict(prob, 4, gain=2.0))
+        ae.load_state_dict(seeded_state_dict(ae, 3)), prob.load_state_dict(seeded_state_dict(prob, 4, gain=2.0))
         return train_ipdae.IpdaeTrainer(ae.to(rk.dev), prob.to(rk.dev), N=N_POINTS, K=K, lr=5e-4, lamda=1e-6, rate_loss_enable_step=0,
                                         autocast=autocast)
     keep = {}

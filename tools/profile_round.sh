@@ -17,7 +17,7 @@ timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-fo
 fi
 # the secondary workloads: bench line (with its CPU baseline) and kernel statistics of the same command without the CPU leg
 if [ -z "$PROFILE_SKIP_SECONDARY" ]; then
-WL=("s3dis" "pppf --batch 256" "pppe-train --graph")
+WL=("s3dis" "pppf --batch 256" "pppe-train --graph" "ipdae-train")
 for w in "${WL[@]}"; do
   n=$(echo $w | tr -d " -")
   timeout -k 10 400 python3 bench.py --workload $w > $O/$n.json 2> $O/$n.err; echo "$w bench rc=$?"
