@@ -49,6 +49,7 @@ def main():
     put_json("bench_under_rocprof.json", f"{a.round}_bench_under_rocprof.json")
     put_csv("trace/**/*kernel_stats.csv", f"{a.round}_kernel_stats.csv")
     put_csv("trace/**/*kernel_trace.csv", f"{a.round}_kernel_trace.csv")
+    put_csv("trace_headline/**/*kernel_stats.csv", f"{a.round}_headline_kernel_stats.csv")
     for wl in ("s3dis", "pppfbatch256", "pppetraingraph", "ipdaetrain"):
         put_json(f"{wl}.json", f"{a.round}_{wl}_bench.json")
         put_csv(f"trace_{wl}/**/*kernel_stats.csv", f"{a.round}_{wl}_kernel_stats.csv")

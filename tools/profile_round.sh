@@ -7,6 +7,9 @@ cd $GRAFT_REPO_ROOT
 if [ -z "$PROFILE_SKIP_MAIN" ]; then
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2> $O/trace.err; echo "trace rc=$?"
+# the headline legs alone: the kernel statistics whose sa_pn_forward_h2_kernel average is the HEADLINE's launches only (the default run's
+# statistics mix in the room-scale workload's launches of the same kernel, which cover fewer patches)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_headline -- python3 bench.py --steps 20 --warmup 5 --no-secondary --cpu-clouds 0 > $O/headline_under_rocprof.json 2> $O/trace_headline.err; echo "headline trace rc=$?"
 fi
 if [ -z "$PROFILE_SKIP_PMC" ]; then
 B="python3 bench.py --steps 1 --warmup 1 --batch 256 --cpu-clouds 0 --no-secondary --no-files"
