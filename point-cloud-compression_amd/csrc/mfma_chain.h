@@ -474,6 +474,13 @@ __device__ __forceinline__ void h2_split8(const f32x4 &v0, const f32x4 &v1, floa
 }
 
 #define H2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#ifdef H2_PRIO       // experiment (tools/experiments/r5): raise the wave's issue priority over its MFMA groups
+#define H2_PRIO_UP() __builtin_amdgcn_s_setprio(H2_PRIO)
+#define H2_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define H2_PRIO_UP()
+#define H2_PRIO_DOWN()
+#endif
 
 // dense layer on f16x2 operands with the weight blocks RESIDENT in LDS as [kt][mt][plane] fragments (K = 32 per kt); the three
 // products smallest first: (lo,hi) (hi,lo) (hi,hi).  SWAP as in dense_b3.
@@ -499,6 +506,7 @@ __device__ __forceinline__ void dense_h2(const f32x4 *w, int lane, const f16x8 (
         }
         const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG;
         __builtin_amdgcn_sched_barrier(0);
+        H2_PRIO_UP();
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -507,6 +515,7 @@ __device__ __forceinline__ void dense_h2(const f32x4 *w, int lane, const f16x8 (
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt][m0 + m] = SWAP ? H2_MFMA(in[nt][kt][PB[q]], cur[m][PA[q]], acc[nt][m0 + m])
                                            : H2_MFMA(cur[m][PA[q]], in[nt][kt][PB[q]], acc[nt][m0 + m]);
+        H2_PRIO_DOWN();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MG; ++m)
@@ -624,6 +633,7 @@ __device__ __forceinline__ void dense_h2_rd(RD &rd, int &f, const f16x8 (&in)[NT
         const int kt = gi / (MT / MG), m0 = (gi % (MT / MG)) * MG, f0 = f + 2 * gi * MG;
         rd.template need<2 * MG>(f0);
         __builtin_amdgcn_sched_barrier(0);
+        H2_PRIO_UP();
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -631,6 +641,7 @@ __device__ __forceinline__ void dense_h2_rd(RD &rd, int &f, const f16x8 (&in)[NT
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt][m0 + m] = H2_MFMA(rd.at(f0 + 2 * m + PA[q]), in[nt][kt][PB[q]], acc[nt][m0 + m]);
+        H2_PRIO_DOWN();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2 * MG; ++i) rd.done(f0 + i);
