@@ -37,6 +37,7 @@ parser.add_argument('--max_steps', type=int, default=80000, help='Train up to th
 parser.add_argument('--device', default='cuda', help='AE Model Device (cuda)')
 parser.add_argument('--reset', action='store_true', help='Reset training and start from scratch (ignore saved model).')
 parser.add_argument('--autocast', action='store_true', help='bf16 operands on the matrix cores (the reference wraps its CUDA step in autocast, train.py:175).')
+parser.add_argument('--eager', action='store_true', help='launch every kernel of every step from Python instead of replaying the captured step.')
 
 
 def latest(folder, prefix):
@@ -58,9 +59,6 @@ def load_checkpoints(tr, folder):                                               
         if p:
             print(f"Loading {prefix} from:", p)
             sd = torch.load(p, map_location="cpu", weights_only=True)                  # tensors, numbers and containers only
-            if prefix == "optimizer":
-                sd["state"] = {k: {kk: (vv.to(tr.opt.params[0].device) if torch.is_tensor(vv) and vv.dim() else vv) for kk, vv in st.items()}
-                               for k, st in sd["state"].items()}
             target.load_state_dict(sd)
     p = latest(folder, "global")
     if p:
@@ -103,6 +101,7 @@ def main():
     else:
         print("Resetting training from scratch.")
     losses, fbpps, bpps = [], [], []
+    graph = None                       # the iteration as one hipGraph (pccx.train_ipdae.GraphedIpdaeStep), captured on the first full batch
     for epoch in range(9999):
         order = torch.randperm(len(files))                                             # DataLoader(shuffle=True), train.py:117
         for b0 in range(0, len(files), args.batch_size):
@@ -110,7 +109,14 @@ def main():
                 break
             batch = data[order[b0:b0 + args.batch_size].to(args.device)]
             lr_before = tr.lr
-            out = tr.step(batch, torch.randint(0, N, (batch.shape[0],), dtype=torch.long))   # the draw of pn_kit.py:321
+            starts = torch.randint(0, N, (batch.shape[0],), dtype=torch.long)         # the draw of pn_kit.py:321
+            if args.eager or batch.shape[0] != args.batch_size:
+                out = tr.step(batch, starts)                                           # (a short last batch has another shape: eager)
+            elif graph is None:
+                graph = tr.graphed(batch, starts, warmup=1)                            # the warm-up iteration IS this step
+                out = {k_: float(v) for k_, v in zip(("loss", "fbpp", "bpp"), graph.warm_out)}
+            else:
+                out = graph(batch, starts)
             losses.append(out["loss"]), fbpps.append(out["fbpp"]), bpps.append(out["bpp"])
             if tr.global_step % args.step_window == 0:                                 # :241-247
                 print(f"[Epoch {epoch}] Step {tr.global_step} | Feature bpp: {np.mean(fbpps):.5f} | Bpp: {np.mean(bpps):.5f} | "

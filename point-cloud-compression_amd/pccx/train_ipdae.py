@@ -240,13 +240,14 @@ class GraphedIpdaeStep:
         self.x = batch_x.detach().to(torch.float32).clone().contiguous()
         self.starts = torch.as_tensor(starts).to(device=dev, dtype=torch.int32).contiguous().clone()
         self.lam = torch.zeros((), device=dev, dtype=torch.float32)
+        self.warm_out = None
         if warmup > 0:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
                     self._set_lam()
-                    self._body()
+                    self.warm_out = self._body()                     # (loss, fbpp, bpp) of the last warm-up iteration, device scalars
                     self._advance()
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
