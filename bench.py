@@ -415,9 +415,31 @@ class Ranks:
             dist.destroy_process_group()
 
 
+_SETTLED = [False]
+
+
+def settle(rk, seconds=0.3):
+    """Once per process, in front of its FIRST timed region: `seconds` of untimed GPU fill kernels.  On this pool a fresh process stalls once
+    for 50-90 ms somewhere in its first ~0.1 s of GPU activity (three probes, tools/experiments/r5/pppf_alloc_probe.py: the stall follows
+    the elapsed busy time, not the launch count, the allocator or a kernel -- a clock / power-state transition); a short workload (PPPF
+    forward: W = 2 warm-up steps of 6 ms) would otherwise time it inside its K steps (19 ms per step measured instead of 6.2)."""
+    if _SETTLED[0] or not getattr(rk, "gpu", False):
+        return
+    _SETTLED[0] = True
+    import torch
+    buf = torch.empty(64 << 20, device=rk.dev, dtype=torch.float32)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            buf.fill_(1.0)
+        torch.cuda.synchronize()
+    del buf
+
+
 def timed(rk, fn, steps, sync, tag=None):
     """EXACTLY ``steps`` calls of fn between barrier + synchronize on both sides; MAX over ranks.  With `tag`, each rank's time up to its
     own synchronize (before the closing barrier) is kept as well (Ranks.rank_ms)."""
+    settle(rk)
     rk.barrier()
     sync()
     t0 = time.perf_counter()
