@@ -181,16 +181,23 @@ def main():
     lib = families._lib.load()
     dyn1 = torch.ones(2, device=dev)
     for K_, N_, M_, epi, what in ((259, 256, PB * 128, 0, "sa3 layer 0"), (256, 256, PB * 128, 0, "sa3 layer 1"), (256, 512, PB * 128, 0, "sa3 layer 2"),
-                                  (512, 1024, PB * 128, 1, "sa3 layer 3 (fp32 rows out)"), (512, 512, PB * 256, 0, "FoldingNet mlp1 layer 1")):
+                                  (512, 1024, PB * 128, 1, "sa3 layer 3, fp32 rows out (the form before the union maximum)"),
+                                  (512, 1024, PB * 128, 3, "sa3 layer 3 as shipped: maximum over the member rows of each patch in the epilogue"),
+                                  (512, 512, PB * 256, 0, "FoldingNet mlp1 layer 1")):
         lyr = stack((N_,), K_)[0]
         families.h2_prepare_stack([lyr], np.zeros(K_), np.ones(K_))
         src = torch.rand(M_, K_, device=dev)
         pin = torch.empty(lib.pccx_planes_floats_h2(M_, K_), device=dev, dtype=torch.float32)
         families._lib.call("pccx_group_planes_h2", src.data_ptr(), K_, K_, None, 0, 0, None, M_, 1, 1, float(lyr.h2["sig"]), None, pin.data_ptr(), st_)
         del src
-        ms = timed(lambda: lyr.planes_h2(pin, M_, epi, 0, sig_next=lyr.h2["sig"], dyn=dyn1), args.iters)
+        if epi == 3:
+            member = (torch.rand(M_, device=dev) < 0.9).to(torch.uint8)
+            ms = timed(lambda: lyr.planes_h2(pin, M_, 2, group=128, dyn=dyn1, member=member), args.iters)
+        else:
+            ms = timed(lambda: lyr.planes_h2(pin, M_, epi, 0, sig_next=lyr.h2["sig"], dyn=dyn1), args.iters)
         row(f"planes_gemm f16x2 {K_}->{N_} on {M_} rows ({what})", ms, "mfma", 2.0 * M_ * K_ * N_, "TFLOP/s", round(MFMA_H2_PEAK, 1),
-            "csrc/planes.hip <2>: three fp16 MFMA products per fp32 product; 4 B per activation in" + (" and out" if epi == 0 else ", fp32 rows out"))
+            "csrc/planes.hip <2>: three fp16 MFMA products per fp32 product; 4 B per activation in" +
+            (" and out" if epi == 0 else ", fp32 rows out" if epi == 1 else ", one fp32 row per 128 out"))
         del pin
     for name, k0, widths, nsrc in (("sa1 3-3-64-64-128", 3, (3, 64, 64, 128), 512), ("sa2 131-128-128-128-256", 131, (128, 128, 128, 256), 512)):
         st = stack(widths, k0)
