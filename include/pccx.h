@@ -509,6 +509,10 @@ PCCX_API int pccx_rows_affine_small(const float *base, int C, int64_t div, const
  * y (B,N,C) fp32 rows, idx (B,M,ns) int64 with -1 padding -> out (B,M,C).  C % 4 == 0.  With it PointnetSAModule (which gathers
  * un-centred rows, :73-85) runs its Conv-BN-ReLU stack on the N source rows once instead of on M*ns copies of them. */
 PCCX_API int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream);
+/* The same maxima written as the NEXT level's input rows (pointnet_sa_module.py:83, features first, xyz last): out (B, M, ldo),
+ * ldo = 32 * ceil((C + 3) / 32): [C maxima | xyz (B, M, 3) of the centroids | zeros] -- what the gathering planes kernels read. */
+PCCX_API int pccx_gather_max_rows(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, const float *xyz, float *out, int ldo,
+                                  void *stream);
 /* torch.max(features, neighbour_dim)[0] (pointnet_sa_module.py:91, pppe_pcd_ae.py:610):
  * x (G,Kn,C) -> out (G,C). */
 PCCX_API int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream);

@@ -602,15 +602,26 @@ extern "C" int pccx_reassemble(const float *patches, int64_t P, int k, float sca
 }
 
 #define GM_THREADS 1024                    // 2 workgroups of 64 KB per CU = all 32 wave slots: the walk is a chain of dependent reads
+// the tail of cloud b's padded output rows (pccx_gather_max_rows): columns C .. C + 2 <- the centroids' coordinates, the rest <- 0
+__device__ __forceinline__ void gm_write_tail(float *__restrict__ out, const float *__restrict__ xyz, int b, int M, int C, int ldo, int tid)
+{
+    const int tw = ldo - C;
+    for (int e = tid; e < M * tw; e += GM_THREADS) {
+        const int g = e / tw, c = e - g * tw;
+        out[((size_t)b * M + g) * ldo + C + c] = c < 3 ? xyz[((size_t)b * M + g) * 3 + c] : 0.f;
+    }
+}
 template <bool LDS_TILE>
 __global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__restrict__ y, int B, int N, int C, const int64_t *__restrict__ idx,
-                                                                int M, int ns, int chunk, float *__restrict__ out)
+                                                                int M, int ns, int chunk, float *__restrict__ out, int ldo,
+                                                                const float *__restrict__ xyz)
 {
     extern __shared__ __attribute__((aligned(16))) float gm_tile[];
     const int c0 = blockIdx.x * chunk, tid = threadIdx.x;
     const int cw = min(chunk, C - c0), q4 = chunk >> 2;                      // chunk % 4 == 0, C % 4 == 0
     const int ldy4 = C >> 2;
   for (int b = blockIdx.y; b < B; b += gridDim.y) {                          // more clouds than the grid's y range: walk them
+    if (xyz && blockIdx.x == 0) gm_write_tail(out, xyz, b, M, C, ldo, tid);
     const float4 *y4 = (const float4 *)(y + (size_t)b * N * C + c0);
     if (LDS_TILE) {
         float4 *t4 = (float4 *)gm_tile;
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__r
             const float4 v = LDS_TILE ? t4[(int)jj * q4 + q] : y4[(size_t)jj * ldy4 + q];
             m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
-        ((float4 *)(out + ((size_t)b * M + g) * C + c0))[q] = m;
+        ((float4 *)(out + ((size_t)b * M + g) * ldo + c0))[q] = m;
     }
     if (LDS_TILE) __syncthreads();                                            // the tile is rewritten for the next cloud
   }
@@ -657,12 +668,14 @@ __global__ __launch_bounds__(GM_THREADS) void gather_max_kernel(const float *__r
 // is read from memory once per cloud instead of once per channel chunk -- it was 1.07 GB of the first level's 1.6 GB per 2048 patches --
 // and a group's walk chains LDS reads only.  Workgroup = cloud; tile = `chunk` channels of all N rows.
 __global__ __launch_bounds__(GM_THREADS) void gather_max_lds_idx_kernel(const float *__restrict__ y, int B, int N, int C, const int64_t *__restrict__ idx,
-                                                                        int M, int ns, int chunk, float *__restrict__ out)
+                                                                        int M, int ns, int chunk, float *__restrict__ out, int ldo,
+                                                                        const float *__restrict__ xyz)
 {
     extern __shared__ __attribute__((aligned(16))) float gm_tile[];
     const int tid = threadIdx.x, q4 = chunk >> 2, ldy4 = C >> 2;
     unsigned short *sidx = (unsigned short *)(gm_tile + (size_t)N * chunk);          // [M][ns] after the tile
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    if (xyz) gm_write_tail(out, xyz, b, M, C, ldo, tid);
     const int64_t *ib = idx + (size_t)b * M * ns;
     for (int i = tid; i < M * ns; i += GM_THREADS) {
         const long long j = ib[i];
@@ -696,19 +709,21 @@ __global__ __launch_bounds__(GM_THREADS) void gather_max_lds_idx_kernel(const fl
                 const float4 v = t4[(int)ig[s_] * q4 + q];
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
-            ((float4 *)(out + ((size_t)b * M + g) * C + c0))[q] = m;
+            ((float4 *)(out + ((size_t)b * M + g) * ldo + c0))[q] = m;
         }
     }
     __syncthreads();                                                                  // sidx / the tile are rewritten for the next cloud
   }
 }
 
-extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream)
+static int gather_max_launch(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, int ldo, void *stream,
+                             const float *xyz = nullptr)
 {
     if (B == 0 || M == 0) return PCCX_OK;   // empty batch: nothing to do, pointers may be null
     PCCX_CHECK_ARG(y && idx && out, "pccx_gather_max: null pointer");
     PCCX_CHECK_ARG(B > 0 && N >= 1 && M >= 1 && ns >= 1 && C >= 4 && C % 4 == 0, "pccx_gather_max: bad shape B=%d N=%d C=%d M=%d ns=%d (C %% 4 == 0)",
                    B, N, C, M, ns);
+    PCCX_CHECK_ARG(ldo >= C && ldo % 4 == 0 && (uintptr_t)out % 16 == 0, "pccx_gather_max: output rows of %d floats for %d channels (a multiple of 4, 16-byte aligned)", ldo, C);
     const unsigned gy = (unsigned)(B < 65535 ? B : 65535);
     {
         // index table in LDS (16-bit) + a 32 KB tile = at most 64 KB per workgroup: two workgroups per CU as before
@@ -719,7 +734,7 @@ extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_
             PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_max_lds_idx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                64 * 1024));
             hipLaunchKernelGGL(gather_max_lds_idx_kernel, dim3(gy), dim3(GM_THREADS), (size_t)N * ck * 4 + ib, (hipStream_t)stream, y, B, N, C, idx, M,
-                               ns, ck, out);
+                               ns, ck, out, ldo, xyz);
             PCCX_CHECK_LAUNCH();
             return PCCX_OK;
         }
@@ -730,14 +745,32 @@ extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_
         PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_max_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            64 * 1024));
         hipLaunchKernelGGL(gather_max_kernel<true>, dim3((C + chunk - 1) / chunk, gy), dim3(GM_THREADS), (size_t)N * chunk * 4, (hipStream_t)stream, y,
-                           B, N, C, idx, M, ns, chunk, out);
+                           B, N, C, idx, M, ns, chunk, out, ldo, xyz);
     } else {
         chunk = C < 256 ? C : 256;                                            // rows through L2: a workgroup per 256 channels
         hipLaunchKernelGGL(gather_max_kernel<false>, dim3((C + chunk - 1) / chunk, gy), dim3(GM_THREADS), 0, (hipStream_t)stream, y, B, N, C, idx,
-                           M, ns, chunk, out);
+                           M, ns, chunk, out, ldo, xyz);
     }
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
+}
+
+extern "C" int pccx_gather_max(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, float *out, void *stream)
+{
+    return gather_max_launch(y, B, N, C, idx, M, ns, out, C, stream);
+}
+
+// pccx_gather_max writing the NEXT set-abstraction level's input rows directly (pointnet_sa_module.py:83: features first, xyz last):
+// out (B, M, ldo) with ldo = 32 * ceil((C + 3) / 32) floats per row = [the C maxima | xyz (B, M, 3) of the centroids | zeros] -- the
+// padded fp32 rows the gathering forms of the planes kernels read (pccx_planes_chain4_gather_h2 / pccx_planes_gemm_gather_h2), so
+// the level's operand-plane pass (pccx_group_planes_h2: 1.2 GB of traffic for the second level of PPPF_AE on 2048 patches) is not run.
+extern "C" int pccx_gather_max_rows(const float *y, int B, int N, int C, const int64_t *idx, int M, int ns, const float *xyz, float *out, int ldo,
+                                    void *stream)
+{
+    if (B == 0 || M == 0) return PCCX_OK;
+    PCCX_CHECK_ARG(xyz, "pccx_gather_max_rows: null coordinates");
+    PCCX_CHECK_ARG(ldo == (C + 3 + 31) / 32 * 32, "pccx_gather_max_rows: rows of %d floats for %d + 3 channels, need %d", ldo, C, (C + 3 + 31) / 32 * 32);
+    return gather_max_launch(y, B, N, C, idx, M, ns, out, ldo, stream, xyz);     // the tails are written by the same kernel
 }
 
 extern "C" int pccx_group_max(const float *x, int64_t G, int Kn, int C, float *out, void *stream)

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "pccx_rows_affine_small": [_P, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int64, _P, _P],
     "pccx_rows_affine_planes": [_P, C.c_int, C.c_int64, _P, C.c_int, C.c_int, C.c_int64, _P, C.c_int, C.c_int64, _P, _P],
     "pccx_gather_max": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P],
+    "pccx_gather_max_rows": [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P],
     "pccx_group_max": [_P, C.c_int64, C.c_int, C.c_int, _P, _P],
     "pccx_planes_floats": [C.c_int64, C.c_int],
     "pccx_group_planes": [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P],

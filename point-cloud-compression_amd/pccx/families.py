@@ -384,6 +384,39 @@ def gather_max(y, idx):
     return out
 
 
+class PaddedRows:
+    """The input rows of a set-abstraction level as the gathering planes kernels read them: src (B, N, ldp) fp32 with ldp = 32 * ceil((C + 3) / 32),
+    row = [C features | xyz | zeros] (pointnet_sa_module.py:83: features first, xyz last)."""
+
+    def __init__(self, src, C):
+        self.src, self.C = src, int(C)
+
+
+def gather_max_rows(y, idx, new_xyz):
+    """gather_max whose output IS the next level's input rows (pccx_gather_max_rows): -> PaddedRows((B, M, ldp), C)"""
+    B, N, Cc = y.shape
+    _, M, ns = idx.shape
+    ldp = (Cc + 3 + 31) // 32 * 32
+    out = torch.empty(B, M, ldp, device=y.device, dtype=torch.float32)
+    _lib.call("pccx_gather_max_rows", y.contiguous().data_ptr(), B, N, Cc, idx.contiguous().data_ptr(), M, ns, new_xyz.contiguous().data_ptr(),
+              out.data_ptr(), ldp, _stream())
+    return PaddedRows(out, Cc)
+
+
+_IDENTITY = {}
+
+
+def identity_index(P, n, device):
+    """(P * n) int64: 0 .. n - 1 for each of the P batch elements (the gathering kernels' index of the rows as they stand)"""
+    key = (int(P), int(n), str(device))
+    t = _IDENTITY.get(key)
+    if t is None:
+        if len(_IDENTITY) > 8:
+            _IDENTITY.clear()
+        t = _IDENTITY[key] = torch.arange(n, device=device, dtype=torch.int64).repeat(P).contiguous()
+    return t
+
+
 def group_max(x):
     """(G,Kn,C) -> (G,C)."""
     G, Kn, Cc = x.shape
@@ -454,6 +487,10 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
     # run_union_max() marks those rows (pccx_group_members) and takes that maximum in the last layer's epilogue -- neither the layer's
     # fp32 rows (1 GB per 2048 patches) nor the per-centroid table exist.  union_max=False keeps gather_max + group_max (tests compare).
     union_max = True
+    # Between the f16x2 levels the maxima are written as the next level's padded input rows (pccx_gather_max_rows) and that level's first
+    # kernel gathers them itself (the gathering forms of the chain / GEMM with an identity index): the operand-plane pass of levels 2 and 3
+    # (pccx_group_planes_h2: 0.23 + 0.11 ms per 2048 patches) is not run.  Same planes, same results; False keeps the plane pass (tests compare).
+    padded_levels = True
 
     def run_union_max(self, stack, xyz, feats, h2):
         """max over the npoint centroids of the level's output (B, C'), f16x2 arithmetic; needs N in {32, 64, 128} source rows per element"""
@@ -466,50 +503,72 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
             _lib.call("pccx_group_members", idx.data_ptr(), idx.numel(), self.npoint * self.nsample, N, member.data_ptr(), _stream())
         with stage("sa_stack_%d" % stack[-1].N):
             dyn, _ = h2
-            f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
-            x2 = xyz.reshape(-1, 3).contiguous()
-            C0 = int(f2.shape[1]) if f2 is not None else 0
-            pl = torch.empty(_lib.load().pccx_planes_floats_h2(B * N, C0 + 3), device=x2.device, dtype=torch.float32)
-            _lib.call("pccx_group_planes_h2", f2.data_ptr() if f2 is not None else None, C0, C0, x2.data_ptr(), 3, 3, None, B * N, 1, 1,
-                      float(stack[0].h2["sig"]), dyn.data_ptr(), pl.data_ptr(), _stream())
-            for i, layer in enumerate(stack[:-1]):
+            if isinstance(feats, PaddedRows):
+                pl, first = self._h2_first_layer_gathered(stack, feats, dyn, stack[1].h2["sig"]), 1
+            else:
+                f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
+                x2 = xyz.reshape(-1, 3).contiguous()
+                C0 = int(f2.shape[1]) if f2 is not None else 0
+                pl, first = torch.empty(_lib.load().pccx_planes_floats_h2(B * N, C0 + 3), device=x2.device, dtype=torch.float32), 0
+                _lib.call("pccx_group_planes_h2", f2.data_ptr() if f2 is not None else None, C0, C0, x2.data_ptr(), 3, 3, None, B * N, 1, 1,
+                          float(stack[0].h2["sig"]), dyn.data_ptr(), pl.data_ptr(), _stream())
+            for i, layer in enumerate(stack[first:-1], start=first):
                 pl = layer.planes_h2(pl, B * N, 0, sig_next=stack[i + 1].h2["sig"], dyn=dyn)
             return stack[-1].planes_h2(pl, B * N, 2, group=N, dyn=dyn, member=member)
 
-    def run(self, stack, xyz, feats, h2=None):
+    def run(self, stack, xyz, feats, h2=None, pad_out=False):
         """xyz (B,N,3); feats (B,N,C) channels-last or None -> (new_xyz (B,M,3), feats (B,M,C')).
         h2 = (dyn, amax_out): evaluate the stack in the f16x2 arithmetic (h2_prepare_stack has run): dyn = the level's dynamic input
-        normalisation {s, 1 / s} on the device, amax_out = 8 floats that receive the largest value of the stack's output."""
+        normalisation {s, 1 / s} on the device, amax_out = 8 floats that receive the largest value of the stack's output.  With h2, feats
+        may be a PaddedRows (the previous level's pad_out) and pad_out=True returns one: the maxima written as the NEXT level's input rows
+        [features | new_xyz | 0], which its first kernel gathers itself -- no operand-plane pass between the levels."""
         B = xyz.shape[0]
         with stage("fps"):
             new_xyz, _ = ops.sample_farthest_points(xyz, self.npoint)               # :66-68 (start index 0)
         with stage("ball_query"):
             idx = ops.ball_query(new_xyz, xyz, self.nsample, self.radius).idx       # :71 (-1 padded; gather clamps, :27)
         if self.dedup and B > 0 and stack[-1].N % 4 == 0:
-            return new_xyz, self._run_dedup(stack, xyz, feats, idx, B, h2)
+            return new_xyz, self._run_dedup(stack, xyz, feats, idx, B, h2, new_xyz if pad_out else None)
         if h2 is not None:
             raise _lib.PccxError("PointnetSAModule: the f16x2 stacks are built for the source-row evaluation (dedup=True)")
         return self._run_grouped(stack, xyz, feats, idx, new_xyz, B)
 
-    def _run_dedup_h2(self, stack, f2, x2, rows_n, C0, h2):
+    def _h2_first_layer_gathered(self, stack, padded, dyn, sig_next):
+        """the stack's first layer on PaddedRows through the gathering GEMM (identity index): -> planes of sig_next * output"""
+        l0, src = stack[0], padded.src
+        Bn, n_src, ldp = src.shape
+        M = Bn * n_src
+        out = torch.empty(_lib.load().pccx_planes_floats_h2(M, l0.N), device=src.device, dtype=torch.float32)
+        _lib.call("pccx_planes_gemm_gather_h2", src.data_ptr(), ldp, identity_index(Bn, n_src, src.device).data_ptr(), n_src, n_src, M, l0.K,
+                  l0.h2["ws"].data_ptr(), l0.h2["b"].data_ptr(), l0.N, l0.relu, 0, 0, float(l0.h2["sig"]),
+                  float(sig_next) / (l0.h2["sig"] * l0.h2["tau"]), dyn.data_ptr(), None, out.data_ptr(), l0.N, _stream())
+        return out
+
+    def _run_dedup_h2(self, stack, f2, x2, rows_n, C0, h2, padded=None):
         """the stack on the source rows in the f16x2 arithmetic: rows -> planes of sigma_0 s [features, xyz], then ONE chain kernel (sa1 /
-        sa2) or the layers one by one (sa3), the last with the row epilogue that un-scales and records the output's maximum"""
+        sa2) or the layers one by one (sa3), the last with the row epilogue that un-scales and records the output's maximum.  padded: the
+        rows as the previous level wrote them (PaddedRows): the first kernel gathers and splits them itself, no planes pass."""
         dyn, amax_out = h2
         lib = _lib.load()
+        ap = amax_out.data_ptr() if amax_out is not None else None
+        if padded is not None and chain4_fits(stack):
+            ws, sc, a = self._chain2_args(stack)
+            src = padded.src
+            y = torch.empty(rows_n, stack[3].N, device=src.device, dtype=torch.float32)
+            _lib.call("pccx_planes_chain4_gather_h2", src.data_ptr(), src.shape[2], identity_index(src.shape[0], src.shape[1], src.device).data_ptr(),
+                      src.shape[1], src.shape[1], rows_n, stack[0].K, ws.data_ptr(), *a, 1, sc.ctypes.data, dyn.data_ptr(), ap, y.data_ptr(),
+                      stack[3].N, _stream())
+            return y
+        if padded is not None:
+            pl = self._h2_first_layer_gathered(stack, padded, dyn, stack[1].h2["sig"])
+            for i, layer in enumerate(stack[1:-1], start=1):
+                pl = layer.planes_h2(pl, rows_n, 0, sig_next=stack[i + 1].h2["sig"], dyn=dyn)
+            return stack[-1].planes_h2(pl, rows_n, 1, dyn=dyn, amax=amax_out)
         pl = torch.empty(lib.pccx_planes_floats_h2(rows_n, C0 + 3), device=x2.device, dtype=torch.float32)
         _lib.call("pccx_group_planes_h2", f2.data_ptr() if f2 is not None else None, C0, C0, x2.data_ptr(), 3, 3, None, rows_n, 1, 1,
                   float(stack[0].h2["sig"]), dyn.data_ptr(), pl.data_ptr(), _stream())
-        ap = amax_out.data_ptr() if amax_out is not None else None
         if chain4_fits(stack):
-            if getattr(self, "_chain2_of", None) is not stack:
-                h = [l.h2 for l in stack]
-                sc = np.array([h[0]["sig"]] + [h[i]["sig"] / (h[i - 1]["sig"] * h[i - 1]["tau"]) for i in (1, 2, 3)] +
-                              [1.0 / (h[3]["sig"] * h[3]["tau"])], dtype=np.float32)
-                self._chain2_of, self._chain2 = stack, (torch.cat([x["ws"] for x in h]), sc)
-            ws, sc = self._chain2
-            a = []
-            for l in stack:
-                a += [l.h2["b"].data_ptr(), l.N]
+            ws, sc, a = self._chain2_args(stack)
             y = torch.empty(rows_n, stack[3].N, device=x2.device, dtype=torch.float32)
             _lib.call("pccx_planes_chain4_h2", pl.data_ptr(), rows_n, stack[0].K, ws.data_ptr(), *a, 1, sc.ctypes.data, dyn.data_ptr(), ap,
                       y.data_ptr(), stack[3].N, _stream())
@@ -518,9 +577,24 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
             pl = layer.planes_h2(pl, rows_n, 0, sig_next=stack[i + 1].h2["sig"], dyn=dyn)
         return stack[-1].planes_h2(pl, rows_n, 1, dyn=dyn, amax=amax_out)
 
-    def _run_dedup(self, stack, xyz, feats, idx, B, h2=None):
+    def _chain2_args(self, stack):
+        """the f16x2 chain's weight stream, its five scales and its (bias, width) arguments, once per pack"""
+        if getattr(self, "_chain2_of", None) is not stack:
+            h = [l.h2 for l in stack]
+            sc = np.array([h[0]["sig"]] + [h[i]["sig"] / (h[i - 1]["sig"] * h[i - 1]["tau"]) for i in (1, 2, 3)] +
+                          [1.0 / (h[3]["sig"] * h[3]["tau"])], dtype=np.float32)
+            self._chain2_of, self._chain2 = stack, (torch.cat([x["ws"] for x in h]), sc)
+        ws, sc = self._chain2
+        a = []
+        for l in stack:
+            a += [l.h2["b"].data_ptr(), l.N]
+        return ws, sc, a
+
+    def _run_dedup(self, stack, xyz, feats, idx, B, h2=None, pad_xyz=None):
         with stage("sa_stack_%d" % stack[-1].N):
-            if h2 is not None:
+            if h2 is not None and isinstance(feats, PaddedRows):
+                y = self._run_dedup_h2(stack, None, None, B * xyz.shape[1], feats.C, h2, padded=feats)
+            elif h2 is not None:
                 f2 = feats.reshape(-1, feats.shape[-1]).contiguous() if feats is not None else None
                 x2 = xyz.reshape(-1, 3).contiguous()
                 y = self._run_dedup_h2(stack, f2, x2, x2.shape[0], int(f2.shape[1]) if f2 is not None else 0, h2)
@@ -547,6 +621,8 @@ class PointnetSAModule(nn.Module):                      # pointnet_sa_module.py:
                 rows = cat_rows([feats, xyz] if feats is not None else [xyz])
                 y = run_stack(stack, rows)
         with stage("gather_max"):
+            if pad_xyz is not None:
+                return gather_max_rows(y.view(B, xyz.shape[1], -1), idx, pad_xyz)   # :91, written as the next level's input rows
             return gather_max(y.view(B, xyz.shape[1], -1), idx)                     # :91 max over the group's members
 
     def _run_grouped(self, stack, xyz, feats, idx, new_xyz, B):
@@ -664,7 +740,8 @@ class PPPF_AE(_Packable):
             if (lvl == 2 and mod.union_max and pts.shape[1] in (32, 64, 128) and stack[-1].relu and not chain4_fits(stack)):
                 feats = mod.run_union_max(stack, pts, feats, (dy(lvl), None))       # (B, dim): :44 and :91 of the level in one epilogue
                 continue
-            pts, feats = mod.run(stack, pts, feats, h2=(dy(lvl), am(lvl + 1) if lvl < 2 else None))
+            pts, feats = mod.run(stack, pts, feats, h2=(dy(lvl), am(lvl + 1) if lvl < 2 else None),
+                                 pad_out=lvl < 2 and PointnetSAModule.padded_levels)
         with stage("latent"):
             g = group_max(feats) if feats.dim() == 3 else feats                     # :44 max over the 32 points
             latent = sigmoid_spread(g, self.L)                                      # :136-137

@@ -220,6 +220,49 @@ def test_third_level_union_maximum_equals_gather_max_then_group_max_bit_for_bit(
 
 
 @pytest.mark.gpu
+def test_padded_rows_between_the_levels_equal_the_operand_plane_pass_bit_for_bit(oracle_nets):
+    """Between the f16x2 levels of PPPF_AE the group maxima are written as the next level's input rows [features | xyz | 0]
+    (pccx_gather_max_rows) and that level's first kernel gathers and splits them itself (pccx_planes_chain4_gather_h2 /
+    pccx_planes_gemm_gather_h2 with an identity index) instead of reading operand planes built by pccx_group_planes_h2.  Against the
+    plane pass (padded_levels=False): IDENTICAL latents, symbols and reconstructions, with either form of the third level; and
+    pccx_gather_max_rows against pccx_gather_max + the tail it appends."""
+    import pccx
+    from pccx import _lib, families
+    m, _ = oracle_nets
+    g = families.PPPF_AE(512, 0, 16, 7)
+    g.load_state_dict(m.state_dict())
+    rng = np.random.default_rng(13)
+    old = pccx.DEFAULT_MATMUL
+    try:
+        pccx.DEFAULT_MATMUL = "f16x2"
+        for x in (synth.pppf_input(), (rng.random((5, 512, 3)) * 1.6).astype(np.float32), (rng.random((3, 512, 3)) * 30).astype(np.float32)):
+            xc = torch.from_numpy(x).cuda()
+            for um in (True, False):
+                families.PointnetSAModule.union_max = um
+                try:
+                    assert families.PointnetSAModule.padded_levels
+                    a = g(xc)
+                    families.PointnetSAModule.padded_levels = False
+                    b = g(xc)
+                finally:
+                    families.PointnetSAModule.padded_levels = True
+                    families.PointnetSAModule.union_max = True
+                for u, v in zip(a, b):
+                    assert torch.equal(u, v)
+    finally:
+        pccx.DEFAULT_MATMUL = old
+    B, N, C, M, ns = 3, 64, 132, 10, 7                                                # C + 3 = 135 -> rows of 160 floats
+    y = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32)).cuda()
+    idx = torch.from_numpy(rng.integers(-1, N, (B, M, ns))).cuda()
+    cxyz = torch.from_numpy(rng.standard_normal((B, M, 3)).astype(np.float32)).cuda()
+    pr = families.gather_max_rows(y, idx, cxyz)
+    assert pr.C == C and tuple(pr.src.shape) == (B, M, 160)
+    assert torch.equal(pr.src[..., :C], families.gather_max(y, idx)) and torch.equal(pr.src[..., C:C + 3], cxyz) and not pr.src[..., C + 3:].any()
+    with pytest.raises(_lib.PccxError):
+        _lib.call("pccx_gather_max_rows", y.data_ptr(), B, N, C, idx.data_ptr(), M, ns, cxyz.data_ptr(), pr.src.data_ptr(), 136, None)
+
+
+@pytest.mark.gpu
 def test_pointnet_sa_module_on_source_rows_equals_the_grouped_evaluation_bit_for_bit(oracle_nets, matmul_mode):
     """PointnetSAModule gathers features and xyz un-centred (pointnet_sa_module.py:73-85), so each grouped row is a copy of a source
     row: families.PointnetSAModule evaluates its Conv-BN-ReLU stack on the N source rows and takes every group's maximum from that
