@@ -233,22 +233,27 @@ __device__ __forceinline__ void wave_argmax(float &v, int &i)
     for (int r = 1; r < 4; ++r) argmax_merge(v, i, rv[r], ri[r]);
 }
 
-// USE_LDS (the cloud's copy fits the LDS) is a template parameter: as a run-time flag the round's one load of the winner's coordinates
-// -- `use_lds ? sx + 3 far : p + 3 far` -- became a FLAT load (one pointer that may be LDS or global), whose round trip waits on both
-// memory counters; it sits on the serial path of every round.
+// The winner's COORDINATES travel with its key.  Rounds 2-4 kept a copy of the cloud in LDS (96 KB for 8192 points) only to read the
+// coordinates of the point a round selects, which held the kernel to one workgroup per CU.  Here every lane carries the coordinates of
+// its own best point through the lane's scan (three more selects per point), the lane that owns the wave's winner parks them beside the
+// wave's key, and after the barrier the winning wave's slot is read -- the same depth of dependent LDS reads as before (key, then
+// coordinates), 768 B of LDS per workgroup, so TWO 1024-thread workgroups share a CU (57 registers: 8 waves per SIMD) and one cloud's
+// barrier waits run under the other's arithmetic.  Measured (1024 clouds of 8192 points, 64 samples): 0.377 -> 0.361 ms -- a round turns
+// out to be bound by the EXECUTION of its vector instructions (16 waves x ~100 instructions x 4 cycles on 4 SIMDs ~ 0.7 us of a 1.47 us
+// round), not by its latencies, so the second workgroup buys only the barrier waits.  Indices: the same arithmetic per point, the same
+// first-maximum rule (bit-identical).  The second template parameter is unused (kept for the instantiation names in the profiles).
 template <int PPT, bool USE_LDS>
 __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
                                                    const int32_t *__restrict__ start, int64_t *__restrict__ out)
 {
-    extern __shared__ float smem[];
-    unsigned long long *part_k = (unsigned long long *)smem;   // [2][16] wave winners as 64-bit keys (argmax_key)
-    float *sx = smem + 64;                // [3N] when use_lds
+    __shared__ unsigned long long part_k[2][16];              // wave winners as 64-bit keys (argmax_key)
+    __shared__ float part_c[2][16][4];                        // ... and their coordinates
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *p = xyz + (size_t)b * N * 3;
 
     // Points live in registers in PAIRS (point tid + 2j*1024 and tid + (2j+1)*1024): the three differences, squares and the two adds
     // of a round run as packed fp32 (v_pk_add_f32 / v_pk_mul_f32, no contraction: -ffp-contract=off), i.e. the operation sequence
-    // of pccx_sqdist per point at half the instruction count -- a round is bound by the VALU work of the CU's 8192 points.
+    // of pccx_sqdist per point at half the instruction count.
     constexpr int PP = (PPT + 1) / 2;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 px[PP], py[PP], pz[PP], md[PP];
@@ -265,19 +270,14 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
                 md[j][e] = -INFINITY;          // never selected
             }
         }
-    if (USE_LDS)
-        for (int i = tid; i < 3 * N; i += 1024) sx[i] = p[i];
-    __syncthreads();
 
     int far = start ? start[b] : 0;
     if (far < 0 || far >= N) far = 0;
+    float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];     // the first centroid's coordinates: one read from memory
     int par = 0;
     for (int s = 0; s < npoint; ++s) {
         if (tid == 0) out[(size_t)b * npoint + s] = far;             // centroids[:, i] = farthest (:324)
-        float cx, cy, cz;
-        if (USE_LDS) { cx = sx[3 * far]; cy = sx[3 * far + 1]; cz = sx[3 * far + 2]; }
-        else { cx = p[3 * far]; cy = p[3 * far + 1]; cz = p[3 * far + 2]; }
-        float best = -INFINITY;
+        float best = -INFINITY, bx = 0.f, by = 0.f, bz = 0.f;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
@@ -291,13 +291,23 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float *__restrict__ xyz
                 const bool up = md[j][e] > best;                              // ascending index, strict '>'
                 best = up ? md[j][e] : best;
                 bi = up ? tid + (2 * j + e) * 1024 : bi;
+                bx = up ? px[j][e] : bx;
+                by = up ? py[j][e] : by;
+                bz = up ? pz[j][e] : bz;
             }
         }
-        const unsigned long long wk = wave_argmax_key(argmax_key(best, bi));
-        if (lane == 0) part_k[par * 16 + w] = wk;
+        const unsigned long long mk = argmax_key(best, bi);
+        const unsigned long long wk = wave_argmax_key(mk);
+        if (mk == wk) {                        // the owner of the wave's winner (indices are distinct; lanes with no point tie on -inf and write zeros)
+            part_k[par][w] = wk;
+            part_c[par][w][0] = bx; part_c[par][w][1] = by; part_c[par][w][2] = bz;
+        }
         __syncthreads();
-        const unsigned long long vk = row16_argmax_key(part_k[par * 16 + (lane & 15)]);   // the 16 wave winners, one per lane of every row
+        const unsigned long long k16 = part_k[par][lane & 15];       // the 16 wave winners, one per lane of every row
+        const unsigned long long vk = row16_argmax_key(k16);
         far = __builtin_amdgcn_readfirstlane(argmax_key_index(vk));   // torch.max(distance,-1)[1] (:329)
+        const int ww = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(k16 == vk)) - 1) & 15;
+        cx = part_c[par][ww][0]; cy = part_c[par][ww][1]; cz = part_c[par][ww][2];
         par ^= 1;
     }
 }
@@ -407,15 +417,7 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
 template <int PPT>
 static int launch_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int64_t *out, hipStream_t st)
 {
-    const bool use_lds = (size_t)N * 12 + 256 <= 150 * 1024;
-    const size_t shmem = 256 + (use_lds ? (size_t)N * 12 : 0);
-    if (use_lds) {
-        PCCX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<PPT, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((fps_kernel<PPT, true>), dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out);
-    } else {
-        hipLaunchKernelGGL((fps_kernel<PPT, false>), dim3(B), dim3(1024), shmem, st, xyz, N, npoint, start, out);
-    }
+    hipLaunchKernelGGL((fps_kernel<PPT, true>), dim3(B), dim3(1024), 0, st, xyz, N, npoint, start, out);
     PCCX_CHECK_LAUNCH();
     return PCCX_OK;
 }
