@@ -330,7 +330,8 @@ def cpu_baseline_ipdae_train(cfg, cloud, start, budget_s):
         n += 1
     return {"value": n * xb.shape[0] / tot, "unit": "clouds/s", **cores_fields(), "kind": "port",
             "sample": f"{n} optimisation step(s) on the GPU leg's first cloud ({xb.shape[1]} points, 64 patches of {K}), CPU restatement of "
-                      f"train.py:162-236 (torch autograd + torch.optim.Adam)", "ms_per_step": 1e3 * tot / n, "loss": out["loss"]}
+                      f"train.py:162-236 (torch autograd + torch.optim.Adam; the Chamfer term by brute force over 8192 x 8192 pairs -- pytorch3d is "
+                      f"absent here -- which is most of a step)", "ms_per_step": 1e3 * tot / n, "loss": out["loss"]}
 
 
 # =====================================================================================================================
