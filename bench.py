@@ -1021,6 +1021,28 @@ def run_pppf(args, rk):
                 cpu = cpu_baseline_pppf(model.state_dict(), patches[:min(patches.shape[0], 256)], Kp, args.cpu_budget / 2)
             except Exception as e:
                 cpu = {"error": repr(e)}
+        # agreement of the quoted arithmetic with the other two on the TIMED patches (the headline's f16x2_vs_f32, for this family): one
+        # forward each, outside every timed region
+        agree = None
+        if args.matmul == "f16x2" and "h2" in (model._packed or {}):
+            import pccx as _pccx
+            try:
+                got = [t.clone() for t in keep["o"]]
+                agree = {}
+                for other in ("bf16x3", "f32"):
+                    _pccx.DEFAULT_MATMUL = other
+                    ref = model(patches)
+                    same = (got[2] == ref[2]).all(dim=1)
+                    agree[other] = {"patches": int(got[2].shape[0]), "symbols": int(got[2].numel()), "symbols_differing": int((got[2] != ref[2]).sum()),
+                                    "max_latent_diff": float((got[1] - ref[1]).abs().max()),
+                                    "max_recon_diff_where_symbols_agree": float((got[0] - ref[0])[same].abs().max()) if bool(same.any()) else None}
+                    del ref
+                agree["note"] = ("rec / latent / symbols of ONE forward on the timed patches in f16x2 against the same forward in bf16x3 and in exact "
+                                 "fp32 (generic layers); tests/test_families.py holds all three to the reference fixture at the same tolerances")
+            except Exception as e:
+                agree = {"error": repr(e)}
+            finally:
+                _pccx.DEFAULT_MATMUL = args.matmul
         rf = None
         # the arithmetic that RUNS: the planes stacks (set abstraction, FoldingNet chains) take the flag's arithmetic -- f16x2 since round 5 --
         # while the four small Linears on one row per patch (latent projections, the folding MLPs' per-patch parts) stay bf16x3
@@ -1046,7 +1068,7 @@ def run_pppf(args, rk):
             "config": {"workload": "PPPF_AE K=512 d=16 (configs[2]): 2048-pt ShapeNet-shaped clouds, 8 patches per cloud", "matmul": eff_matmul,
                        "matmul_requested": args.matmul,
                        "clouds_per_gpu_per_step": B, "patches_per_step": B * S, "weights": "seeded random"},
-            "roofline": rf, "stage_ms_per_step": stage_ms, "cpu_baseline": cpu,
+            "roofline": rf, "stage_ms_per_step": stage_ms, "f16x2_vs_other_arithmetics": agree, "cpu_baseline": cpu,
             "gpu_over_cpu": (rk.world * B * S * Kp * args.steps / dt / cpu["value"]) if cpu and "value" in cpu else None})
     return None
 
